@@ -1,0 +1,282 @@
+"""ctypes mirror of include/fabber_vb.h (the C ABI of the HIP voxelwise-VB engine).
+
+Only plain data lives here: structure layouts, enum values and a helper that resolves the
+built-in models' parameter defaults into an ``fvb_config`` the same way the reference's
+``FwdModel::GetParameters`` (fwdmodel.cc:210-282) and ``WhiteNoiseModel::HardcodedInitialDists``
+(noisemodel_white.cc:127-164) do. The C++ host library does the same resolution natively for
+the fabber_capi path; this module is what bench.py and the tests use to talk to the kernel
+library directly with device pointers.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+FVB_MAX_PARAMS = 16
+FVB_MAX_PHIS = 8
+FVB_ABI_VERSION = 3
+
+MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
+TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)
+TRANSFORM_CODES = {"I": 0, "L": 1, "S": 2, "F": 3, "A": 4}
+PRIOR_NORMAL, PRIOR_IMAGE, PRIOR_ARD, PRIOR_SPATIAL_M, PRIOR_SPATIAL_m, PRIOR_SPATIAL_P, PRIOR_SPATIAL_p = range(7)
+PRIOR_CODES = {"N": 0, "-": 0, "I": 1, "A": 2, "M": 3, "m": 4, "P": 5, "p": 6}
+CONV_MAXITS, CONV_FCHANGE, CONV_FREDUCE, CONV_TRIALMODE, CONV_LM = range(5)
+CONV_NAMES = {"maxits": 0, "pointzeroone": 1, "freduce": 2, "trialmode": 3, "lm": 4}
+NOISE_WHITE, NOISE_AR1 = 0, 1
+STATUS_OK, STATUS_BAD_OFFSET, STATUS_BAD_JACOBIAN, STATUS_BAD_FREE_ENERGY, STATUS_BAD_RESULT, STATUS_BAD_AR_ALPHA = range(6)
+
+_dp = C.POINTER(C.c_double)
+
+
+class FvbConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_voxels", C.c_int32),
+        ("n_times", C.c_int32),
+        ("n_params", C.c_int32),
+        ("n_phis", C.c_int32),
+        ("noise", C.c_int32),
+        ("model", C.c_int32),
+        ("model_iopt", C.c_int32 * 4),
+        ("model_dopt", C.c_double * 4),
+        ("design", C.c_void_p),
+        ("transform", C.c_int32 * FVB_MAX_PARAMS),
+        ("prior_type", C.c_int32 * FVB_MAX_PARAMS),
+        ("prior_mean", C.c_double * FVB_MAX_PARAMS),
+        ("prior_var", C.c_double * FVB_MAX_PARAMS),
+        ("prior_prec", C.c_double * FVB_MAX_PARAMS),
+        ("post_mean", C.c_double * FVB_MAX_PARAMS),
+        ("post_var", C.c_double * FVB_MAX_PARAMS),
+        ("image_prior", C.c_void_p * FVB_MAX_PARAMS),
+        ("noise_prior_b", C.c_double * FVB_MAX_PHIS),
+        ("noise_prior_c", C.c_double * FVB_MAX_PHIS),
+        ("noise_post_b", C.c_double * FVB_MAX_PHIS),
+        ("noise_post_c", C.c_double * FVB_MAX_PHIS),
+        ("locked_noise_stdev", C.c_double),
+        ("phi_index", C.c_void_p),
+        ("convergence", C.c_int32),
+        ("max_iterations", C.c_int32),
+        ("max_trials", C.c_int32),
+        ("need_f", C.c_int32),
+        ("min_fchange", C.c_double),
+        ("init_mvn", C.c_void_p),
+        ("f_history_rows", C.c_int32),
+        ("data_f64", C.c_int32),
+    ]
+
+
+class FvbOutputs(C.Structure):
+    _fields_ = [
+        ("mvn", C.c_void_p),
+        ("free_energy", C.c_void_p),
+        ("f_history", C.c_void_p),
+        ("f_history_len", C.c_void_p),
+        ("status", C.c_void_p),
+        ("iterations", C.c_void_p),
+    ]
+
+
+class FvbPostproc(C.Structure):
+    _fields_ = [
+        ("mean", C.c_void_p),
+        ("var", C.c_void_p),
+        ("std", C.c_void_p),
+        ("zstat", C.c_void_p),
+        ("modelfit", C.c_void_p),
+        ("residuals", C.c_void_p),
+        ("noise_mean", C.c_void_p),
+        ("noise_std", C.c_void_p),
+    ]
+
+
+def mvn_rows(n):
+    """Rows of the packed MVN image for an n-dimensional MVN (dist_mvn.cc:408)."""
+    return n * (n + 1) // 2 + n + 1
+
+
+# ---- transforms.h:114-242, transforms.cc:17-25 (host-side, used only to resolve priors) ----
+def to_model(tr, x):
+    if tr == TRANSFORM_LOG:
+        return math.exp(x)
+    if tr == TRANSFORM_SOFTPLUS:
+        return math.log(1 + math.exp(x)) if x < 10 else x
+    if tr == TRANSFORM_FRACTIONAL:
+        return 1 / (1 + math.exp(x))
+    if tr == TRANSFORM_ABS:
+        return abs(x)
+    return x
+
+
+def to_fabber(tr, x):
+    if tr == TRANSFORM_LOG:
+        return math.log(x)
+    if tr == TRANSFORM_SOFTPLUS:
+        return math.log(math.exp(x) - 1) if x < 10 else x
+    if tr == TRANSFORM_FRACTIONAL:
+        return math.log(1 / x - 1)
+    return x
+
+
+def to_fabber_var(tr, v):
+    if tr in (TRANSFORM_IDENTITY, TRANSFORM_FRACTIONAL):
+        return v
+    if tr == TRANSFORM_LOG:
+        return math.log(v)
+    return to_fabber(tr, to_model(tr, 0) + math.sqrt(v)) ** 2
+
+
+def model_parameter_defaults(model, **opts):
+    """GetParameterDefaults of the built-in models: list of dicts with name, prior (mean, var),
+    post (mean, var), prior_type, transform. fwdmodel_poly.cc:53-60, fwdmodel_linear.cc:83-90,
+    examples/fwdmodel_exp.cc:49-63."""
+    params = []
+    if model == MODEL_POLY:
+        for i in range(int(opts["degree"]) + 1):
+            params.append(dict(name="c%d" % i, prior=(0.0, 1e12), post=(0.0, 1e12), prior_type="N", transform=TRANSFORM_IDENTITY))
+    elif model == MODEL_LINEAR:
+        for i in range(int(opts["n_basis"])):
+            params.append(dict(name="Parameter_%d" % (i + 1), prior=(0.0, 1e12), post=(0.0, 1e12), prior_type="N", transform=TRANSFORM_IDENTITY))
+    elif model == MODEL_EXP:
+        for i in range(int(opts.get("num_exps", 1))):
+            for nm in ("amp", "r"):
+                params.append(dict(name="%s%d" % (nm, i + 1), prior=(1.0, 1e5), post=(1.0, 1.5), prior_type="N", transform=TRANSFORM_LOG))
+    else:
+        raise ValueError("unknown model %r" % (model,))
+    return params
+
+
+class ConfigHolder:
+    """An FvbConfig plus the numpy arrays its pointer members refer to (kept alive here)."""
+
+    def __init__(self, cfg, params, keep):
+        self.cfg = cfg
+        self.params = params
+        self.keep = keep
+
+    @property
+    def n_mvn_rows(self):
+        return mvn_rows(self.cfg.n_params + self.n_noise_outputs)
+
+    @property
+    def n_noise_outputs(self):
+        return self.cfg.n_phis if self.cfg.noise == NOISE_WHITE else 3
+
+
+def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps=1, dt=1.0,
+                 convergence="maxits", max_iterations=10, min_fchange=0.01, max_trials=10,
+                 need_f=None, f_history_rows=0, noise_pattern="1", masked_timepoints=(),
+                 prior_noise_stddev=-1.0, locked_noise_stdev=-1.0, param_overrides=None,
+                 image_priors=None, init_mvn=None, noise=NOISE_WHITE):
+    """Resolve options into an fvb_config whose pointer members are HOST numpy arrays.
+
+    param_overrides: {name: dict(type=, mean=, prec=, transform=)} == PSP_byname options
+    (fwdmodel.cc:238-266). image_priors: {name: float64 array [n_voxels]}.
+    """
+    keep = {}
+    cfg = FvbConfig()
+    cfg.abi_version = FVB_ABI_VERSION
+    cfg.n_voxels = n_voxels
+    cfg.n_times = n_times
+    cfg.noise = noise
+    cfg.model = model
+    if model == MODEL_POLY:
+        cfg.model_iopt[0] = int(degree)
+        params = model_parameter_defaults(model, degree=degree)
+    elif model == MODEL_LINEAR:
+        design = np.ascontiguousarray(design, dtype=np.float64)
+        assert design.shape[0] == n_times
+        keep["design"] = design
+        cfg.design = design.ctypes.data
+        params = model_parameter_defaults(model, n_basis=design.shape[1])
+    elif model == MODEL_EXP:
+        cfg.model_iopt[0] = int(num_exps)
+        cfg.model_dopt[0] = float(dt)
+        params = model_parameter_defaults(model, num_exps=num_exps)
+    else:
+        raise ValueError(model)
+    P = len(params)
+    assert P <= FVB_MAX_PARAMS
+    cfg.n_params = P
+    param_overrides = param_overrides or {}
+    image_priors = image_priors or {}
+    for k, p in enumerate(params):
+        ov = param_overrides.get(p["name"], {})
+        tr = p["transform"]
+        if "transform" in ov:
+            tr = TRANSFORM_CODES[ov["transform"]] if isinstance(ov["transform"], str) else ov["transform"]
+        ptype = ov.get("type", p["prior_type"])
+        mean, var = p["prior"]
+        if "mean" in ov or "prec" in ov:
+            # fwdmodel.cc:258-263: DistParams(mean, 1/prec)
+            mean = float(ov.get("mean", mean))
+            prec = float(ov.get("prec", 1.0 / var))
+            var = 1.0 / prec
+        if 1.0 / var > 1e12:  # fwdmodel.cc:268-271
+            var = 1e-12
+        # Prior to Fabber space (fwdmodel.cc:277, transforms.cc:10-15)
+        fmean = to_fabber(tr, mean)
+        fvar = to_fabber_var(tr, var)
+        cfg.transform[k] = tr
+        cfg.prior_type[k] = PRIOR_CODES[ptype]
+        cfg.prior_mean[k] = fmean
+        cfg.prior_var[k] = fvar
+        cfg.prior_prec[k] = 1.0 / fvar if fvar != 0 else math.inf
+        cfg.post_mean[k] = p["post"][0]
+        cfg.post_var[k] = p["post"][1]
+        p.update(transform=tr, prior_type=ptype)
+        if PRIOR_CODES[ptype] == PRIOR_IMAGE:
+            img = np.ascontiguousarray(image_priors[p["name"]], dtype=np.float64)
+            assert img.shape == (n_voxels,)
+            keep["image_%d" % k] = img
+            cfg.image_prior[k] = img.ctypes.data
+
+    # noise pattern -> phi index per timepoint (noisemodel_white.cc:166-226)
+    pat = []
+    for ch in noise_pattern:
+        if "1" <= ch <= "9":
+            pat.append(ord(ch) - ord("0"))
+        elif "A" <= ch <= "Z":
+            pat.append(ord(ch) - ord("A") + 10)
+        elif "a" <= ch <= "z":
+            pat.append(ord(ch) - ord("a") + 10)
+        else:
+            raise ValueError("noise-pattern: invalid character %r" % ch)
+    if len(pat) > n_times:
+        raise ValueError("noise-pattern: Pattern length exceeds data length")
+    n_phis = max(pat)
+    assert n_phis <= FVB_MAX_PHIS
+    cfg.n_phis = n_phis if noise == NOISE_WHITE else 1
+    phi_index = np.zeros(n_times, dtype=np.uint8)
+    for t in range(n_times):
+        phi_index[t] = pat[t % len(pat)] - 1
+    for mt in masked_timepoints:  # 1-based (noisemodel.cc:34-40)
+        phi_index[mt - 1] = 255
+    keep["phi_index"] = phi_index
+    cfg.phi_index = phi_index.ctypes.data
+    for i in range(FVB_MAX_PHIS):
+        if prior_noise_stddev == -1.0:  # noisemodel_white.cc:141-150
+            cfg.noise_prior_b[i], cfg.noise_prior_c[i] = 1e6, 1e-6
+            cfg.noise_post_b[i], cfg.noise_post_c[i] = 1e-8, 50.0
+        else:  # :151-162
+            c = 0.5
+            b = 1 / (prior_noise_stddev * prior_noise_stddev * c)
+            cfg.noise_prior_b[i] = cfg.noise_post_b[i] = b
+            cfg.noise_prior_c[i] = cfg.noise_post_c[i] = c
+    if noise == NOISE_AR1:  # noisemodel_ar.cc:379-403
+        cfg.noise_prior_b[0], cfg.noise_prior_c[0] = 1e6, 1e-6
+        cfg.noise_post_b[0], cfg.noise_post_c[0] = 1e-8, 1e-6
+    cfg.locked_noise_stdev = locked_noise_stdev
+
+    cfg.convergence = CONV_NAMES[convergence] if isinstance(convergence, str) else convergence
+    cfg.max_iterations = max_iterations
+    cfg.max_trials = max_trials
+    cfg.min_fchange = min_fchange
+    uses_f = cfg.convergence != CONV_MAXITS
+    cfg.need_f = int(uses_f if need_f is None else (need_f or uses_f))
+    cfg.f_history_rows = f_history_rows
+    if init_mvn is not None:
+        init_mvn = np.ascontiguousarray(init_mvn, dtype=np.float64)
+        keep["init_mvn"] = init_mvn
+        cfg.init_mvn = init_mvn.ctypes.data
+    return ConfigHolder(cfg, params, keep)

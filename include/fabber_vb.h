@@ -1,0 +1,223 @@
+/*
+ * fabber_vb.h - C ABI of the MI355X voxelwise Variational Bayes engine.
+ *
+ * This is the thin shim between the host C++ side (the Vb inference technique, the
+ * fabber_capi entry points) and the hand-written HIP kernels. Everything the reference does
+ * per voxel inside Vb::DoCalculations (inference_vb.cc:360-576) is expressed as ONE call on a
+ * plain-old-data problem description plus flat arrays:
+ *
+ *   reference                                              here
+ *   ---------------------------------------------------    ---------------------------------
+ *   Vb::SetupPerVoxelDists        inference_vb.cc:144      fvb_config (initial dists) + kernel prologue
+ *   Vb::DoCalculationsVoxelwise   inference_vb.cc:415      fabber_vb_run_device / fabber_vb_run_host
+ *   WhiteNoiseModel::UpdateTheta  noisemodel_white.cc:275  in-kernel
+ *   WhiteNoiseModel::UpdateNoise  noisemodel_white.cc:228  in-kernel
+ *   WhiteNoiseModel::CalcFreeEnergy noisemodel_white.cc:365 in-kernel (need_f)
+ *   MVNDist inverse / logdet      dist_mvn.cc:197-265      in-kernel LDL^T
+ *   LinearizedFwdModel::ReCentre  fwdmodel_linear.cc:126   in-kernel central differences
+ *   FwdModel::EvaluateFabber      fwdmodel.cc:365          in-kernel transform + device model body
+ *   Prior::ApplyToMVN             priors.cc:108-181        in-kernel (N, I, A prior types)
+ *   ConvergenceDetector::Test     convergence.cc:43-378    in-kernel state machines
+ *   MVNDist::Save packing         dist_mvn.cc:377-433      kernel output layout (rows x V)
+ *   InferenceTechnique::SaveResults inference.cc:112-281   fabber_vb_postproc_device
+ *
+ * Layout conventions (all arrays are "row x voxel", voxel fastest, exactly the reference's
+ * NEWMAT::Matrix(rows, nVoxels) images and the fabber_capi [t][z][y][x] order after masking,
+ * rundata_array.cc:100-133):
+ *   data      float or double [n_times][n_voxels] (cfg->data_f64)
+ *   mvn       double [n_mvn_rows][n_voxels]   n = n_params + n_phis,
+ *                                             n_mvn_rows = n(n+1)/2 + n + 1 (dist_mvn.cc:408)
+ *   free_energy  double [n_voxels]
+ *   f_history    double [f_history_rows][n_voxels]
+ *   status / iterations  int32 [n_voxels]
+ *
+ * No torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef FABBER_VB_H
+#define FABBER_VB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVB_MAX_PARAMS 16
+#define FVB_MAX_PHIS 8
+#define FVB_ABI_VERSION 3
+
+/* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
+ * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
+ * its offset/Jacobian are supplied per iteration by the host (see fabber_vb_hostjac_*). */
+enum fvb_model
+{
+    FVB_MODEL_POLY = 0,
+    FVB_MODEL_LINEAR = 1,
+    FVB_MODEL_EXP = 2,
+    FVB_MODEL_HOSTJAC = 100
+};
+
+/* transforms.h:19-23 */
+enum fvb_transform
+{
+    FVB_TRANSFORM_IDENTITY = 0,
+    FVB_TRANSFORM_LOG = 1,
+    FVB_TRANSFORM_SOFTPLUS = 2,
+    FVB_TRANSFORM_FRACTIONAL = 3,
+    FVB_TRANSFORM_ABS = 4
+};
+
+/* priors.h prior type codes: 'N'/'-' normal, 'I' image, 'A' ARD, 'M','m','P','p' spatial */
+enum fvb_prior
+{
+    FVB_PRIOR_NORMAL = 0,
+    FVB_PRIOR_IMAGE = 1,
+    FVB_PRIOR_ARD = 2,
+    FVB_PRIOR_SPATIAL_M = 3,
+    FVB_PRIOR_SPATIAL_m = 4,
+    FVB_PRIOR_SPATIAL_P = 5,
+    FVB_PRIOR_SPATIAL_p = 6
+};
+
+/* setup.cc:50-58 registered convergence detector names */
+enum fvb_convergence
+{
+    FVB_CONV_MAXITS = 0,       /* "maxits"       convergence.cc:43  */
+    FVB_CONV_FCHANGE = 1,      /* "pointzeroone" convergence.cc:86  */
+    FVB_CONV_FREDUCE = 2,      /* "freduce"      convergence.cc:117 */
+    FVB_CONV_TRIALMODE = 3,    /* "trialmode"    convergence.cc:162 */
+    FVB_CONV_LM = 4            /* "lm"           convergence.cc:278 */
+};
+
+enum fvb_noise
+{
+    FVB_NOISE_WHITE = 0, /* noisemodel_white.cc */
+    FVB_NOISE_AR1 = 1    /* noisemodel_ar.cc, nPhis = 1, cross terms "none" */
+};
+
+/* Per-voxel status word written by the kernel. Mirrors the exceptions the reference's voxel
+ * loop catches (inference_vb.cc:529-544). */
+enum fvb_status
+{
+    FVB_OK = 0,
+    FVB_BAD_OFFSET = 1,      /* fwdmodel_linear.cc:134-140 non-finite model prediction  */
+    FVB_BAD_JACOBIAN = 2,    /* fwdmodel_linear.cc:174-181 non-finite Jacobian          */
+    FVB_BAD_FREE_ENERGY = 3, /* noisemodel_white.cc:445-451 non-finite F                */
+    FVB_BAD_RESULT = 4,      /* inference_vb.cc:556-570 zero +- identity fallback       */
+    FVB_BAD_AR_ALPHA = 5     /* noisemodel_ar.cc:492-499 negative alpha variance        */
+};
+
+/* Problem description. Pointers inside are HOST pointers for fabber_vb_run_host and for the
+ * oracle, DEVICE pointers for fabber_vb_run_device (documented per field). */
+typedef struct fvb_config
+{
+    int32_t abi_version; /* must be FVB_ABI_VERSION */
+    int32_t n_voxels;
+    int32_t n_times;
+    int32_t n_params; /* P, forward-model parameters */
+    int32_t n_phis;   /* white: number of noise-pattern symbols; AR1: 1 */
+    int32_t noise;    /* enum fvb_noise */
+
+    /* ---- forward model ---- */
+    int32_t model;          /* enum fvb_model */
+    int32_t model_iopt[4];  /* poly: [0]=degree. exp: [0]=num-exps */
+    double model_dopt[4];   /* exp: [0]=dt */
+    const double *design;   /* linear: [n_times][n_params] row-major, Jacobian of LinearFwdModel
+                               (fwdmodel_linear.cc:53-81). Same memory space as data. */
+
+    /* ---- parameters: FwdModel::GetParameters (fwdmodel.cc:210-282) resolved on host ---- */
+    int32_t transform[FVB_MAX_PARAMS];
+    int32_t prior_type[FVB_MAX_PARAMS];
+    double prior_mean[FVB_MAX_PARAMS]; /* Fabber space (fwdmodel.cc:277) */
+    double prior_var[FVB_MAX_PARAMS];  /* Fabber space, DistParams::var()  */
+    double prior_prec[FVB_MAX_PARAMS]; /* Fabber space, DistParams::prec() = 1/var */
+    double post_mean[FVB_MAX_PARAMS];  /* MODEL space initial posterior (fwdmodel.cc:286-305) */
+    double post_var[FVB_MAX_PARAMS];   /* MODEL space */
+    const double *image_prior[FVB_MAX_PARAMS]; /* [n_voxels] for prior type I, else NULL */
+
+    /* ---- noise model initial distributions (noisemodel_white.cc:127-164) ---- */
+    double noise_prior_b[FVB_MAX_PHIS];
+    double noise_prior_c[FVB_MAX_PHIS];
+    double noise_post_b[FVB_MAX_PHIS];
+    double noise_post_c[FVB_MAX_PHIS];
+    double locked_noise_stdev; /* <= 0: not locked (noisemodel_white.cc:110,265) */
+    const uint8_t *phi_index;  /* [n_times] 0-based phi per timepoint, 255 = masked timepoint
+                                  (noisemodel_white.cc:166-226). NULL => all zeros. */
+
+    /* ---- convergence (convergence.cc) ---- */
+    int32_t convergence;  /* enum fvb_convergence */
+    int32_t max_iterations;
+    int32_t max_trials;
+    int32_t need_f;       /* m_needF, inference_vb.cc:242 */
+    double min_fchange;   /* also max-fchange for LM */
+
+    /* ---- resume (inference_vb.cc:183-216) ---- */
+    const double *init_mvn; /* [n_mvn_rows][n_voxels] continue-from-mvn, or NULL */
+
+    /* ---- output control ---- */
+    int32_t f_history_rows; /* 0 = do not record (save-free-energy-history) */
+    int32_t data_f64;       /* 0: data is float32 (fabber_capi, fabber_capi.h:109); 1: data is float64
+                               (the C++ FabberRunData::SetVoxelData(Matrix) route, rundata.cc:924) */
+} fvb_config;
+
+/* Result arrays; any pointer may be NULL if that output is not wanted, except mvn. */
+typedef struct fvb_outputs
+{
+    double *mvn;           /* [n_mvn_rows][n_voxels] */
+    double *free_energy;   /* [n_voxels] */
+    double *f_history;     /* [f_history_rows][n_voxels] */
+    int32_t *f_history_len;/* [n_voxels] entries pushed (inference_vb.cc:496-497,553-554) */
+    int32_t *status;       /* [n_voxels] enum fvb_status */
+    int32_t *iterations;   /* [n_voxels] m_ctx->it at exit */
+} fvb_outputs;
+
+/* Post-processing outputs: InferenceTechnique::SaveResults (inference.cc:112-281) and
+ * Vb::SaveResults (inference_vb.cc:966-1051). All optional. */
+typedef struct fvb_postproc
+{
+    double *mean;     /* [n_params][n_voxels] model-space means   (inference.cc:139-147) */
+    double *var;      /* [n_params][n_voxels] */
+    double *std;      /* [n_params][n_voxels] */
+    double *zstat;    /* [n_params][n_voxels] */
+    double *modelfit; /* [n_times][n_voxels]  (inference.cc:181-243) */
+    double *residuals;/* [n_times][n_voxels] */
+    double *noise_mean; /* [n_phis][n_voxels] (inference_vb.cc:981-989) */
+    double *noise_std;  /* [n_phis][n_voxels] */
+} fvb_postproc;
+
+/* Number of rows of the packed MVN image for n = n_params + n_noise_outputs (dist_mvn.cc:408). */
+int32_t fabber_vb_mvn_rows(int32_t n);
+
+/* Library / device introspection. */
+int32_t fabber_vb_abi_version(void);
+int32_t fabber_vb_device_count(void);
+const char *fabber_vb_last_error(void);
+
+/* Which kernel a configuration would dispatch to ("lane<exp,4>" / "wave" / ...). */
+const char *fabber_vb_kernel_name(const fvb_config *cfg);
+
+/*
+ * Run the voxelwise VB loop. All pointers (data, cfg->design, cfg->image_prior[], cfg->phi_index,
+ * cfg->init_mvn and every fvb_outputs member) are DEVICE pointers. The launch is asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream). Returns 0 or a negative error code; the
+ * message is available from fabber_vb_last_error().
+ */
+int32_t fabber_vb_run_device(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream);
+
+/* Same with HOST pointers: uploads, runs, downloads, synchronises. `device` = HIP device index. */
+int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device);
+
+/* Result images from the packed MVN (device pointers, asynchronous on stream). */
+int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const double *mvn,
+    const fvb_postproc *pp, void *stream);
+int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const double *mvn,
+    const fvb_postproc *pp, int32_t device);
+
+/* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
+void fabber_vb_set_variant(int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FABBER_VB_H */

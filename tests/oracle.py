@@ -1,0 +1,148 @@
+"""Loader for the CPU oracle (oracle/liboracle.so). Test infrastructure only.
+
+Builds the library on first use with oracle/Makefile (g++ only, a few seconds).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from fabber_core_amd import vbabi
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+class OracleTrace(C.Structure):
+    _fields_ = [("means", C.c_void_p), ("noise_b", C.c_void_p), ("max_rows", C.c_int32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_ROOT, "oracle", "liboracle.so")
+        src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle.so"])
+        L = C.CDLL(path)
+        L.oracle_vb_run.restype = C.c_int32
+        L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.oracle_vb_postproc.restype = C.c_int32
+        L.oracle_vb_postproc.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.c_void_p, C.POINTER(vbabi.FvbPostproc)]
+        for name in ("oracle_gammaln", "oracle_digamma"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double]
+        for name in ("oracle_transform_to_model", "oracle_transform_to_fabber", "oracle_transform_to_model_var",
+                     "oracle_transform_to_fabber_var"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_int32, C.c_double]
+        L.oracle_evaluate_fabber.restype = C.c_int32
+        L.oracle_evaluate_fabber.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.c_void_p]
+        L.oracle_convergence_trace.restype = C.c_int32
+        L.oracle_convergence_trace.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.oracle_inverse.restype = C.c_int32
+        L.oracle_inverse.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+        L.oracle_logdet.restype = C.c_double
+        L.oracle_logdet.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def alloc_outputs(holder):
+    """Host result arrays for a config, plus the FvbOutputs struct pointing at them."""
+    cfg = holder.cfg
+    V = cfg.n_voxels
+    arrs = dict(
+        mvn=np.full((holder.n_mvn_rows, V), np.nan),
+        free_energy=np.full(V, np.nan),
+        status=np.full(V, -1, dtype=np.int32),
+        iterations=np.full(V, -1, dtype=np.int32),
+        f_history_len=np.zeros(V, dtype=np.int32),
+    )
+    if cfg.f_history_rows > 0:
+        arrs["f_history"] = np.full((cfg.f_history_rows, V), np.nan)
+    out = vbabi.FvbOutputs()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    return arrs, out
+
+
+def prepare_data(holder, data):
+    """float32 data is the C-ABI route, float64 the in-memory NEWMAT::Matrix route."""
+    cfg = holder.cfg
+    data = np.ascontiguousarray(data)
+    if data.dtype == np.float64:
+        cfg.data_f64 = 1
+    else:
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        cfg.data_f64 = 0
+    assert data.shape == (cfg.n_times, cfg.n_voxels), (data.shape, cfg.n_times, cfg.n_voxels)
+    return data
+
+
+def run(holder, data, v_begin=0, v_end=None, halt_bad_voxel=False, trace_rows=0):
+    """Run the oracle. data: float32 [n_times][n_voxels]. Returns dict of result arrays."""
+    cfg = holder.cfg
+    data = prepare_data(holder, data)
+    arrs, out = alloc_outputs(holder)
+    tr = None
+    trp = None
+    if trace_rows:
+        arrs["trace_means"] = np.full((trace_rows, cfg.n_params, cfg.n_voxels), np.nan)
+        arrs["trace_noise_b"] = np.full((trace_rows, cfg.n_phis, cfg.n_voxels), np.nan)
+        tr = OracleTrace(arrs["trace_means"].ctypes.data, arrs["trace_noise_b"].ctypes.data, trace_rows)
+        trp = C.addressof(tr)
+    if v_end is None:
+        v_end = cfg.n_voxels
+    rc = lib().oracle_vb_run(C.byref(cfg), data.ctypes.data, C.byref(out), v_begin, v_end, int(halt_bad_voxel), trp)
+    if rc < 0:
+        raise RuntimeError("oracle_vb_run failed: %d" % rc)
+    arrs["first_bad_voxel"] = rc
+    return arrs
+
+
+def postproc(holder, data, mvn, want=("mean", "var", "std", "zstat", "modelfit", "residuals", "noise_mean", "noise_std")):
+    cfg = holder.cfg
+    V, T, P, N = cfg.n_voxels, cfg.n_times, cfg.n_params, cfg.n_phis
+    shapes = dict(mean=(P, V), var=(P, V), std=(P, V), zstat=(P, V), modelfit=(T, V), residuals=(T, V),
+                  noise_mean=(N, V), noise_std=(N, V))
+    data = prepare_data(holder, data)
+    mvn = np.ascontiguousarray(mvn, dtype=np.float64)
+    pp = vbabi.FvbPostproc()
+    arrs = {}
+    for k in want:
+        arrs[k] = np.full(shapes[k], np.nan)
+        setattr(pp, k, arrs[k].ctypes.data)
+    rc = lib().oracle_vb_postproc(C.byref(cfg), data.ctypes.data, mvn.ctypes.data, C.byref(pp))
+    assert rc == 0
+    return arrs
+
+
+def unpack_mvn(mvn, n):
+    """Packed MVN rows -> (cov [V][n][n], means [V][n])."""
+    V = mvn.shape[1]
+    cov = np.zeros((V, n, n))
+    k = 0
+    for r in range(n):
+        for c in range(r + 1):
+            cov[:, r, c] = cov[:, c, r] = mvn[k]
+            k += 1
+    means = mvn[k:k + n].T.copy()
+    return cov, means
+
+
+def convergence_trace(conv, F, max_iterations=10, max_trials=10, min_fchange=0.01, stop_at_done=True):
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    n = len(F)
+    done = np.zeros(n, dtype=np.int32)
+    save = np.zeros(n, dtype=np.int32)
+    revert = np.zeros(n, dtype=np.int32)
+    alpha = np.zeros(n)
+    conv = vbabi.CONV_NAMES[conv] if isinstance(conv, str) else conv
+    m = lib().oracle_convergence_trace(conv, max_iterations, max_trials, min_fchange, F.ctypes.data, n,
+                                       done.ctypes.data, save.ctypes.data, revert.ctypes.data, alpha.ctypes.data,
+                                       int(stop_at_done))
+    return done[:m].astype(bool), save[:m].astype(bool), revert[:m].astype(bool), alpha[:m]
