@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: voxels/s of the voxelwise VB hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1] [--voxels V]
+
+A "step" is one complete pass of the hot path (every voxel of this rank's shard fitted to VB
+convergence: fabber_vb_run_device = Vb::DoCalculationsVoxelwise) over one batch of synthetic
+input that is already resident in HBM. Default workload = BASELINE.json configs[2], the
+configuration the north star's target is quoted on and which fits one GPU: bi-exponential model,
+white noise, 100 timepoints, max-iterations 50, 1e6 voxels PER GPU (weak scaling: N ranks fit
+N x 1e6 voxels; voxels are independent, so the shard is a contiguous block and the only
+collective is one tiny all-reduce of [sum F or noise checksum, sum iterations, bad voxels]).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - HBM roofline of the VB kernel: algorithmic bytes (4 T in + 4 rows out per voxel,
+                 SURVEY.md section 8d) / HIP-event kernel time, against 8 TB/s. The kernel is
+                 fp64-VALU bound, not HBM bound; the honest binding figure is reported beside it
+                 under roofline.fp64_valu.
+  cpu_baseline - the CPU oracle (port of the reference algorithm, single thread) timed on this
+                 host on a bounded voxel sample, plus the max relative difference of the
+                 posterior means between GPU and CPU on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (model kwargs, T, default voxels per GPU, iterations, description)
+    "c3": dict(num_exps=2, T=100, dt=0.02, voxels=1_000_000, its=50,
+               desc="BASELINE configs[2]: bi-exponential (examples biexp), white noise, 100 timepoints, max-iterations 50"),
+    "c2": dict(num_exps=1, T=50, dt=0.04, voxels=128 * 128 * 64, its=10,
+               desc="BASELINE configs[1]: exp single-exponential, white noise, 50 timepoints, 128x128x64 voxels, max-iterations 10"),
+}
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the 157.3 TF fp32 vector peak)
+EXP_FLOP_EQ = 25.0             # flop-equivalents charged per fp64 exp()
+
+
+def flops_per_voxel_iteration(P, T, num_exps):
+    """(2P+1) E_m + 2TP + P(P+1)T + 6TP + 6T + 2P^3 + 6P^2 with
+    E_m = 3 T N_e flops + T N_e exp() for the exponential model."""
+    e_m = 3 * T * num_exps + T * num_exps * EXP_FLOP_EQ
+    return (2 * P + 1) * e_m + 2 * T * P + P * (P + 1) * T + 6 * T * P + 6 * T + 2 * P ** 3 + 6 * P ** 2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--voxels", type=int, default=None, help="voxels per GPU (default: the workload's)")
+    ap.add_argument("--need-f", action="store_true", help="also evaluate the free energy 4x per iteration (CLI default of the reference)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="voxels timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--variant", default="auto", choices=["auto", "lane", "wave"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the VB engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    import cases
+    from fabber_core_amd import hiplib
+    from fabber_core_amd.device import DeviceProblem
+
+    hiplib.set_variant(args.variant)
+    w = WORKLOADS[args.workload]
+    V = args.voxels or w["voxels"]
+    T, P = w["T"], 2 * w["num_exps"]
+    # every rank gets its own contiguous block of the (world x V)-voxel problem: distinct seed
+    holder, y = cases.exp_problem(V, T, w["num_exps"], w["dt"], seed=20260103 + rank, max_iterations=w["its"],
+                                  need_f=bool(args.need_f))
+    prob = DeviceProblem(holder, y, device)
+    summary = torch.zeros(3, dtype=torch.float64, device=device)
+
+    def step():
+        prob.run()
+        # per-step global health/convergence summary: [sum F (or noise-mean checksum), sum iterations, bad voxels]
+        n = holder.cfg.n_params + 1
+        noise_row = n * (n + 1) // 2 + holder.cfg.n_params
+        summary[0] = prob.free_energy.sum() if args.need_f else prob.mvn[noise_row].sum()
+        summary[1] = prob.iterations.sum(dtype=torch.float64)
+        summary[2] = (prob.status != 0).sum(dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(summary, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()      # same stream the kernel is launched on (torch's current stream)
+        prob.run()
+        ev[i][1].record()
+        n = holder.cfg.n_params + 1
+        noise_row = n * (n + 1) // 2 + holder.cfg.n_params
+        summary[0] = prob.free_energy.sum() if args.need_f else prob.mvn[noise_row].sum()
+        summary[1] = prob.iterations.sum(dtype=torch.float64)
+        summary[2] = (prob.status != 0).sum(dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(summary, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    summ = summary.cpu().numpy()
+
+    result = None
+    if rank == 0:
+        total_voxels = V * world
+        value = total_voxels * args.steps / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        rows = holder.n_mvn_rows
+        alg_bytes = (4 * T + 4 * rows) * V
+        mean_its = summ[1] / (V * world)
+        flops = flops_per_voxel_iteration(P, T, w["num_exps"]) * mean_its * V
+        roofline = {
+            "bound": "hbm", "kernel": prob.kernel,
+            "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+            "note": "kernel is fp64-VALU/transcendental bound (arithmetic intensity ~6e3 flop/B), see fp64_valu",
+            "fp64_valu": {"achieved": flops / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP-eq/s",
+                          "frac": flops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "flop_eq_per_voxel_iteration": flops_per_voxel_iteration(P, T, w["num_exps"]),
+                          "exp_flop_eq": EXP_FLOP_EQ},
+        }
+        cpu = None
+        if args.cpu_sample > 0:
+            import oracle
+            ns = min(args.cpu_sample, V)
+            hs, _ = cases.exp_problem(ns, T, w["num_exps"], w["dt"], seed=1, max_iterations=w["its"], need_f=bool(args.need_f))
+            ys = np.ascontiguousarray(y[:, :ns])
+            oracle.run(hs, ys[:, :64].repeat(ns // 64 + 1, axis=1)[:, :ns])  # page in
+            c0 = time.perf_counter()
+            ref = oracle.run(hs, ys)
+            cpu_s = time.perf_counter() - c0
+            got = prob.results()
+            n = P + 1
+            off = n * (n + 1) // 2
+            ok = (ref["status"] == 0) & (got["status"][:ns] == 0)
+            a, b = ref["mvn"][off:off + P][:, ok], got["mvn"][off:off + P, :ns][:, ok]
+            dmean = float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-12)))
+            cpu = {"value": ns / cpu_s, "unit": "voxels/s", "cores": 1, "kind": "port",
+                   "sample": "first %d voxels of rank 0's shard, same model/iterations, oracle/liboracle.so single thread, %.1f s" % (ns, cpu_s),
+                   "host_cpus": os.cpu_count(), "max_rel_dmean_vs_cpu": dmean,
+                   "gpu_over_cpu_single_thread": (V / (k_ms * 1e-3)) / (ns / cpu_s)}
+        result = {
+            "metric": "voxels/sec to VB convergence", "value": value, "unit": "voxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w["desc"], "voxels_per_gpu": V, "total_voxels": total_voxels, "timepoints": T,
+                       "params": P, "iterations": w["its"], "need_f": bool(args.need_f), "parallelism": "voxel-shard x%d" % world,
+                       "input_dtype": "f32", "mean_iterations": mean_its, "bad_voxels": int(summ[2])},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

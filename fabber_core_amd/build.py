@@ -1,0 +1,104 @@
+"""In-tree build of the native libraries (hipcc for gfx950, g++ for the host side).
+
+    python -m fabber_core_amd.build [--force] [--jobs N]
+
+Produces fabber_core_amd/lib/libfabber_vb_hip.so (HIP kernels + fabber_vb C ABI). The objects
+are compiled one translation unit per process so that the template instantiations build in
+parallel; nothing is cached outside the repository, so the built .so travels with a snapshot
+of the tree.
+"""
+import argparse
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build", "obj")
+ARCH = "gfx950"
+
+HIP_SOURCES = ["vb_api.hip", "vb_lane_poly.hip", "vb_lane_linear.hip", "vb_lane_exp.hip", "vb_wave.hip"]
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math",
+             "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the fabber_vb HIP engine cannot be built")
+    return exe
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "fabber_vb.h"))
+    return hs
+
+
+def _stamp(src, flags):
+    h = hashlib.sha256()
+    h.update(" ".join(flags).encode())
+    for f in [src] + _headers():
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _compile_one(args):
+    src, flags, force = args
+    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+    stamp_file = obj + ".stamp"
+    stamp = _stamp(src, flags)
+    if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj, False, ""
+    cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), p.stdout, p.stderr))
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return obj, True, p.stderr
+
+
+def build_hip(force=False, jobs=None, verbose=True, extra_flags=()):
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    flags = HIP_FLAGS + list(extra_flags)
+    work = [(os.path.join(CSRC, s), flags, force) for s in HIP_SOURCES]
+    jobs = jobs or min(len(work), os.cpu_count() or 4)
+    objs, rebuilt = [], False
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for obj, did, warn in ex.map(_compile_one, work):
+            objs.append(obj)
+            rebuilt |= did
+            if verbose and did:
+                print("[build] compiled", os.path.basename(obj), file=sys.stderr)
+            if verbose and warn.strip():
+                print(warn, file=sys.stderr)
+    lib = os.path.join(LIBDIR, "libfabber_vb_hip.so")
+    if rebuilt or not os.path.exists(lib):
+        cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s\n%s" % (" ".join(cmd), p.stdout, p.stderr))
+        if verbose:
+            print("[build] linked", lib, file=sys.stderr)
+    return lib
+
+
+def build_all(force=False, jobs=None, verbose=True):
+    libs = [build_hip(force=force, jobs=jobs, verbose=verbose)]
+    return libs
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    for l in build_all(force=a.force, jobs=a.jobs):
+        print(l)

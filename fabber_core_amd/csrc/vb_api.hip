@@ -1,0 +1,533 @@
+/*
+ * vb_api.hip - C ABI of the voxelwise VB engine (include/fabber_vb.h): validation, kernel
+ * selection, launch, and the host-pointer convenience entry points.
+ *
+ * There is no CPU fallback: if no HIP device is present or a launch fails the call returns a
+ * negative code and fabber_vb_last_error() says why.
+ */
+#include "vb_dispatch.h"
+#include "vb_wave_kernel.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fvb;
+
+namespace
+{
+thread_local std::string g_last_error;
+int g_variant = 0; // 0 auto, 1 lane, 2 wave
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define FVB_HIP_CHECK(expr)                                                                                  \
+    do                                                                                                       \
+    {                                                                                                        \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(-100 - (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+int noise_outputs(const fvb_config *cfg)
+{
+    return cfg->noise == FVB_NOISE_WHITE ? cfg->n_phis : 3;
+}
+
+int validate(const fvb_config *cfg)
+{
+    if (!cfg)
+        return fail(-1, "config is NULL");
+    if (cfg->abi_version != FVB_ABI_VERSION)
+        return fail(-2, "fvb_config.abi_version mismatch");
+    if (cfg->n_voxels < 0 || cfg->n_times <= 0)
+        return fail(-3, "bad n_voxels / n_times");
+    if (cfg->n_params <= 0 || cfg->n_params > FVB_MAX_PARAMS)
+        return fail(-4, "n_params out of range");
+    if (cfg->n_phis <= 0 || cfg->n_phis > FVB_MAX_PHIS)
+        return fail(-5, "n_phis out of range");
+    if (cfg->noise != FVB_NOISE_WHITE)
+        return fail(-6, "noise model not supported by this build");
+    if (cfg->convergence < FVB_CONV_MAXITS || cfg->convergence > FVB_CONV_LM)
+        return fail(-7, "unknown convergence detector");
+    if (cfg->max_iterations <= 0)
+        return fail(-8, "max_iterations must be positive");
+    if (cfg->convergence != FVB_CONV_MAXITS && !cfg->need_f)
+        return fail(-9, "convergence detector uses F but need_f is 0");
+    if (cfg->model == FVB_MODEL_LINEAR && !cfg->design)
+        return fail(-10, "linear model needs a design matrix");
+    if (cfg->model == FVB_MODEL_EXP && (cfg->n_params != 2 * cfg->model_iopt[0]))
+        return fail(-11, "exp model: n_params != 2 * num-exps");
+    if (cfg->model == FVB_MODEL_POLY && (cfg->n_params != cfg->model_iopt[0] + 1))
+        return fail(-12, "poly model: n_params != degree + 1");
+    for (int k = 0; k < cfg->n_params; k++)
+    {
+        if (cfg->prior_type[k] == FVB_PRIOR_IMAGE && !cfg->image_prior[k])
+            return fail(-13, "image prior without an image");
+        if (cfg->prior_type[k] > FVB_PRIOR_ARD)
+            return fail(-14, "spatial priors are not handled by the voxelwise engine");
+    }
+    return 0;
+}
+
+LaneKernelInfo select_lane(const fvb_config *cfg)
+{
+    if (g_variant == 2 || cfg->n_phis != 1)
+        return LaneKernelInfo{ nullptr, 0, nullptr };
+    const bool need_f = cfg->need_f != 0;
+    switch (cfg->model)
+    {
+    case FVB_MODEL_POLY:
+        return get_lane_kernel_poly(cfg->n_params, need_f);
+    case FVB_MODEL_LINEAR:
+        return get_lane_kernel_linear(cfg->n_params, need_f);
+    case FVB_MODEL_EXP:
+        return get_lane_kernel_exp(cfg->n_params, need_f);
+    default:
+        return LaneKernelInfo{ nullptr, 0, nullptr };
+    }
+}
+
+bool needs_save(const fvb_config *cfg)
+{
+    return cfg->convergence == FVB_CONV_FREDUCE || cfg->convergence == FVB_CONV_TRIALMODE
+        || cfg->convergence == FVB_CONV_LM;
+}
+
+int count_unmasked(const fvb_config *cfg, const uint8_t *phi_index_host)
+{
+    if (!phi_index_host)
+        return cfg->n_times;
+    int n = 0;
+    for (int t = 0; t < cfg->n_times; t++)
+        n += (phi_index_host[t] != 255);
+    return n;
+}
+
+// ---- post-processing kernel: InferenceTechnique::SaveResults / Vb::SaveResults ----------------
+__global__ __launch_bounds__(256) void vb_postproc_kernel(
+    const fvb_config cfg, const void *data, const double *mvn, const fvb_postproc pp, const int n_noise)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= cfg.n_voxels)
+        return;
+    const size_t V = (size_t)cfg.n_voxels;
+    const int P = cfg.n_params, n = P + n_noise, T = cfg.n_times;
+    const int nCov = n * (n + 1) / 2;
+    double means[FVB_MAX_PARAMS];
+    for (int p = 0; p < P; p++)
+    {
+        const double m = mvn[(size_t)(nCov + p) * V + v];
+        const double var = mvn[(size_t)(p * (p + 1) / 2 + p) * V + v];
+        const int tr = cfg.transform[p];
+        // FwdModel::ToModel, fwdmodel.cc:326-337
+        const double mm = to_model(tr, m);
+        const double mv = to_model_var(tr, var);
+        const double sd = sqrt(mv);
+        means[p] = mm; // model-space value, what EvaluateModel receives
+        if (pp.mean)
+            pp.mean[(size_t)p * V + v] = mm;
+        if (pp.var)
+            pp.var[(size_t)p * V + v] = mv;
+        if (pp.std)
+            pp.std[(size_t)p * V + v] = sd;
+        if (pp.zstat)
+            pp.zstat[(size_t)p * V + v] = mm / sd;
+    }
+    for (int i = 0; i < n_noise; i++) // inference_vb.cc:981-989
+    {
+        const int q = P + i;
+        if (pp.noise_mean)
+            pp.noise_mean[(size_t)i * V + v] = mvn[(size_t)(nCov + q) * V + v];
+        if (pp.noise_std)
+            pp.noise_std[(size_t)i * V + v] = sqrt(mvn[(size_t)(q * (q + 1) / 2 + q) * V + v]);
+    }
+    if (pp.modelfit || pp.residuals) // inference.cc:181-243
+    {
+        ModelArgs ma;
+        ma.iopt0 = cfg.model_iopt[0];
+        ma.dopt0 = cfg.model_dopt[0];
+        ma.design = cfg.design;
+        for (int t = 0; t < T; t++)
+        {
+            const double fit = eval_model_runtime(cfg.model, ma, P, t, means);
+            if (pp.modelfit)
+                pp.modelfit[(size_t)t * V + v] = fit;
+            if (pp.residuals)
+            {
+                const size_t idx = (size_t)t * V + v;
+                const double y = cfg.data_f64 ? ((const double *)data)[idx] : (double)((const float *)data)[idx];
+                pp.residuals[idx] = y - fit;
+            }
+        }
+    }
+}
+
+// RAII device buffer used only by the *_host entry points
+struct DevBuf
+{
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes)
+    {
+        return hipMalloc(&p, bytes ? bytes : 8);
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int32_t fabber_vb_mvn_rows(int32_t n)
+{
+    return n * (n + 1) / 2 + n + 1;
+}
+
+int32_t fabber_vb_abi_version(void)
+{
+    return FVB_ABI_VERSION;
+}
+
+int32_t fabber_vb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *fabber_vb_last_error(void)
+{
+    return g_last_error.c_str();
+}
+
+void fabber_vb_set_variant(int32_t variant)
+{
+    g_variant = variant;
+}
+
+const char *fabber_vb_kernel_name(const fvb_config *cfg)
+{
+    if (validate(cfg) != 0)
+        return "invalid";
+    LaneKernelInfo k = select_lane(cfg);
+    if (k.fn && g_variant != 2)
+        return k.name;
+    return "wave";
+}
+
+int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream_,
+    int32_t n_unmasked)
+{
+    int rc = validate(cfg);
+    if (rc)
+        return rc;
+    if (!out || !out->mvn)
+        return fail(-20, "outputs.mvn is required");
+    if (cfg->n_voxels == 0)
+        return 0;
+    if (!data)
+        return fail(-21, "data is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    KernelArgs ka;
+    ka.cfg = *cfg;
+    ka.out = *out;
+    ka.data = data;
+    ka.save = nullptr;
+    ka.n_unmasked = n_unmasked;
+
+    LaneKernelInfo lk = select_lane(cfg);
+    if (lk.fn)
+    {
+        if (needs_save(cfg))
+            FVB_HIP_CHECK(hipMallocAsync((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels, stream));
+        const unsigned grid = (unsigned)((cfg->n_voxels + 63) / 64);
+        hipLaunchKernelGGL(lk.fn, dim3(grid), dim3(64), 0, stream, ka);
+        FVB_HIP_CHECK(hipGetLastError());
+        if (ka.save)
+            FVB_HIP_CHECK(hipFreeAsync(ka.save, stream));
+        return 0;
+    }
+    return launch_wave_kernel(ka, stream, g_last_error);
+}
+
+int32_t fabber_vb_run_device(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream)
+{
+    // The number of unmasked timepoints is needed as a scalar by the kernels; phi_index is a
+    // device pointer here, so read it back (n_times bytes, once per call).
+    int n_unmasked = cfg ? cfg->n_times : 0;
+    if (cfg && cfg->phi_index && cfg->n_times > 0)
+    {
+        std::vector<uint8_t> h(cfg->n_times);
+        FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg->phi_index, h.size(), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        FVB_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        n_unmasked = count_unmasked(cfg, h.data());
+    }
+    return fabber_vb_run_device_ex(cfg, data, out, stream, n_unmasked);
+}
+
+int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device)
+{
+    int rc = validate(cfg);
+    if (rc)
+        return rc;
+    if (!out || !out->mvn)
+        return fail(-20, "outputs.mvn is required");
+    if (fabber_vb_device_count() <= 0)
+        return fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
+    FVB_HIP_CHECK(hipSetDevice(device));
+    const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times;
+    if (V == 0)
+        return 0;
+    const int P = cfg->n_params;
+    const int rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
+    const size_t esz = cfg->data_f64 ? 8 : 4;
+
+    fvb_config d = *cfg;
+    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS];
+    FVB_HIP_CHECK(b_data.alloc(T * V * esz));
+    FVB_HIP_CHECK(hipMemcpy(b_data.p, data, T * V * esz, hipMemcpyHostToDevice));
+    if (cfg->design)
+    {
+        FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P));
+        FVB_HIP_CHECK(hipMemcpy(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice));
+        d.design = (const double *)b_design.p;
+    }
+    if (cfg->phi_index)
+    {
+        FVB_HIP_CHECK(b_phi.alloc(T));
+        FVB_HIP_CHECK(hipMemcpy(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice));
+        d.phi_index = (const uint8_t *)b_phi.p;
+    }
+    if (cfg->init_mvn)
+    {
+        FVB_HIP_CHECK(b_init.alloc(sizeof(double) * rows * V));
+        FVB_HIP_CHECK(hipMemcpy(b_init.p, cfg->init_mvn, sizeof(double) * rows * V, hipMemcpyHostToDevice));
+        d.init_mvn = (const double *)b_init.p;
+    }
+    for (int k = 0; k < P; k++)
+        if (cfg->image_prior[k])
+        {
+            FVB_HIP_CHECK(b_img[k].alloc(sizeof(double) * V));
+            FVB_HIP_CHECK(hipMemcpy(b_img[k].p, cfg->image_prior[k], sizeof(double) * V, hipMemcpyHostToDevice));
+            d.image_prior[k] = (const double *)b_img[k].p;
+        }
+    fvb_outputs dout;
+    memset(&dout, 0, sizeof(dout));
+    DevBuf b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
+    FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * V));
+    dout.mvn = (double *)b_mvn.p;
+    if (out->free_energy)
+    {
+        FVB_HIP_CHECK(b_f.alloc(sizeof(double) * V));
+        dout.free_energy = (double *)b_f.p;
+    }
+    if (out->f_history && cfg->f_history_rows > 0)
+    {
+        FVB_HIP_CHECK(b_hist.alloc(sizeof(double) * cfg->f_history_rows * V));
+        FVB_HIP_CHECK(hipMemset(b_hist.p, 0xff, sizeof(double) * cfg->f_history_rows * V)); // NaN fill
+        dout.f_history = (double *)b_hist.p;
+    }
+    if (out->f_history_len)
+    {
+        FVB_HIP_CHECK(b_hlen.alloc(sizeof(int32_t) * V));
+        dout.f_history_len = (int32_t *)b_hlen.p;
+    }
+    if (out->status)
+    {
+        FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * V));
+        dout.status = (int32_t *)b_status.p;
+    }
+    if (out->iterations)
+    {
+        FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * V));
+        dout.iterations = (int32_t *)b_it.p;
+    }
+    rc = fabber_vb_run_device_ex(&d, b_data.p, &dout, nullptr, count_unmasked(cfg, cfg->phi_index));
+    if (rc)
+        return rc;
+    FVB_HIP_CHECK(hipDeviceSynchronize());
+    FVB_HIP_CHECK(hipMemcpy(out->mvn, dout.mvn, sizeof(double) * rows * V, hipMemcpyDeviceToHost));
+    if (dout.free_energy)
+        FVB_HIP_CHECK(hipMemcpy(out->free_energy, dout.free_energy, sizeof(double) * V, hipMemcpyDeviceToHost));
+    if (dout.f_history)
+        FVB_HIP_CHECK(hipMemcpy(out->f_history, dout.f_history, sizeof(double) * cfg->f_history_rows * V, hipMemcpyDeviceToHost));
+    if (dout.f_history_len)
+        FVB_HIP_CHECK(hipMemcpy(out->f_history_len, dout.f_history_len, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    if (dout.status)
+        FVB_HIP_CHECK(hipMemcpy(out->status, dout.status, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    if (dout.iterations)
+        FVB_HIP_CHECK(hipMemcpy(out->iterations, dout.iterations, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp,
+    void *stream)
+{
+    int rc = validate(cfg);
+    if (rc)
+        return rc;
+    if (!mvn || !pp)
+        return fail(-22, "mvn / postproc outputs are NULL");
+    if ((pp->residuals) && !data)
+        return fail(-21, "residuals need the data");
+    if (cfg->n_voxels == 0)
+        return 0;
+    const unsigned grid = (unsigned)((cfg->n_voxels + 255) / 256);
+    hipLaunchKernelGGL(vb_postproc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *cfg, data, mvn, *pp,
+        noise_outputs(cfg));
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp,
+    int32_t device)
+{
+    int rc = validate(cfg);
+    if (rc)
+        return rc;
+    if (fabber_vb_device_count() <= 0)
+        return fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
+    FVB_HIP_CHECK(hipSetDevice(device));
+    const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times;
+    if (V == 0)
+        return 0;
+    const int P = cfg->n_params, N = noise_outputs(cfg);
+    const int rows = fabber_vb_mvn_rows(P + N);
+    const size_t esz = cfg->data_f64 ? 8 : 4;
+    fvb_config d = *cfg;
+    DevBuf b_data, b_design, b_mvn;
+    if (data)
+    {
+        FVB_HIP_CHECK(b_data.alloc(T * V * esz));
+        FVB_HIP_CHECK(hipMemcpy(b_data.p, data, T * V * esz, hipMemcpyHostToDevice));
+    }
+    if (cfg->design)
+    {
+        FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P));
+        FVB_HIP_CHECK(hipMemcpy(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice));
+        d.design = (const double *)b_design.p;
+    }
+    FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * V));
+    FVB_HIP_CHECK(hipMemcpy(b_mvn.p, mvn, sizeof(double) * rows * V, hipMemcpyHostToDevice));
+    struct Item
+    {
+        double *const *host;
+        double **dev;
+        size_t rows;
+    };
+    fvb_postproc dpp;
+    memset(&dpp, 0, sizeof(dpp));
+    Item items[8] = { { &pp->mean, &dpp.mean, (size_t)P }, { &pp->var, &dpp.var, (size_t)P },
+        { &pp->std, &dpp.std, (size_t)P }, { &pp->zstat, &dpp.zstat, (size_t)P }, { &pp->modelfit, &dpp.modelfit, T },
+        { &pp->residuals, &dpp.residuals, T }, { &pp->noise_mean, &dpp.noise_mean, (size_t)N },
+        { &pp->noise_std, &dpp.noise_std, (size_t)N } };
+    DevBuf bufs[8];
+    for (int i = 0; i < 8; i++)
+        if (*items[i].host)
+        {
+            FVB_HIP_CHECK(bufs[i].alloc(sizeof(double) * items[i].rows * V));
+            *items[i].dev = (double *)bufs[i].p;
+        }
+    rc = fabber_vb_postproc_device(&d, data ? b_data.p : nullptr, (const double *)b_mvn.p, &dpp, nullptr);
+    if (rc)
+        return rc;
+    FVB_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 8; i++)
+        if (*items[i].host)
+            FVB_HIP_CHECK(hipMemcpy(*items[i].host, *items[i].dev, sizeof(double) * items[i].rows * V, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- host-compiled twins of device building blocks, for unit tests without a GPU --------------
+int32_t fabber_vb_convergence_trace(int32_t conv, int32_t max_iterations, int32_t max_trials, double min_fchange,
+    const double *F, int32_t nF, int32_t *done, int32_t *save, int32_t *revert, double *alpha, int32_t stop_at_done)
+{
+    ConvState c;
+    conv_init(c, conv, max_iterations, max_trials, min_fchange);
+    conv_reset(c);
+    int n = 0;
+    for (int i = 0; i < nF; i++)
+    {
+        bool d = conv_test(c, F[i]);
+        done[i] = d;
+        save[i] = conv_need_save(c);
+        revert[i] = conv_need_revert(c);
+        alpha[i] = conv_lm_alpha(c);
+        n++;
+        if (d && stop_at_done)
+            break;
+    }
+    return n;
+}
+
+double fabber_vb_gammaln(double x)
+{
+    return gammaln(x);
+}
+double fabber_vb_digamma(double x)
+{
+    return digamma(x);
+}
+double fabber_vb_transform(int32_t which, int32_t tr, double x)
+{
+    switch (which)
+    {
+    case 0:
+        return to_model(tr, x);
+    case 1:
+        return to_fabber(tr, x);
+    case 2:
+        return to_model_var(tr, x);
+    default:
+        return to_fabber_var(tr, x);
+    }
+}
+
+// Host twin of the in-register LDL^T inverse for P = 1..6 (unit test of vb_math.h)
+int32_t fabber_vb_ldl_inverse(int32_t P, const double *packed, double *inv_packed, double *logabs, int32_t *sign)
+{
+    bool ok = false;
+    double la = 0;
+    int sg = 1;
+#define FVB_LDL_CASE(PP)                                                                                     \
+    case PP:                                                                                                 \
+    {                                                                                                        \
+        double a[PP * (PP + 1) / 2], r[PP * (PP + 1) / 2];                                                   \
+        for (int i = 0; i < PP * (PP + 1) / 2; i++)                                                          \
+            a[i] = packed[i];                                                                                \
+        ok = mvn_invert<PP>(a, r, la, sg);                                                                   \
+        for (int i = 0; i < PP * (PP + 1) / 2; i++)                                                          \
+            inv_packed[i] = r[i];                                                                            \
+        break;                                                                                               \
+    }
+    switch (P)
+    {
+        FVB_LDL_CASE(1)
+        FVB_LDL_CASE(2)
+        FVB_LDL_CASE(3)
+        FVB_LDL_CASE(4)
+        FVB_LDL_CASE(5)
+        FVB_LDL_CASE(6)
+    default:
+        return -1;
+    }
+    if (logabs)
+        *logabs = la;
+    if (sign)
+        *sign = sg;
+    return ok ? 0 : 1;
+}
+
+} // extern "C"

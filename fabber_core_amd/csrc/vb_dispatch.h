@@ -1,0 +1,30 @@
+/* vb_dispatch.h - lookup of the templated lane kernels, one translation unit per model so that
+ * the instantiations compile in parallel. */
+#pragma once
+
+#include "vb_lane_kernel.h"
+
+namespace fvb
+{
+typedef void (*LaneKernelFn)(const KernelArgs);
+
+struct LaneKernelInfo
+{
+    LaneKernelFn fn;
+    int save_rows;
+    const char *name;
+};
+
+// Each returns {NULL,0,NULL} when (P, need_f) has no instantiation; the caller then falls back to
+// the generic wave-per-voxel kernel.
+LaneKernelInfo get_lane_kernel_poly(int P, bool need_f);
+LaneKernelInfo get_lane_kernel_linear(int P, bool need_f);
+LaneKernelInfo get_lane_kernel_exp(int P, bool need_f);
+} // namespace fvb
+
+#define FVB_LANE_CASE(MODEL, TAG, PP)                                                                        \
+    case PP:                                                                                                 \
+        if (need_f)                                                                                          \
+            return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, true>, lane_save_rows<PP>(),                \
+                "lane<" TAG "," #PP ",F>" };                                                                 \
+        return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, false>, lane_save_rows<PP>(), "lane<" TAG "," #PP ">" };

@@ -1,0 +1,696 @@
+/*
+ * vb_lane_kernel.h - voxelwise VB, one LANE per voxel, everything in registers.
+ *
+ * Mapping (see DESIGN.md "Kernel mapping"): a wavefront owns 64 consecutive voxels of the
+ * masked-voxel list. The time series image is [t][voxel], so for a fixed t the 64 lanes read 64
+ * consecutive values: every global access of the kernel is a fully coalesced 256 B (float) /
+ * 512 B (double) line. There is no cross-lane traffic at all: the J'J / J'r / r'r accumulations
+ * that a wave-per-voxel mapping would do with shuffles are plain register FMAs here, the P x P
+ * factorisation keeps all 64 lanes busy, and LDS is not needed because the Jacobian is never
+ * stored: each re-linearisation streams once over t and keeps only the moments
+ *        A = J' Q J,   u = J' Q (y - g),   s = (y - g)' Q (y - g)
+ * of the linearised model about the current centre. Every quantity the update equations and
+ * the free energy need is a function of (A, u, s):
+ *        J' X J            = phi A                              (noisemodel_white.cc:303-305)
+ *        J' X (y - g + J ml) = phi (u + A ml)                   (:321)
+ *        k' Q k, k = y - g + J (ml - m)  = s - 2 d'u + d'A d,  d = m - ml   (:235,:252,:416)
+ *        tr(Sigma J' Q J)  = tr(Sigma A)                        (:252,:417)
+ *
+ * Reference path reproduced per voxel: Vb::SetupPerVoxelDists (inference_vb.cc:207-247) and the
+ * body of Vb::DoCalculationsVoxelwise (inference_vb.cc:423-571).
+ */
+#pragma once
+
+#include "vb_math.h"
+#include "vb_models.h"
+
+namespace fvb
+{
+struct KernelArgs
+{
+    fvb_config cfg; // pointer members are device pointers
+    fvb_outputs out;
+    const void *data;
+    double *save;      // [lane_save_rows(P)][V] scratch for save/revert, or NULL
+    int32_t n_unmasked; // T - #masked timepoints
+};
+
+template <int P>
+constexpr int lane_save_rows()
+{
+    return 3 * P + 2 * (P * (P + 1) / 2) + 3;
+}
+
+#if defined(__HIPCC__)
+
+template <int P>
+struct VoxelState
+{
+    static constexpr int PT = P * (P + 1) / 2;
+    double m[P];
+    double Lam[PT];
+    double Sig[PT];
+    double logdetLam; // log|det Lam| from the factorisation that produced Sig (or -log|det Sig|)
+    bool precValid, covValid;
+    double pm[P], pprec[P]; // theta prior: means and (diagonal) precisions
+    double b, c;            // noise posterior Gamma(scale b, shape c)
+};
+
+template <int P>
+struct Moments
+{
+    static constexpr int PT = P * (P + 1) / 2;
+    double A[PT];
+    double u[P];
+    double s;
+    double ml[P];
+};
+
+__device__ __forceinline__ double load_data(const KernelArgs &ka, size_t idx)
+{
+    return ka.cfg.data_f64 ? ((const double *)ka.data)[idx] : (double)((const float *)ka.data)[idx];
+}
+
+// MVNDist::GetCovariance (dist_mvn.cc:232-265)
+template <int P>
+__device__ __forceinline__ bool ensure_cov(VoxelState<P> &st)
+{
+    if (st.covValid)
+        return true;
+    int sign;
+    double logabs;
+    bool ok = mvn_invert<P>(st.Lam, st.Sig, logabs, sign);
+    st.logdetLam = logabs;
+    st.covValid = true;
+    return ok;
+}
+// MVNDist::GetPrecisions (dist_mvn.cc:197-230)
+template <int P>
+__device__ __forceinline__ bool ensure_prec(VoxelState<P> &st)
+{
+    if (st.precValid)
+        return true;
+    int sign;
+    double logabs;
+    bool ok = mvn_invert<P>(st.Sig, st.Lam, logabs, sign);
+    st.logdetLam = -logabs;
+    st.precValid = true;
+    return ok;
+}
+
+// LinearizedFwdModel::ReCentre (fwdmodel_linear.cc:126-182) fused with the J'J / J'r / r'r
+// accumulations of UpdateTheta / UpdateNoise / CalcFreeEnergy. J(t,i) = (f(c + d e_i)(t) -
+// f(c - d e_i)(t)) / (c2_i - c3_i) exactly as the reference, except that the division is a
+// multiplication by the once-computed reciprocal (<= 1 ulp per Jacobian entry).
+template <class Model, int P>
+__device__ __forceinline__ int recentre(
+    const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P], Moments<P> &mo)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const int T = ka.cfg.n_times;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    double tp[P], tp2[P], tp3[P], rden[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        const int tr = ka.cfg.transform[i];
+        double delta = centre[i] * 1e-5; // fwdmodel_linear.cc:157-161
+        if (delta < 0)
+            delta = -delta;
+        if (delta < 1e-10)
+            delta = 1e-10;
+        const double c2 = centre[i] + delta;
+        const double c3 = centre[i] - delta;
+        tp[i] = to_model(tr, centre[i]); // fwdmodel.cc:375-379
+        tp2[i] = to_model(tr, c2);
+        tp3[i] = to_model(tr, c3);
+        rden[i] = 1.0 / (c2 - c3);
+        mo.ml[i] = centre[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        mo.A[i] = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        mo.u[i] = 0;
+    mo.s = 0;
+    bool bad_offset = false, bad_jac = false;
+    const uint8_t *phi_index = ka.cfg.phi_index;
+    for (int t = 0; t < T; t++)
+    {
+        const double g = Model::eval(ma, t, tp);
+        double J[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            FVB_NO_CONTRACT
+            double q[P];
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                q[j] = tp[j];
+            q[i] = tp2[i];
+            const double f2 = Model::eval(ma, t, q);
+            q[i] = tp3[i];
+            const double f3 = Model::eval(ma, t, q);
+            J[i] = (f2 - f3) * rden[i];
+            bad_jac |= !is_finite(J[i]);
+        }
+        bad_offset |= !is_finite(g);
+        const bool unmasked = phi_index ? (phi_index[t] != 255) : true; // wave-uniform
+        if (unmasked)
+        {
+            const double r = load_data(ka, (size_t)t * V + v) - g;
+#pragma unroll
+            for (int i = 0; i < P; i++)
+            {
+#pragma unroll
+                for (int j = 0; j <= i; j++)
+                    mo.A[tri(i, j)] += J[i] * J[j];
+                mo.u[i] += J[i] * r;
+            }
+            mo.s += r * r;
+        }
+    }
+    return bad_offset ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
+}
+
+// Prior::ApplyToMVN for every parameter (inference_vb.cc:460-463; priors.cc:108-181). Returns
+// the value of the LAST prior's free-energy term ('=' not '+=' in the reference).
+template <int P, bool NEEDF>
+__device__ __forceinline__ bool apply_priors(const KernelArgs &ka, int v, int it, VoxelState<P> &st, double &Fprior)
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+    {
+        const int type = ka.cfg.prior_type[k];
+        double fk = 0;
+        if (type == FVB_PRIOR_ARD) // priors.cc:150-181
+        {
+            ok &= ensure_cov<P>(st);
+            const double post_mean = st.m[k];
+            const double post_cov = st.Sig[tri(k, k)];
+            const double new_cov = post_mean * post_mean + post_cov;
+            if (it == 0)
+            {
+                st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
+                st.pm[k] = ka.cfg.prior_mean[k];
+            }
+            else
+            {
+                st.pprec[k] = 1.0 / new_cov;
+            }
+            if (NEEDF)
+            {
+                const double bb = 2 / new_cov;
+                fk = -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
+            }
+        }
+        else if (type == FVB_PRIOR_IMAGE) // priors.cc:133-142
+        {
+            st.pm[k] = ka.cfg.image_prior[k][v];
+            st.pprec[k] = ka.cfg.prior_prec[k];
+        }
+        else // priors.cc:108-117
+        {
+            st.pm[k] = ka.cfg.prior_mean[k];
+            st.pprec[k] = ka.cfg.prior_prec[k];
+        }
+        Fprior = fk;
+    }
+    return ok;
+}
+
+// WhiteNoiseModel::UpdateTheta (noisemodel_white.cc:275-363), one phi
+template <int P>
+__device__ __forceinline__ bool update_theta(VoxelState<P> &st, const Moments<P> &mo, double alpha)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const double phibar = st.b * st.c; // GammaDist::CalcMean, dist_gamma.cc:21-24
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            st.Lam[tri(i, j)] = phibar * mo.A[tri(i, j)] + ((i == j) ? st.pprec[i] : 0.0); // eq (19)
+    st.precValid = true;
+    st.covValid = false;
+    if (alpha <= 0.0)
+    {
+        double rhs[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            double aml = 0;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                aml += mo.A[tri(i, j)] * mo.ml[j];
+            rhs[i] = phibar * (mo.u[i] + aml) + st.pprec[i] * st.pm[i];
+        }
+        if (!ensure_cov<P>(st))
+            return false;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            double s = 0;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                s += st.Sig[tri(i, j)] * rhs[j];
+            st.m[i] = s; // eq (20)
+        }
+    }
+    else
+    {
+        // Levenberg-Marquardt form, noisemodel_white.cc:330-350
+        double Delta[P], Mx[PT], Mi[PT];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            Delta[i] = phibar * mo.u[i] + st.pprec[i] * st.pm[i] - st.pprec[i] * mo.ml[i];
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            Mx[i] = st.Lam[i];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            Mx[tri(i, i)] += alpha * st.Lam[tri(i, i)];
+        double la;
+        int sg;
+        if (ldl_inverse<P>(Mx, Mi, la, sg))
+        {
+#pragma unroll
+            for (int i = 0; i < P; i++)
+            {
+                double s = 0;
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    s += Mi[tri(i, j)] * Delta[j];
+                st.m[i] = mo.ml[i] + s;
+            }
+        } // singular: warn and keep the means (:347-350)
+    }
+    return true;
+}
+
+// k'Qk and tr(Sigma J'QJ) from the moments
+template <int P>
+__device__ __forceinline__ void residual_terms(const VoxelState<P> &st, const Moments<P> &mo, double &kk, double &trSA)
+{
+    double d[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        d[i] = st.m[i] - mo.ml[i];
+    double du = 0, dAd = 0;
+    trSA = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        du += d[i] * mo.u[i];
+#pragma unroll
+        for (int j = 0; j < P; j++)
+        {
+            dAd += d[i] * mo.A[tri(i, j)] * d[j];
+            trSA += st.Sig[tri(i, j)] * mo.A[tri(i, j)];
+        }
+    }
+    kk = mo.s - 2 * du + dAd;
+    // k'Qk is a sum of squares in the reference. The expanded form can come out slightly
+    // negative (zero-residual data) or, when a voxel has wandered into astronomically large
+    // parameter values, hugely negative by cancellation; a negative value would make the noise
+    // scale b negative and every later logarithm NaN, which the reference never does.
+    kk = (kk > 0.0) ? kk : ((kk <= 0.0) ? 0.0 : kk); // NaN passes through
+}
+
+// WhiteNoiseModel::UpdateNoise (noisemodel_white.cc:228-273), one phi
+template <int P>
+__device__ __forceinline__ bool update_noise(const KernelArgs &ka, VoxelState<P> &st, const Moments<P> &mo)
+{
+    if (!ensure_cov<P>(st))
+        return false;
+    double kk, trSA;
+    residual_terms<P>(st, mo, kk, trSA);
+    const double tmp = kk + trSA;
+    st.b = 1 / (tmp * 0.5 + 1 / ka.cfg.noise_prior_b[0]);                   // eq (22)
+    st.c = ((double)ka.n_unmasked - 1) * 0.5 + ka.cfg.noise_prior_c[0];     // eq (21)
+    if (ka.cfg.locked_noise_stdev > 0)
+        st.b = 1 / st.c / ka.cfg.locked_noise_stdev / ka.cfg.locked_noise_stdev;
+    return true;
+}
+
+// WhiteNoiseModel::CalcFreeEnergy (noisemodel_white.cc:365-454), one phi. Returns false if
+// a NEWMAT-type failure happened; *finite is cleared if F is not finite.
+template <int P>
+__device__ __forceinline__ bool calc_free_energy(
+    const KernelArgs &ka, VoxelState<P> &st, const Moments<P> &mo, double Fprior, double &F, bool &finite)
+{
+    bool ok = ensure_cov<P>(st);
+    ok &= ensure_prec<P>(st);
+    double kk, trSA;
+    residual_terms<P>(st, mo, kk, trSA);
+    const double si = st.b, ci = st.c;
+    const double siPrior = ka.cfg.noise_prior_b[0], ciPrior = ka.cfg.noise_prior_c[0];
+    const double nq = (double)ka.n_unmasked;
+    const double expectedLogThetaDist = 0.5 * st.logdetLam - 0.5 * P * (LOG_2PI + 1);
+    const double dg = digamma(ci) + log(si);
+    const double expectedLogPhiDist = -gammaln(ci) - ci * log(si) - ci + (ci - 1) * dg;
+    double parts = dg * (nq * 0.5 + ciPrior - 1);                              // [0]
+    parts += -gammaln(ciPrior) - ciPrior * log(siPrior) - si * ci / siPrior;  // [9]
+    parts += -0.5 * si * ci * kk - 0.5 * trSA;                                // [2] (trace unscaled)
+    double logdetPrior = 0, quad = 0, trSL0 = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        logdetPrior += log(fabs(st.pprec[i]));
+        const double dm = st.m[i] - st.pm[i];
+        quad += dm * st.pprec[i] * dm;
+        trSL0 += st.Sig[tri(i, i)] * st.pprec[i];
+    }
+    parts += 0.5 * logdetPrior - 0.5 * nq * LOG_2PI - 0.5 * P * LOG_2PI; // [3]
+    parts += -0.5 * quad;                                                  // [4]
+    parts += -0.5 * trSL0;                                                 // [5]
+    F = -expectedLogThetaDist - expectedLogPhiDist + parts;
+    finite = is_finite(F);
+    F += Fprior; // Vb::CalculateF, inference_vb.cc:310
+    return ok;
+}
+
+template <int P>
+__device__ __forceinline__ void save_state(const KernelArgs &ka, int v, const VoxelState<P> &st)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    double *p = ka.save + v;
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        p[(size_t)(r++) * V] = st.m[i];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        p[(size_t)(r++) * V] = st.Lam[i];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        p[(size_t)(r++) * V] = st.Sig[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        p[(size_t)(r++) * V] = st.pm[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        p[(size_t)(r++) * V] = st.pprec[i];
+    p[(size_t)(r++) * V] = st.b;
+    p[(size_t)(r++) * V] = st.c;
+    p[(size_t)(r++) * V] = (st.precValid ? 1.0 : 0.0) + (st.covValid ? 2.0 : 0.0) + 4.0 * 0;
+    // logdetLam is recomputed on demand after a restore (validity flags decide)
+}
+
+template <int P>
+__device__ __forceinline__ void restore_state(const KernelArgs &ka, int v, VoxelState<P> &st)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    const double *p = ka.save + v;
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.m[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        st.Lam[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        st.Sig[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.pm[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.pprec[i] = p[(size_t)(r++) * V];
+    st.b = p[(size_t)(r++) * V];
+    st.c = p[(size_t)(r++) * V];
+    const int flags = (int)p[(size_t)(r++) * V];
+    // Whichever representation was valid is kept; the other is re-derived (and with it
+    // log|det Lam|) the next time it is asked for, as MVNDist does.
+    if (flags & 1)
+    {
+        st.precValid = true;
+        st.covValid = false;
+    }
+    else
+    {
+        st.precValid = false;
+        st.covValid = true;
+    }
+}
+
+template <class Model, int P, bool NEEDF>
+__global__ __launch_bounds__(64) void vb_lane_kernel(const KernelArgs ka)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    const int T = ka.cfg.n_times;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    if (v >= ka.cfg.n_voxels)
+        return;
+
+    ModelArgs ma;
+    ma.iopt0 = ka.cfg.model_iopt[0];
+    ma.dopt0 = ka.cfg.model_dopt[0];
+    ma.design = ka.cfg.design;
+
+    VoxelState<P> st;
+    Moments<P> mo;
+    int status = FVB_OK;
+
+    // ---- Vb::SetupPerVoxelDists, per-voxel part (inference_vb.cc:207-247) ----
+    if (ka.cfg.init_mvn)
+    {
+        // MVNDist::Load + GetSubmatrix + WhiteParams::InputFromMVN
+        // (dist_mvn.cc:347-374,136-166; noisemodel_white.cc:70-79)
+        constexpr int n = P + 1;
+        constexpr int nCov = n * (n + 1) / 2;
+        const double *src = ka.cfg.init_mvn + v;
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            st.Sig[i] = src[(size_t)i * V];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            st.m[i] = src[(size_t)(nCov + i) * V];
+        const double nm = src[(size_t)(nCov + P) * V];
+        const double nv = src[(size_t)tri(P, P) * V];
+        st.b = nv / nm; // GammaDist::SetMeanVariance, dist_gamma.cc:29-33
+        st.c = nm / st.b;
+    }
+    else
+    {
+        // FwdModel::GetInitialPosterior (fwdmodel.cc:284-313)
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            st.Sig[i] = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            st.m[i] = (ka.cfg.prior_type[i] == FVB_PRIOR_IMAGE) ? ka.cfg.image_prior[i][v] : ka.cfg.post_mean[i];
+            st.Sig[tri(i, i)] = ka.cfg.post_var[i];
+        }
+        if (Model::needs_data_max)
+        {
+            double data_max = load_data(ka, v);
+            for (int t = 1; t < T; t++)
+            {
+                const double y = load_data(ka, (size_t)t * V + v);
+                data_max = (y > data_max) ? y : data_max;
+            }
+            Model::init_posterior(ma, data_max, st.m);
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) // FwdModel::ToFabber, fwdmodel.cc:315-324
+        {
+            const int tr = ka.cfg.transform[i];
+            st.m[i] = to_fabber(tr, st.m[i]);
+            st.Sig[tri(i, i)] = to_fabber_var(tr, st.Sig[tri(i, i)]);
+        }
+        st.b = ka.cfg.noise_post_b[0];
+        st.c = ka.cfg.noise_post_c[0];
+    }
+    st.covValid = true;
+    st.precValid = false;
+    st.logdetLam = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) // fwd_prior = MVNDist(P): zero mean, identity (inference_vb.cc:159)
+    {
+        st.pm[i] = 0;
+        st.pprec[i] = 1;
+    }
+
+    double F = 1234.5678; // inference_vb.cc:438
+    double Fprior = 0;
+    int it = 0;
+    int hist_len = 0;
+    bool setup_failed = false;
+
+    // inference_vb.cc:235 and :443 re-centre about the same means: one pass gives both
+    status = recentre<Model, P>(ka, ma, v, st.m, mo);
+    if (status != FVB_OK)
+        setup_failed = true;
+
+    if (status == FVB_OK)
+    {
+        ConvState conv;
+        conv_init(conv, ka.cfg.convergence, ka.cfg.max_iterations, ka.cfg.max_trials, ka.cfg.min_fchange);
+        conv_reset(conv);
+        if (ka.save)
+            save_state<P>(ka, v, st); // :432-434
+        bool stop = false;
+        do
+        {
+            if (ka.save && conv_need_save(conv)) // :451-458
+                save_state<P>(ka, v, st);
+            if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
+            {
+                status = FVB_BAD_RESULT;
+                break;
+            }
+            bool finite = true;
+            if (NEEDF)
+            {
+                double Fn; // "before" :468
+                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
+                {
+                    status = FVB_BAD_RESULT;
+                    break;
+                }
+                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
+                {
+                    status = FVB_BAD_FREE_ENERGY;
+                    break;
+                }
+                F = Fn;
+            }
+            if (!update_theta<P>(st, mo, conv_lm_alpha(conv))) // :470
+            {
+                status = FVB_BAD_RESULT;
+                break;
+            }
+            if (NEEDF)
+            {
+                double Fn; // "theta" :477
+                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
+                {
+                    status = FVB_BAD_RESULT;
+                    break;
+                }
+                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
+                {
+                    status = FVB_BAD_FREE_ENERGY;
+                    break;
+                }
+                F = Fn;
+            }
+            if (!update_noise<P>(ka, st, mo)) // :479
+            {
+                status = FVB_BAD_RESULT;
+                break;
+            }
+            if (NEEDF)
+            {
+                double Fn; // "phi" :485
+                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
+                {
+                    status = FVB_BAD_RESULT;
+                    break;
+                }
+                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
+                {
+                    status = FVB_BAD_FREE_ENERGY;
+                    break;
+                }
+                F = Fn;
+            }
+            status = recentre<Model, P>(ka, ma, v, st.m, mo); // :490
+            if (status != FVB_OK)
+                break;
+            if (NEEDF)
+            {
+                double Fn; // "lin" :495
+                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
+                {
+                    status = FVB_BAD_RESULT;
+                    break;
+                }
+                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
+                {
+                    status = FVB_BAD_FREE_ENERGY;
+                    break;
+                }
+                F = Fn;
+            }
+            if (ka.out.f_history && hist_len < ka.cfg.f_history_rows) // :496-497
+                ka.out.f_history[(size_t)hist_len * V + v] = F;
+            hist_len++;
+            ++it;
+            stop = conv_test(conv, F);
+        } while (!stop);
+
+        if (status == FVB_OK)
+        {
+            if (ka.save && conv_need_save(conv)) // :506-513
+                save_state<P>(ka, v, st);
+            if (ka.save && conv_need_revert(conv)) // :516-525
+            {
+                restore_state<P>(ka, v, st);
+                status = recentre<Model, P>(ka, ma, v, st.m, mo);
+                if (status == FVB_OK && NEEDF)
+                {
+                    bool finite = true;
+                    double Fn;
+                    if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
+                        status = FVB_BAD_RESULT;
+                    else if (!finite)
+                        status = FVB_BAD_FREE_ENERGY;
+                    else
+                        F = Fn;
+                }
+            }
+        }
+    }
+
+    // ---- result MVN: MVNDist(fwd_post, noise.OutputAsMVN()) packed as MVNDist::Save does
+    // (inference_vb.cc:549-550; dist_mvn.cc:57-100,410-429; noisemodel_white.cc:55-68) ----
+    if (!ensure_cov<P>(st))
+    {
+        // GetCovariance() threw for every element: the concatenating constructor stores zeros
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            st.Sig[i] = 0;
+        if (status == FVB_OK)
+            status = FVB_BAD_RESULT;
+    }
+    {
+        double *dst = ka.out.mvn + v;
+        constexpr int n = P + 1;
+        constexpr int nCov = n * (n + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            dst[(size_t)i * V] = st.Sig[i];
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            dst[(size_t)tri(P, j) * V] = 0.0;
+        dst[(size_t)tri(P, P) * V] = st.b * st.b * st.c; // GammaDist::CalcVariance
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            dst[(size_t)(nCov + i) * V] = st.m[i];
+        dst[(size_t)(nCov + P) * V] = st.b * st.c; // GammaDist::CalcMean
+        dst[(size_t)(nCov + n) * V] = 1.0;
+    }
+    if (ka.out.f_history && hist_len < ka.cfg.f_history_rows) // :553-554
+        ka.out.f_history[(size_t)hist_len * V + v] = F;
+    hist_len++;
+    if (ka.out.f_history_len)
+        ka.out.f_history_len[v] = hist_len;
+    if (ka.out.free_energy)
+        ka.out.free_energy[v] = F;
+    if (ka.out.status)
+        ka.out.status[v] = status | (setup_failed ? 0x100 : 0);
+    if (ka.out.iterations)
+        ka.out.iterations[v] = it;
+}
+
+#endif // __HIPCC__
+
+} // namespace fvb

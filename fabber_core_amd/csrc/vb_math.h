@@ -1,0 +1,420 @@
+/*
+ * vb_math.h - scalar and small-matrix building blocks of the voxelwise VB kernels.
+ *
+ * Everything here is FVB_HD (__host__ __device__) so that the same source is compiled into the
+ * gfx950 kernels and into the host library (where the unit tests of the convergence state
+ * machine and of the special functions exercise it without a GPU).
+ */
+#pragma once
+
+#include "../../include/fabber_vb.h"
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FVB_HD __host__ __device__ __forceinline__
+#else
+#define FVB_HD inline
+#endif
+
+namespace fvb
+{
+constexpr double LOG_2PI = 1.8378770664093454835606594728112;
+
+FVB_HD bool is_finite(double x)
+{
+    // the reference's test "0 * x == 0 * x" (fwdmodel_linear.cc:134,174)
+    return (x - x) == 0.0;
+}
+
+// ---- transforms.h:114-242, transforms.cc:17-25 ----------------------------------------------
+FVB_HD double to_model(int tr, double val)
+{
+    switch (tr)
+    {
+    case FVB_TRANSFORM_LOG:
+        return exp(val);
+    case FVB_TRANSFORM_SOFTPLUS:
+        return (val < 10) ? log(1 + exp(val)) : val;
+    case FVB_TRANSFORM_FRACTIONAL:
+        return 1 / (1 + exp(val));
+    case FVB_TRANSFORM_ABS:
+        return fabs(val);
+    default:
+        return val;
+    }
+}
+FVB_HD double to_fabber(int tr, double val)
+{
+    switch (tr)
+    {
+    case FVB_TRANSFORM_LOG:
+        return log(val);
+    case FVB_TRANSFORM_SOFTPLUS:
+        return (val < 10) ? log(exp(val) - 1) : val;
+    case FVB_TRANSFORM_FRACTIONAL:
+        return log(1 / val - 1);
+    default:
+        return val;
+    }
+}
+FVB_HD double to_model_var(int tr, double val)
+{
+    switch (tr)
+    {
+    case FVB_TRANSFORM_IDENTITY:
+    case FVB_TRANSFORM_FRACTIONAL:
+        return val;
+    case FVB_TRANSFORM_LOG:
+        return exp(val);
+    default:
+    {
+        double d = to_model(tr, sqrt(val)) - to_model(tr, 0.0);
+        return d * d;
+    }
+    }
+}
+FVB_HD double to_fabber_var(int tr, double val)
+{
+    switch (tr)
+    {
+    case FVB_TRANSFORM_IDENTITY:
+    case FVB_TRANSFORM_FRACTIONAL:
+        return val;
+    case FVB_TRANSFORM_LOG:
+        return log(val);
+    default:
+    {
+        double d = to_fabber(tr, to_model(tr, 0.0) + sqrt(val));
+        return d * d;
+    }
+    }
+}
+
+// ---- tools.cc:87-98: 6-term Lanczos log-gamma -------------------------------------------------
+FVB_HD double gammaln(double x)
+{
+    double total = 1.000000000190015;
+    total += 76.18009172947146 / (x + 1);
+    total += -86.50532032941677 / (x + 2);
+    total += 24.01409824083091 / (x + 3);
+    total += -1.231739572450155 / (x + 4);
+    total += 0.1208650973866179e-2 / (x + 5);
+    total += -0.5395239384953e-5 / (x + 6);
+    return log(2.5066282746310005 * total / x) + (x + 0.5) * log(x + 5.5) - x - 5.5;
+}
+
+// ---- digamma (MISCMATHS::digamma is outside the reference tree): recurrence to x >= 10, then
+// the asymptotic series. fp64 throughout. -------------------------------------------------------
+FVB_HD double digamma(double x)
+{
+    double r = 0;
+    // at most 10 steps for the arguments VB produces (c >= 1e-6)
+    for (int i = 0; i < 10; i++)
+    {
+        if (x < 10.0)
+        {
+            r -= 1.0 / x;
+            x += 1.0;
+        }
+    }
+    const double f = 1.0 / (x * x);
+    const double t = f
+        * (-1.0 / 12.0
+              + f * (1.0 / 120.0
+                        + f * (-1.0 / 252.0
+                                  + f * (1.0 / 240.0
+                                            + f * (-1.0 / 132.0
+                                                      + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+    return r + log(x) - 0.5 / x + t;
+}
+
+// ---- packed symmetric matrices ----------------------------------------------------------------
+// Lower triangle, row-major: element (i,j), j <= i, lives at i(i+1)/2 + j - the same order as the
+// reference's MVN image rows (dist_mvn.cc:419-425), so results are stored without reshuffling.
+FVB_HD constexpr int tri(int i, int j)
+{
+    return (i >= j) ? (i * (i + 1) / 2 + j) : (j * (j + 1) / 2 + i);
+}
+
+// LDL^T factorisation + inverse + log|det| of a packed symmetric PxP matrix, fully unrolled for
+// compile-time P so that every element stays in a register. Plays the role of NEWMAT's .i() and
+// LogDeterminant() (dist_mvn.cc:213,248; noisemodel_white.cc:308,390,422): like the LU behind
+// those, only an exactly zero pivot counts as singular; non-finite values propagate.
+// Returns false if singular. logabs/sign may be ignored by the caller.
+template <int P>
+FVB_HD bool ldl_inverse(const double (&a)[P * (P + 1) / 2], double (&inv)[P * (P + 1) / 2], double &logabs, int &sign)
+{
+    double L[P * (P + 1) / 2]; // strictly lower part: multipliers; diagonal: D
+    double rD[P];
+    bool ok = true;
+    logabs = 0;
+    sign = 1;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+    {
+        double d = a[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++)
+            d -= L[tri(j, k)] * L[tri(j, k)] * L[tri(k, k)];
+        L[tri(j, j)] = d;
+        if (d == 0.0)
+            ok = false;
+        if (d < 0)
+            sign = -sign;
+        logabs += log(fabs(d));
+        const double rd = 1.0 / d;
+        rD[j] = rd;
+#pragma unroll
+        for (int i = j + 1; i < P; i++)
+        {
+            double s = a[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++)
+                s -= L[tri(i, k)] * L[tri(j, k)] * L[tri(k, k)];
+            L[tri(i, j)] = s * rd;
+        }
+    }
+    // M = L^-1 (unit lower), overwriting the strictly lower part of L column by column
+    double M[P * (P + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < P; j++)
+    {
+        M[tri(j, j)] = 1.0;
+#pragma unroll
+        for (int i = j + 1; i < P; i++)
+        {
+            double s = -L[tri(i, j)];
+#pragma unroll
+            for (int k = j + 1; k < i; k++)
+                s -= L[tri(i, k)] * M[tri(k, j)];
+            M[tri(i, j)] = s;
+        }
+    }
+    // inv = M^T D^-1 M
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+        {
+            double s = 0;
+#pragma unroll
+            for (int k = i; k < P; k++)
+                s += M[tri(k, i)] * M[tri(k, j)] * rD[k];
+            inv[tri(i, j)] = s;
+        }
+    return ok;
+}
+
+// MVNDist::GetCovariance / GetPrecisions semantics (dist_mvn.cc:197-265): invert; if singular add
+// 1e-10 to the diagonal and retry; a second failure is the NEWMAT exception the voxel loop
+// catches (inference_vb.cc:537) -> returns false.
+template <int P>
+FVB_HD bool mvn_invert(const double (&a)[P * (P + 1) / 2], double (&inv)[P * (P + 1) / 2], double &logabs, int &sign)
+{
+    if (ldl_inverse<P>(a, inv, logabs, sign))
+        return true;
+    double tmp[P * (P + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; i++)
+        tmp[i] = a[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        tmp[tri(i, i)] += 1e-10;
+    double l2;
+    int s2;
+    return ldl_inverse<P>(tmp, inv, l2, s2);
+}
+
+// ---- convergence detectors (convergence.cc:34-378) as one POD state machine --------------------
+struct ConvState
+{
+    int32_t type;
+    int32_t its, max_its;
+    int32_t trials, max_trials;
+    int32_t save, revert, trialmode, lm;
+    double prev_f, min_fchange;
+    double alpha, alphastart, alphamax;
+};
+
+FVB_HD void conv_init(ConvState &c, int type, int max_iterations, int max_trials, double min_fchange)
+{
+    c.type = type;
+    c.max_its = max_iterations + (type == FVB_CONV_TRIALMODE ? 1 : 0); // convergence.cc:145
+    c.max_trials = max_trials;
+    c.min_fchange = min_fchange;
+}
+
+// Reset(F = -99e99): convergence.cc:63-67, :80-86, :152-160, :262-276
+FVB_HD void conv_reset(ConvState &c)
+{
+    c.its = 0;
+    c.prev_f = -99e99;
+    c.save = (c.type == FVB_CONV_TRIALMODE || c.type == FVB_CONV_LM) ? 1 : 0;
+    c.revert = 0;
+    c.trials = 0;
+    c.trialmode = 0;
+    c.lm = 0;
+    c.alphastart = 1e-6;
+    c.alpha = 0.0;
+    c.alphamax = 1e6;
+}
+
+FVB_HD bool conv_need_save(const ConvState &c)
+{
+    return c.save != 0; // maxits: never true (ConvergenceDetector::NeedSave)
+}
+FVB_HD bool conv_need_revert(const ConvState &c)
+{
+    return c.revert != 0;
+}
+// LMalpha() returns float (convergence.h:73,236)
+FVB_HD double conv_lm_alpha(const ConvState &c)
+{
+    return (c.type == FVB_CONV_LM) ? (double)(float)c.alpha : 0.0;
+}
+
+FVB_HD bool conv_test_counting(ConvState &c)
+{
+    ++c.its;
+    return c.its >= c.max_its;
+}
+FVB_HD bool conv_test_fchange(ConvState &c, double F)
+{
+    double diff = F - c.prev_f;
+    c.prev_f = F;
+    diff = diff > 0 ? diff : -diff;
+    if (diff < c.min_fchange)
+        return true;
+    return conv_test_counting(c);
+}
+
+FVB_HD bool conv_test(ConvState &c, double F)
+{
+    switch (c.type)
+    {
+    case FVB_CONV_MAXITS:
+        return conv_test_counting(c);
+    case FVB_CONV_FCHANGE:
+        return conv_test_fchange(c, F);
+    case FVB_CONV_FREDUCE: // convergence.cc:117-131
+    {
+        double diff = F - c.prev_f;
+        if (diff < 0)
+        {
+            c.revert = 1;
+            return true;
+        }
+        return conv_test_fchange(c, F);
+    }
+    case FVB_CONV_TRIALMODE: // convergence.cc:162-243
+    {
+        double diff = F - c.prev_f;
+        if (!c.trialmode)
+        {
+            if (diff < 0)
+            {
+                c.its = 1;
+                c.trials = 1;
+                c.trialmode = 1;
+                c.revert = 1;
+                c.save = 0;
+                return false;
+            }
+            double absdiff = diff > 0 ? diff : -diff;
+            if (absdiff < c.min_fchange)
+            {
+                c.revert = 0;
+                c.save = 0;
+                return true;
+            }
+            c.save = 1;
+            c.revert = 0;
+            c.prev_f = F;
+            ++c.its;
+            return c.its >= c.max_its;
+        }
+        ++c.trials;
+        if (diff > 0)
+        {
+            if (diff < c.min_fchange)
+            {
+                c.revert = 0;
+                c.save = 0;
+                return true;
+            }
+            c.trialmode = 0;
+            c.trials = 0;
+            c.save = 1;
+            c.revert = 0;
+            c.prev_f = F;
+            return false;
+        }
+        if (c.trials >= c.max_trials)
+        {
+            c.save = 0;
+            c.revert = 1;
+            return true;
+        }
+        c.save = 0;
+        c.revert = 0;
+        return false;
+    }
+    default: // FVB_CONV_LM, convergence.cc:278-378
+    {
+        double diff = F - c.prev_f;
+        double absdiff = diff < 0 ? -diff : diff;
+        if (!c.lm)
+        {
+            if (diff < 0)
+            {
+                c.lm = 1;
+                c.revert = 1;
+                c.alpha = c.alphastart;
+                return false;
+            }
+            if (absdiff < c.min_fchange)
+            {
+                c.revert = 0;
+                return true;
+            }
+            if (c.its >= c.max_its)
+            {
+                c.revert = 0;
+                return true;
+            }
+            c.prev_f = F;
+            ++c.its;
+            return false;
+        }
+        if (diff > 0)
+        {
+            if (c.alpha == c.alphastart)
+                c.lm = 0;
+            else
+                c.alpha /= 10;
+            c.revert = 0;
+            c.prev_f = F;
+            ++c.its;
+            return false;
+        }
+        if (c.alpha >= c.alphamax)
+        {
+            c.revert = 1;
+            return true;
+        }
+        if (c.its >= c.max_its)
+        {
+            c.revert = 0;
+            return true;
+        }
+        c.alpha *= 10;
+        c.revert = 1;
+        return false;
+    }
+    }
+}
+
+} // namespace fvb

@@ -1,0 +1,172 @@
+"""ctypes binding of fabber_core_amd/lib/libfabber_vb_hip.so (the HIP voxelwise-VB engine).
+
+There is deliberately no fallback: if the shared library is missing or no GPU is visible the
+functions raise. Build the library with ``python -m fabber_core_amd.build``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import vbabi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfabber_vb_hip.so")
+_LIB = None
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+def available():
+    """True if the native library has been built (says nothing about a GPU being present)."""
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipEngineError("%s not built: run `python -m fabber_core_amd.build` (no CPU fallback exists)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        cfgp, outp, ppp = C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbOutputs), C.POINTER(vbabi.FvbPostproc)
+        L.fabber_vb_mvn_rows.restype = C.c_int32
+        L.fabber_vb_mvn_rows.argtypes = [C.c_int32]
+        L.fabber_vb_abi_version.restype = C.c_int32
+        L.fabber_vb_device_count.restype = C.c_int32
+        L.fabber_vb_last_error.restype = C.c_char_p
+        L.fabber_vb_kernel_name.restype = C.c_char_p
+        L.fabber_vb_kernel_name.argtypes = [cfgp]
+        L.fabber_vb_set_variant.argtypes = [C.c_int32]
+        L.fabber_vb_run_device.restype = C.c_int32
+        L.fabber_vb_run_device.argtypes = [cfgp, C.c_void_p, outp, C.c_void_p]
+        L.fabber_vb_run_device_ex.restype = C.c_int32
+        L.fabber_vb_run_device_ex.argtypes = [cfgp, C.c_void_p, outp, C.c_void_p, C.c_int32]
+        L.fabber_vb_run_host.restype = C.c_int32
+        L.fabber_vb_run_host.argtypes = [cfgp, C.c_void_p, outp, C.c_int32]
+        L.fabber_vb_postproc_device.restype = C.c_int32
+        L.fabber_vb_postproc_device.argtypes = [cfgp, C.c_void_p, C.c_void_p, ppp, C.c_void_p]
+        L.fabber_vb_postproc_host.restype = C.c_int32
+        L.fabber_vb_postproc_host.argtypes = [cfgp, C.c_void_p, C.c_void_p, ppp, C.c_int32]
+        L.fabber_vb_convergence_trace.restype = C.c_int32
+        L.fabber_vb_convergence_trace.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        for name in ("fabber_vb_gammaln", "fabber_vb_digamma"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double]
+        L.fabber_vb_transform.restype = C.c_double
+        L.fabber_vb_transform.argtypes = [C.c_int32, C.c_int32, C.c_double]
+        L.fabber_vb_ldl_inverse.restype = C.c_int32
+        L.fabber_vb_ldl_inverse.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        if L.fabber_vb_abi_version() != vbabi.FVB_ABI_VERSION:
+            raise HipEngineError("libfabber_vb_hip.so ABI version mismatch: rebuild")
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipEngineError("fabber_vb error %d: %s" % (rc, lib().fabber_vb_last_error().decode()))
+
+
+def device_count():
+    return lib().fabber_vb_device_count()
+
+
+def kernel_name(holder):
+    return lib().fabber_vb_kernel_name(C.byref(holder.cfg)).decode()
+
+
+def set_variant(variant):
+    lib().fabber_vb_set_variant({"auto": 0, "lane": 1, "wave": 2}.get(variant, variant))
+
+
+def n_unmasked(holder):
+    phi = holder.keep.get("phi_index")
+    return int(holder.cfg.n_times if phi is None else np.count_nonzero(phi != 255))
+
+
+def _prepare_data(holder, data):
+    cfg = holder.cfg
+    data = np.ascontiguousarray(data)
+    if data.dtype == np.float64:
+        cfg.data_f64 = 1
+    else:
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        cfg.data_f64 = 0
+    assert data.shape == (cfg.n_times, cfg.n_voxels), (data.shape, cfg.n_times, cfg.n_voxels)
+    return data
+
+
+def run_host(holder, data, device=0):
+    """Voxelwise VB on the GPU from host arrays (config pointers are host numpy arrays).
+    Returns the same dict of arrays as tests/oracle.py:run."""
+    cfg = holder.cfg
+    data = _prepare_data(holder, data)
+    V = cfg.n_voxels
+    arrs = dict(
+        mvn=np.full((holder.n_mvn_rows, V), np.nan),
+        free_energy=np.full(V, np.nan),
+        status=np.full(V, -1, dtype=np.int32),
+        iterations=np.full(V, -1, dtype=np.int32),
+        f_history_len=np.zeros(V, dtype=np.int32),
+    )
+    if cfg.f_history_rows > 0:
+        arrs["f_history"] = np.full((cfg.f_history_rows, V), np.nan)
+    out = vbabi.FvbOutputs()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    _check(lib().fabber_vb_run_host(C.byref(cfg), data.ctypes.data, C.byref(out), device))
+    arrs["setup_failed"] = (arrs["status"] & 0x100) != 0
+    arrs["status"] = arrs["status"] & 0xFF
+    return arrs
+
+
+def postproc_host(holder, data, mvn, want=("mean", "var", "std", "zstat", "modelfit", "residuals", "noise_mean", "noise_std"),
+                  device=0):
+    cfg = holder.cfg
+    V, T, P, N = cfg.n_voxels, cfg.n_times, cfg.n_params, holder.n_noise_outputs
+    shapes = dict(mean=(P, V), var=(P, V), std=(P, V), zstat=(P, V), modelfit=(T, V), residuals=(T, V),
+                  noise_mean=(N, V), noise_std=(N, V))
+    data = _prepare_data(holder, data)
+    mvn = np.ascontiguousarray(mvn, dtype=np.float64)
+    pp = vbabi.FvbPostproc()
+    arrs = {}
+    for k in want:
+        arrs[k] = np.full(shapes[k], np.nan)
+        setattr(pp, k, arrs[k].ctypes.data)
+    _check(lib().fabber_vb_postproc_host(C.byref(cfg), data.ctypes.data, mvn.ctypes.data, C.byref(pp), device))
+    return arrs
+
+
+def convergence_trace(conv, F, max_iterations=10, max_trials=10, min_fchange=0.01, stop_at_done=True):
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    n = len(F)
+    done = np.zeros(n, dtype=np.int32)
+    save = np.zeros(n, dtype=np.int32)
+    revert = np.zeros(n, dtype=np.int32)
+    alpha = np.zeros(n)
+    conv = vbabi.CONV_NAMES[conv] if isinstance(conv, str) else conv
+    m = lib().fabber_vb_convergence_trace(conv, max_iterations, max_trials, min_fchange, F.ctypes.data, n,
+                                          done.ctypes.data, save.ctypes.data, revert.ctypes.data, alpha.ctypes.data,
+                                          int(stop_at_done))
+    return done[:m].astype(bool), save[:m].astype(bool), revert[:m].astype(bool), alpha[:m]
+
+
+def ldl_inverse(a):
+    """Host twin of the in-register LDL^T inverse; a: symmetric PxP. Returns (inv, logabs, sign, ok)."""
+    a = np.asarray(a, dtype=np.float64)
+    P = a.shape[0]
+    packed = np.array([a[i, j] for i in range(P) for j in range(i + 1)])
+    inv = np.zeros_like(packed)
+    logabs = C.c_double()
+    sign = C.c_int32()
+    rc = lib().fabber_vb_ldl_inverse(P, packed.ctypes.data, inv.ctypes.data, C.byref(logabs), C.byref(sign))
+    out = np.zeros((P, P))
+    k = 0
+    for i in range(P):
+        for j in range(i + 1):
+            out[i, j] = out[j, i] = inv[k]
+            k += 1
+    return out, logabs.value, sign.value, rc == 0

@@ -204,6 +204,12 @@ const char *fabber_vb_kernel_name(const fvb_config *cfg);
  */
 int32_t fabber_vb_run_device(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream);
 
+/* As fabber_vb_run_device, for callers that already know the number of unmasked timepoints
+ * (n_times minus the 255 entries of phi_index): saves the small device-to-host read of
+ * phi_index, so the call never synchronises. */
+int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream,
+    int32_t n_unmasked);
+
 /* Same with HOST pointers: uploads, runs, downloads, synchronises. `device` = HIP device index. */
 int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device);
 

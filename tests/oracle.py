@@ -12,6 +12,7 @@ from fabber_core_amd import vbabi
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
+_LIB_FMA = None
 
 
 class OracleTrace(C.Structure):
@@ -51,6 +52,22 @@ def lib():
     return _LIB
 
 
+def lib_fma():
+    """Second CPU build of the same source with FMA contraction (oracle/Makefile)."""
+    global _LIB_FMA
+    if _LIB_FMA is None:
+        path = os.path.join(_ROOT, "oracle", "liboracle_fma.so")
+        src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_fma.so"])
+        L = C.CDLL(path)
+        L.oracle_vb_run.restype = C.c_int32
+        L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        _LIB_FMA = L
+    return _LIB_FMA
+
+
 def alloc_outputs(holder):
     """Host result arrays for a config, plus the FvbOutputs struct pointing at them."""
     cfg = holder.cfg
@@ -83,7 +100,12 @@ def prepare_data(holder, data):
     return data
 
 
-def run(holder, data, v_begin=0, v_end=None, halt_bad_voxel=False, trace_rows=0):
+def run_fma(holder, data):
+    """The oracle compiled with FMA contraction: same algorithm, different rounding."""
+    return run(holder, data, _lib=lib_fma())
+
+
+def run(holder, data, v_begin=0, v_end=None, halt_bad_voxel=False, trace_rows=0, _lib=None):
     """Run the oracle. data: float32 [n_times][n_voxels]. Returns dict of result arrays."""
     cfg = holder.cfg
     data = prepare_data(holder, data)
@@ -97,7 +119,7 @@ def run(holder, data, v_begin=0, v_end=None, halt_bad_voxel=False, trace_rows=0)
         trp = C.addressof(tr)
     if v_end is None:
         v_end = cfg.n_voxels
-    rc = lib().oracle_vb_run(C.byref(cfg), data.ctypes.data, C.byref(out), v_begin, v_end, int(halt_bad_voxel), trp)
+    rc = (_lib or lib()).oracle_vb_run(C.byref(cfg), data.ctypes.data, C.byref(out), v_begin, v_end, int(halt_bad_voxel), trp)
     if rc < 0:
         raise RuntimeError("oracle_vb_run failed: %d" % rc)
     arrs["first_bad_voxel"] = rc

@@ -1,0 +1,114 @@
+"""Comparison helpers shared by the parity tests, smoke() and bench.py.
+
+Two kinds of comparison are needed because of a property of the REFERENCE ALGORITHM itself
+(see DESIGN.md "Numerical reproducibility of the reference algorithm"):
+
+* strict() - per voxel, for well-conditioned problems (polynomial, design-matrix and
+  single-exponential models; one VB iteration of any model from an identical state). The
+  tolerances are set by the reference's own numerical Jacobian: a central difference with step
+  1e-5|theta| (floor 1e-10) amplifies last-bit differences of the model prediction by
+  |f| / (2 delta), i.e. up to ~1e-6 relative in J and more in the covariance.
+
+* population() - for the bi-exponential fit. Its first iterations start from two identical
+  decay rates, J'J is numerically singular, and the iteration map amplifies rounding noise by
+  ~1e11 within four iterations: two CPU builds of the same oracle source (with / without FMA
+  contraction) already disagree by more than 1e-4 on a quarter of the voxels after 50
+  iterations. Per-voxel agreement with "the" CPU result is therefore not a property any
+  non-bit-identical implementation (or the reference itself on another compiler) can have; what
+  can and must agree is the population: share of voxels that agree, share of failed voxels,
+  distribution of the fitted noise precision / free energy.
+"""
+import numpy as np
+
+import oracle
+
+TOL_MEAN = 1e-6   # |d mean| <= TOL_MEAN * max(|mean|, posterior sd)
+TOL_COV = 2e-4    # |d cov_ij| <= TOL_COV * sd_i sd_j   (finite-difference noise, see above)
+TOL_F = 1e-6      # |dF| <= TOL_F * max(1, |F|)
+NORTH_STAR = 1e-4  # BASELINE.json: posterior means within 1e-4 relative
+
+
+def voxel_errors(holder, a, b, mask=None):
+    """Per-voxel scaled errors between result dicts a (CPU) and b (GPU)."""
+    cfg = holder.cfg
+    P, n = cfg.n_params, cfg.n_params + holder.n_noise_outputs
+    if mask is None:
+        mask = np.ones(a["mvn"].shape[1], dtype=bool)
+    cov_a, mean_a = oracle.unpack_mvn(a["mvn"][:, mask], n)
+    cov_b, mean_b = oracle.unpack_mvn(b["mvn"][:, mask], n)
+    sd = np.sqrt(np.abs(np.einsum("vii->vi", cov_a)))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e_mean = np.nanmax(np.abs(mean_a - mean_b) / np.maximum(np.abs(mean_a), sd), axis=1)
+        e_cov = np.nanmax((np.abs(cov_a - cov_b) / (sd[:, :, None] * sd[:, None, :])).reshape(len(sd), -1), axis=1)
+        rel = np.nanmax(np.abs(mean_a[:, :P] - mean_b[:, :P]) / np.maximum(np.abs(mean_a[:, :P]), 1e-12), axis=1)
+    return e_mean, e_cov, rel
+
+
+def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=None, allow_iter_mismatch=0, cpu2=None):
+    """Per-voxel parity: status and iteration counts identical, values within tolerance.
+
+    cpu2 (optional) = result of the second CPU build (oracle.run_fma). If two CPU builds of the
+    same source already differ by more than the base tolerance on this problem (the
+    finite-difference Jacobian amplifies rounding, see module docstring), the tolerance is
+    raised to 10x that measured floor - but never beyond the north-star bound of 1e-4 on the
+    means (1e-2 sd_i sd_j on covariances)."""
+    cfg = holder.cfg
+    tol_f = TOL_F
+    if cpu2 is not None:
+        okf = (a["status"] == 0) & (cpu2["status"] == 0) & (a["iterations"] == cpu2["iterations"])
+        if okf.any():
+            f_mean, f_cov, _ = voxel_errors(holder, a, cpu2, okf)
+            tol_mean = min(max(tol_mean, 10 * float(f_mean.max())), NORTH_STAR)
+            tol_cov = min(max(tol_cov, 10 * float(f_cov.max())), 1e-2)
+            if cfg.need_f:
+                Fa, Fc = a["free_energy"][okf], cpu2["free_energy"][okf]
+                tol_f = min(max(tol_f, 10 * float(np.max(np.abs(Fa - Fc) / np.maximum(1.0, np.abs(Fa))))), 1e-3)
+    assert np.array_equal(a["status"], b["status"]), (what, "status", np.flatnonzero(a["status"] != b["status"])[:8])
+    n_it = int(np.count_nonzero(a["iterations"] != b["iterations"]))
+    assert n_it <= allow_iter_mismatch, (what, "iterations differ on %d voxels" % n_it)
+    ok = (a["status"] == 0) & (a["iterations"] == b["iterations"])
+    out = dict(err_means=0.0, err_cov=0.0, rel_means=0.0, err_f=0.0)
+    if not ok.any():
+        return out
+    e_mean, e_cov, rel = voxel_errors(holder, a, b, ok)
+    out.update(err_means=float(e_mean.max()), err_cov=float(e_cov.max()), rel_means=float(rel.max()))
+    assert out["err_means"] <= tol_mean, (what, "means", out["err_means"], tol_mean)
+    assert out["err_cov"] <= tol_cov, (what, "cov", out["err_cov"], tol_cov)
+    if check_f if check_f is not None else bool(cfg.need_f):
+        Fa, Fb = a["free_energy"][ok], b["free_energy"][ok]
+        out["err_f"] = float(np.max(np.abs(Fa - Fb) / np.maximum(1.0, np.abs(Fa))))
+        assert out["err_f"] <= tol_f, (what, "F", out["err_f"], tol_f)
+    return out
+
+
+def population_stats(holder, a, b):
+    """Agreement statistics between two runs of a chaotic problem."""
+    cfg = holder.cfg
+    n = cfg.n_params + holder.n_noise_outputs
+    off = n * (n + 1) // 2
+    both = (a["status"] == 0) & (b["status"] == 0)
+    e_mean, e_cov, rel = voxel_errors(holder, a, b, both)
+    phi_a = a["mvn"][off + cfg.n_params][a["status"] == 0]
+    phi_b = b["mvn"][off + cfg.n_params][b["status"] == 0]
+    q = [0.1, 0.5, 0.9]
+    return dict(
+        frac_within_1e4=float(np.mean(e_mean <= NORTH_STAR)),
+        frac_within_1e6=float(np.mean(e_mean <= 1e-6)),
+        median_err=float(np.median(e_mean)),
+        bad_a=float(np.mean(a["status"] != 0)), bad_b=float(np.mean(b["status"] != 0)),
+        phi_quantiles_a=np.quantile(phi_a, q), phi_quantiles_b=np.quantile(phi_b, q),
+        iters_a=float(np.mean(a["iterations"])), iters_b=float(np.mean(b["iterations"])),
+    )
+
+
+def population(holder, cpu, gpu, floor, what="", slack=0.05):
+    """gpu-vs-cpu agreement must be as good as cpu-vs-cpu' agreement (floor = population_stats
+    of the two CPU builds), within `slack` (absolute, on shares) / 3 % (on quantiles)."""
+    s = population_stats(holder, cpu, gpu)
+    assert s["frac_within_1e4"] >= floor["frac_within_1e4"] - slack, (what, s, floor)
+    assert s["frac_within_1e6"] >= floor["frac_within_1e6"] - slack, (what, s, floor)
+    assert s["median_err"] <= max(10 * floor["median_err"], 1e-7), (what, s, floor)
+    assert s["bad_b"] <= max(2 * max(floor["bad_a"], floor["bad_b"]), 0.005), (what, s, floor)
+    assert np.allclose(s["phi_quantiles_b"], s["phi_quantiles_a"], rtol=0.03), (what, s)
+    assert abs(s["iters_b"] - s["iters_a"]) <= 0.05 * max(s["iters_a"], 1.0) + 0.5, (what, s)
+    return s

@@ -85,7 +85,16 @@ def test_trialmode_reduce(impl):
     seq += [(F0 - 2 * i * FCHANGE, False) for i in range(MAXTRIALS - 1)]
     seq += [(F0 - 2 * MAXTRIALS * FCHANGE, True)]
     check(impl, "trialmode", seq)
-    seq = [(F0, False), (F0 + 2 * FCHANGE, False), (F0, False), (F0 + 2 * FCHANGE, False)]
+    # Second half of the reference's TestTrialModeConvergenceDetectorReduce
+    # (test_convergence.cc:286-304). The test's comment expects the repeat of F0 + 2 FCHANGE to
+    # "reset number of trials", but convergence.cc:200-243 as written compares with 'diff > 0'
+    # and the repeated value gives diff == 0 exactly, so it counts as a trial and the next
+    # decrease is the third trial = max-trials -> stop. The code, not the stale expectation, is
+    # what the product must reproduce.
+    seq = [(F0, False), (F0 + 2 * FCHANGE, False), (F0, False), (F0 + 2 * FCHANGE, False), (F0, True)]
+    check(impl, "trialmode", seq)
+    # With a genuine increase over the best F the trial counter does reset (convergence.cc:216-226)
+    seq = [(F0, False), (F0 + 2 * FCHANGE, False), (F0, False), (F0 + 4 * FCHANGE, False)]
     seq += [(F0 - 2 * i * FCHANGE, False) for i in range(MAXTRIALS - 1)]
     seq += [(F0 - 2 * MAXTRIALS * FCHANGE, True)]
     check(impl, "trialmode", seq)
