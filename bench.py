@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--voxels", type=int, default=None, help="voxels per GPU (default: the workload's)")
     ap.add_argument("--need-f", action="store_true", help="also evaluate the free energy 4x per iteration (CLI default of the reference)")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="voxels timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="voxels timed on the CPU oracle (0 = skip)")
     ap.add_argument("--variant", default="auto", choices=["auto", "lane", "wave"])
     args = ap.parse_args()
 
@@ -158,23 +158,31 @@ def main():
         cpu = None
         if args.cpu_sample > 0:
             import oracle
+            import parity
             ns = min(args.cpu_sample, V)
             hs, _ = cases.exp_problem(ns, T, w["num_exps"], w["dt"], seed=1, max_iterations=w["its"], need_f=bool(args.need_f))
             ys = np.ascontiguousarray(y[:, :ns])
-            oracle.run(hs, ys[:, :64].repeat(ns // 64 + 1, axis=1)[:, :ns])  # page in
+            oracle.run(hs, ys, v_end=min(64, ns))  # page the library in
             c0 = time.perf_counter()
             ref = oracle.run(hs, ys)
             cpu_s = time.perf_counter() - c0
             got = prob.results()
-            n = P + 1
-            off = n * (n + 1) // 2
-            ok = (ref["status"] == 0) & (got["status"][:ns] == 0)
-            a, b = ref["mvn"][off:off + P][:, ok], got["mvn"][off:off + P, :ns][:, ok]
-            dmean = float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-12)))
+            gpu = {k: (v[:, :ns] if v.ndim == 2 else v[:ns]) for k, v in got.items()}
+            # Parity on the sample. The bi-exponential fit is chaotic: compare the
+            # GPU-vs-CPU agreement with the agreement of two CPU builds of the same oracle source.
+            nf = min(ns, 4096)
+            hf, _ = cases.exp_problem(nf, T, w["num_exps"], w["dt"], seed=1, max_iterations=w["its"], need_f=bool(args.need_f))
+            yf = np.ascontiguousarray(ys[:, :nf])
+            ref_f = {k: (v[:, :nf] if v.ndim == 2 else v[:nf]) for k, v in ref.items() if isinstance(v, np.ndarray)}
+            floor = parity.population_stats(hf, ref_f, oracle.run_fma(hf, yf))
+            stats = parity.population_stats(hs, ref, gpu)
+            tolist = lambda d: {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in d.items()}
             cpu = {"value": ns / cpu_s, "unit": "voxels/s", "cores": 1, "kind": "port",
                    "sample": "first %d voxels of rank 0's shard, same model/iterations, oracle/liboracle.so single thread, %.1f s" % (ns, cpu_s),
-                   "host_cpus": os.cpu_count(), "max_rel_dmean_vs_cpu": dmean,
-                   "gpu_over_cpu_single_thread": (V / (k_ms * 1e-3)) / (ns / cpu_s)}
+                   "host_cpus": os.cpu_count(),
+                   "gpu_over_cpu_single_thread": (V / (k_ms * 1e-3)) / (ns / cpu_s),
+                   "posterior_mean_error_definition": "max over parameters+noise of |d mean| / max(|mean|, posterior sd), per voxel",
+                   "gpu_vs_cpu": tolist(stats), "cpu_vs_cpu_fma_build_floor": tolist(floor)}
         result = {
             "metric": "voxels/sec to VB convergence", "value": value, "unit": "voxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
