@@ -90,8 +90,67 @@ def build_hip(force=False, jobs=None, verbose=True, extra_flags=()):
     return lib
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_FLAGS = ["-O2", "-g", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-parameter", "-Wno-deprecated-declarations"]
+
+
+def _host_sources():
+    return sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".cc"))
+
+
+def _compile_host_one(args):
+    src, force = args
+    obj = os.path.join(OBJDIR, "host_" + os.path.basename(src) + ".o")
+    stamp_file = obj + ".stamp"
+    h = hashlib.sha256()
+    h.update(" ".join(HOST_FLAGS).encode())
+    deps = [src] + _headers() + [os.path.join(d, f) for d in (os.path.join(HOST_DIR, "fabber_core"), os.path.join(HOST_DIR, "armawrap"))
+                                 for f in sorted(os.listdir(d))]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "fabber_capi.h"))
+    for f in deps:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    stamp = h.hexdigest()
+    if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj, False
+    cmd = ["g++"] + HOST_FLAGS + ["-I", HOST_DIR, "-I", os.path.join(HOST_DIR, "fabber_core"), "-c", src, "-o", obj]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), p.stdout, p.stderr))
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return obj, True
+
+
+def build_host(force=False, jobs=None, verbose=True):
+    """libfabbercore_amd.so: the reference's plugin classes + fabber_capi, linked against the
+    HIP engine library that sits next to it (rpath $ORIGIN)."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    work = [(s, force) for s in _host_sources()]
+    objs, rebuilt = [], False
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 4)) as ex:
+        for obj, did in ex.map(_compile_host_one, work):
+            objs.append(obj)
+            rebuilt |= did
+            if verbose and did:
+                print("[build] compiled", os.path.basename(obj), file=sys.stderr)
+    lib = os.path.join(LIBDIR, "libfabbercore_amd.so")
+    engine = os.path.join(LIBDIR, "libfabber_vb_hip.so")
+    if rebuilt or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(engine):
+        cmd = ["g++", "-shared", "-fPIC", "-o", lib] + objs + ["-L", LIBDIR, "-lfabber_vb_hip", "-ldl", "-Wl,-rpath,$ORIGIN",
+                                                                "-Wl,--no-undefined"]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s\n%s" % (" ".join(cmd), p.stdout, p.stderr))
+        if verbose:
+            print("[build] linked", lib, file=sys.stderr)
+    return lib
+
+
 def build_all(force=False, jobs=None, verbose=True):
     libs = [build_hip(force=force, jobs=jobs, verbose=verbose)]
+    libs.append(build_host(force=force, jobs=jobs, verbose=verbose))
     return libs
 
 

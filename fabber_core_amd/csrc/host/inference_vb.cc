@@ -1,0 +1,527 @@
+// inference_vb.cc - the "vb" technique: host driver of the MI355X voxelwise VB engine.
+//
+// Replaces Vb::Initialize / DoCalculations / SaveResults of the reference
+// (inference_vb.cc:100-130, 360-576, 966-1051) and InferenceTechnique::SaveResults
+// (inference.cc:112-281). Everything per-voxel happens inside fabber_vb_run_host /
+// fabber_vb_postproc_host (HIP kernels); this file only resolves options into the engine's
+// problem block, turns per-voxel status words back into the reference's error behaviour, and
+// stores the result images in the run data. There is no CPU path: without a GPU the engine
+// call fails and the failure is reported as a FabberInternalError.
+#include "inference_vb.h"
+
+#include "convergence.h"
+#include "priors.h"
+#include "version.h"
+
+#include "../../../include/fabber_vb.h"
+
+#include <cstring>
+#include <math.h>
+#include <memory>
+
+using namespace std;
+using NEWMAT::ColumnVector;
+using NEWMAT::Matrix;
+
+// ---------------------------------------------------------------------------------------------
+// InferenceTechnique base
+// ---------------------------------------------------------------------------------------------
+std::vector<std::string> InferenceTechnique::GetKnown()
+{
+    return InferenceTechniqueFactory::GetInstance()->GetNames();
+}
+
+InferenceTechnique *InferenceTechnique::NewFromName(const string &name)
+{
+    InferenceTechnique *inf = InferenceTechniqueFactory::GetInstance()->Create(name);
+    if (!inf)
+        throw InvalidOptionValue("method", name, "Unrecognized inference method");
+    return inf;
+}
+
+void InferenceTechnique::UsageFromName(const string &name, std::ostream &stream)
+{
+    std::unique_ptr<InferenceTechnique> inf(NewFromName(name));
+    stream << "Usage information for method: " << name << endl << endl << inf->GetDescription() << endl << endl << "Options: " << endl << endl;
+    vector<OptionSpec> options;
+    inf->GetOptions(options);
+    for (size_t i = 0; i < options.size(); i++)
+        stream << options[i];
+}
+
+InferenceTechnique::InferenceTechnique()
+    : m_model(NULL)
+    , m_num_params(0)
+    , m_halt_bad_voxel(true)
+{
+}
+
+InferenceTechnique::~InferenceTechnique()
+{
+    for (size_t i = 0; i < resultMVNs.size(); i++)
+        delete resultMVNs[i];
+}
+
+void InferenceTechnique::Initialize(FwdModel *fwd_model, FabberRunData &rundata)
+{
+    m_log = rundata.GetLogger();
+    m_debug = rundata.GetBool("debug");
+    m_model = fwd_model;
+    vector<Parameter> params;
+    m_model->GetParameters(rundata, params);
+    m_num_params = (int)params.size();
+    LOG << "InferenceTechnique::Model has " << m_num_params << " parameters" << endl;
+    m_masked_tpoints = rundata.GetIntList("mt", 1);
+    m_halt_bad_voxel = !rundata.GetBool("allow-bad-voxels");
+    LOG << (m_halt_bad_voxel ? "InferenceTechnique::Note: numerical errors in voxels will cause the program to halt.\n"
+                               "InferenceTechnique::Use --allow-bad-voxels (with caution!) to keep on calculating.\n"
+                             : "InferenceTechnique::Using --allow-bad-voxels: numerical errors in a voxel only stop that voxel.\n");
+}
+
+void InferenceTechnique::SaveResults(FabberRunData &rundata) const
+{
+    if (rundata.GetBool("save-mvn"))
+    {
+        Matrix image = m_result_image;
+        rundata.SaveVoxelData("finalMVN", image, VDT_MVN);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vb
+// ---------------------------------------------------------------------------------------------
+struct Vb::EngineStorage
+{
+    fvb_config cfg;
+    Matrix design;                           // T x P row-major = engine layout
+    vector<unsigned char> phi_index;         // per timepoint
+    vector<vector<double> > image_priors;    // per parameter
+    Matrix init_mvn;                         // continue-from-mvn
+    vector<Parameter> params;
+    vector<string> model_outputs;
+    bool has_device_model;
+};
+
+static OptionSpec VB_OPTIONS[] = {
+    { "noise", OPT_STR, "Noise model to use (white or ar1)", OPT_REQ, "" },
+    { "convergence", OPT_STR, "Name of method for detecting convergence", OPT_NONREQ, "maxits" },
+    { "max-iterations", OPT_STR, "number of iterations of VB to use with the maxits convergence detector", OPT_NONREQ, "10" },
+    { "min-fchange", OPT_STR, "When using the fchange convergence detector, the change in F to stop at", OPT_NONREQ, "10" },
+    { "max-trials", OPT_STR, "When using the trial mode convergence detector, the maximum number of trials after an initial reduction in F", OPT_NONREQ, "10" },
+    { "print-free-energy", OPT_BOOL, "Output the free energy in the log", OPT_NONREQ, "" },
+    { "save-free-energy-history", OPT_BOOL, "Save the free energy of every iteration", OPT_NONREQ, "" },
+    { "mcsteps", OPT_INT, "Number of motion correction steps", OPT_NONREQ, "0" },
+    { "continue-from-mvn", OPT_MVN, "Continue previous run from output MVN files", OPT_NONREQ, "" },
+    { "output-only", OPT_BOOL, "Skip model fitting, just output requested data based on supplied MVN", OPT_NONREQ, "" },
+    { "noise-initial-prior", OPT_MATRIX, "MVN of initial noise prior", OPT_NONREQ, "" },
+    { "noise-initial-posterior", OPT_MATRIX, "MVN of initial noise posterior", OPT_NONREQ, "" },
+    { "noise-pattern", OPT_STR, "repeating pattern of noise variances for each point (e.g. 12 gives odd and even data points different variances)", OPT_NONREQ, "1" },
+    { "PSP_byname<n>", OPT_STR, "Name of model parameter to use prior", OPT_NONREQ, "" },
+    { "PSP_byname<n>_type", OPT_STR, "Type of prior to use for parameter <n> - I=image prior", OPT_NONREQ, "" },
+    { "PSP_byname<n>_image", OPT_IMAGE, "Image prior for parameter <n>", OPT_NONREQ, "" },
+    { "PSP_byname<n>_prec", OPT_FLOAT, "Precision to apply to image prior for parameter <n>", OPT_NONREQ, "" },
+    { "PSP_byname<n>_transform", OPT_STR, "Transform to apply to parameter <n>", OPT_NONREQ, "" },
+    { "allow-bad-voxels", OPT_BOOL, "Continue if numerical error found in a voxel, rather than stopping", OPT_NONREQ, "" },
+    { "ar1-cross-terms", OPT_STR, "For AR1 noise, type of cross-linking (dual, same or none)", OPT_NONREQ, "dual" },
+    { "spatial-dims", OPT_INT, "Number of spatial dimensions", OPT_NONREQ, "3" },
+    { "spatial-speed", OPT_STR, "Restrict speed of spatial smoothing", OPT_NONREQ, "-1" },
+    { "param-spatial-priors", OPT_STR, "Type of spatial priors for each parameter, as a sequence of characters. N=nonspatial, M=Markov random field, P=Penny, A=ARD", OPT_NONREQ, "N+" },
+    { "locked-linear-from-mvn", OPT_MVN, "MVN file containing fixed centres for linearization", OPT_NONREQ, "" },
+    { "" },
+};
+
+InferenceTechnique *Vb::NewInstance()
+{
+    return new Vb();
+}
+
+Vb::Vb()
+    : m_noise(NULL)
+    , m_noise_params(0)
+    , m_saveF(false)
+    , m_saveFsHistory(false)
+    , m_printF(false)
+    , m_needF(false)
+    , m_locked_linear(false)
+    , m_nvoxels(0)
+    , m_store(new EngineStorage())
+{
+}
+
+Vb::~Vb()
+{
+    delete m_noise;
+    delete m_store;
+}
+
+void Vb::GetOptions(vector<OptionSpec> &opts) const
+{
+    for (int i = 0; VB_OPTIONS[i].name != ""; i++)
+        opts.push_back(VB_OPTIONS[i]);
+}
+
+string Vb::GetDescription() const
+{
+    return "Variational Bayes inference technique (voxelwise), running on the MI355X engine. See Chappell et al IEEE "
+           "Trans Sig Proc 57:1 (2009)";
+}
+string Vb::GetVersion() const
+{
+    return fabber_version();
+}
+
+void Vb::Initialize(FwdModel *fwd_model, FabberRunData &rundata)
+{
+    InferenceTechnique::Initialize(fwd_model, rundata);
+    m_noise = NoiseModel::NewFromName(rundata.GetString("noise"));
+    m_noise->Initialize(rundata);
+    m_noise_params = m_noise->NumOutputParams();
+    LOG << "Vb::Noise has " << m_noise_params << " parameters" << endl;
+    m_saveF = rundata.GetBool("save-free-energy");
+    m_saveFsHistory = rundata.GetBool("save-free-energy-history");
+    m_printF = rundata.GetBool("print-free-energy");
+    rundata.GetStringDefault("mcsteps", "0"); // read but unused, as in the reference
+    m_locked_linear = rundata.GetStringDefault("locked-linear-from-mvn", "") != "";
+}
+
+bool Vb::IsSpatial(FabberRunData &rundata) const
+{
+    if (rundata.GetString("method") == "spatialvb")
+        return true;
+    for (size_t k = 0; k < m_store->params.size(); k++)
+    {
+        switch (m_store->params[k].prior_type)
+        {
+        case PRIOR_SPATIAL_M:
+        case PRIOR_SPATIAL_m:
+        case PRIOR_SPATIAL_P:
+        case PRIOR_SPATIAL_p:
+            return true;
+        }
+    }
+    return false;
+}
+
+void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
+{
+    EngineStorage &st = *m_store;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.abi_version = FVB_ABI_VERSION;
+    const Matrix &data = rundata.GetMainVoxelData();
+    cfg.n_voxels = data.Ncols();
+    cfg.n_times = data.Nrows();
+    cfg.data_f64 = 1; // the run data holds doubles (rows = timepoints, columns = voxels)
+
+    // ---- model ----
+    st.params.clear();
+    m_model->GetParameters(rundata, st.params);
+    const int P = (int)st.params.size();
+    if (P > FVB_MAX_PARAMS)
+        throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters are not supported by the MI355X engine");
+    cfg.n_params = P;
+    DeviceModelSpec spec;
+    st.has_device_model = m_model->GetDeviceModel(spec);
+    if (!st.has_device_model)
+        throw FabberInternalError("Model '" + rundata.GetString("model")
+            + "' has no device body (FwdModel::GetDeviceModel) and the host-Jacobian path is not part of this build");
+    cfg.model = spec.model;
+    for (int i = 0; i < 4; i++)
+    {
+        cfg.model_iopt[i] = spec.iopt[i];
+        cfg.model_dopt[i] = spec.dopt[i];
+    }
+    if (spec.model == FVB_MODEL_LINEAR)
+    {
+        if (spec.design.Nrows() != cfg.n_times && cfg.n_voxels > 0)
+            throw InvalidOptionValue("basis", stringify(spec.design.Nrows()) + " rows",
+                "Design matrix length does not match the data (" + stringify(cfg.n_times) + " timepoints)");
+        st.design = spec.design;
+        cfg.design = st.design.Store();
+    }
+
+    // ---- parameters / priors ----
+    st.image_priors.assign(P, vector<double>());
+    for (int k = 0; k < P; k++)
+    {
+        const Parameter &p = st.params[k];
+        cfg.transform[k] = p.transform->DeviceCode();
+        cfg.prior_type[k] = Prior::DeviceCode(p.prior_type);
+        cfg.prior_mean[k] = p.prior.mean();
+        cfg.prior_var[k] = p.prior.var();
+        cfg.prior_prec[k] = p.prior.prec();
+        cfg.post_mean[k] = p.post.mean();
+        cfg.post_var[k] = p.post.var();
+        if (p.prior_type == PRIOR_IMAGE)
+        {
+            const Matrix &img = rundata.GetVoxelData(p.options.find("image")->second);
+            if (img.Ncols() != cfg.n_voxels || img.Nrows() < 1)
+                throw InvalidOptionValue("image prior", p.name, "Image prior must have one value per voxel");
+            st.image_priors[k].resize(cfg.n_voxels);
+            for (int v = 0; v < cfg.n_voxels; v++)
+                st.image_priors[k][v] = img.at0(0, v);
+            cfg.image_prior[k] = st.image_priors[k].data();
+        }
+    }
+
+    // ---- noise ----
+    m_noise->ConfigureEngine(cfg, cfg.n_times, st.phi_index);
+    cfg.phi_index = st.phi_index.empty() ? NULL : st.phi_index.data();
+    for (const char *key : { "noise-initial-prior", "noise-initial-posterior" })
+        if (rundata.GetStringDefault(key, "modeldefault") != "modeldefault")
+            throw InvalidOptionValue(key, rundata.GetStringDefault(key, ""), "Loading noise distributions from file is not supported yet");
+
+    // ---- convergence ----
+    std::unique_ptr<ConvergenceDetector> conv(
+        ConvergenceDetector::NewFromName(rundata.GetStringDefault("convergence", "maxits")));
+    conv->Initialize(rundata);
+    cfg.convergence = conv->DeviceCode();
+    cfg.max_iterations = conv->MaxIterations();
+    cfg.max_trials = conv->MaxTrials();
+    cfg.min_fchange = conv->MinFChange();
+    m_needF = conv->UseF() || m_printF || m_saveF || m_saveFsHistory; // inference_vb.cc:242
+    cfg.need_f = m_needF ? 1 : 0;
+    // every iteration pushes one value and the end of the voxel one more; trial mode and LM can
+    // run more iterations than max-iterations
+    cfg.f_history_rows = m_saveFsHistory ? (cfg.max_iterations + 2) * (conv->UseF() ? 12 : 1) : 0;
+
+    // ---- resume ----
+    bool continue_from_mvn = true;
+    try
+    {
+        st.init_mvn = rundata.GetVoxelData("continue-from-mvn");
+    }
+    catch (DataNotFound &)
+    {
+        continue_from_mvn = false;
+    }
+    if (continue_from_mvn)
+    {
+        LOG << "Vb::Continuing from MVN" << endl;
+        const int rows = fabber_vb_mvn_rows(P + m_noise_params);
+        if (st.init_mvn.Nrows() != rows)
+            throw FabberRunDataError("MVNDist::Load  - Incorrect number of rows for an MVN input");
+        if (st.init_mvn.Ncols() != cfg.n_voxels)
+            throw FabberRunDataError("MVNDist::Load - MVN input has the wrong number of voxels");
+        for (int v = 0; v < cfg.n_voxels; v++)
+            if (st.init_mvn.at0(rows - 1, v) != 1)
+                throw FabberRunDataError("MVNDist::Load - Voxel data does not contain a valid MVN - last value != 1");
+        cfg.init_mvn = st.init_mvn.Store();
+        rundata.GetStringDefault("continue-from-params", "");
+    }
+}
+
+void Vb::DoCalculations(FabberRunData &rundata)
+{
+    fvb_config &cfg = m_store->cfg;
+    BuildEngineConfig(rundata, cfg);
+    m_nvoxels = cfg.n_voxels;
+    const int rows = fabber_vb_mvn_rows(cfg.n_params + m_noise_params);
+    m_result_image.ReSize(rows, m_nvoxels);
+    m_free_energy.clear();
+    m_status.assign(m_nvoxels, 0);
+
+    const bool output_only = rundata.GetBool("output-only");
+    if (IsSpatial(rundata) && !output_only)
+        throw FabberInternalError("Spatial VB (method=spatialvb / spatial priors M m P p) is not part of this build yet");
+    if (m_nvoxels == 0)
+        return;
+
+    if (output_only)
+    {
+        LOG << "Vb::DoCalculations output-only set - not performing any calculations" << endl;
+        if (!cfg.init_mvn)
+            throw FabberRunDataError("output-only needs continue-from-mvn");
+        m_result_image = m_store->init_mvn;
+        m_needF = false;
+        return;
+    }
+
+    const Matrix &data = rundata.GetMainVoxelData();
+    vector<int> iterations(m_nvoxels, 0), hist_len(m_nvoxels, 0);
+    m_free_energy.assign(m_nvoxels, 9999);
+    if (cfg.f_history_rows > 0)
+        m_f_history.ReSize(cfg.f_history_rows, m_nvoxels);
+    fvb_outputs out;
+    memset(&out, 0, sizeof(out));
+    out.mvn = m_result_image.Store();
+    out.free_energy = m_free_energy.data();
+    out.status = m_status.data();
+    out.iterations = iterations.data();
+    if (cfg.f_history_rows > 0)
+    {
+        out.f_history = m_f_history.Store();
+        out.f_history_len = hist_len.data();
+    }
+    LOG << "Vb::Voxelwise calculations on the MI355X engine, kernel " << fabber_vb_kernel_name(&cfg) << ", " << m_nvoxels
+        << " voxels x " << cfg.n_times << " timepoints" << endl;
+    const int device = rundata.GetIntDefault("device", 0, 0);
+    int rc = fabber_vb_run_host(&cfg, data.Store(), &out, device);
+    if (rc != 0)
+        throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
+
+    // ---- per-voxel failures: what the reference's catch blocks do (inference_vb.cc:529-544) ----
+    static const char *reasons[] = { "", "LinearizedFwdModel::ReCentre: Non-finite values found in offset",
+        "LinearizedFwdModel::ReCentre: Non-finite values found in jacobian", "WhiteNoiseModel::Non-finite free energy!",
+        "NEWMAT exception: matrix is singular", "Ar1cNoiseModel: negative variance" };
+    const Matrix &coords = rundata.GetVoxelCoords();
+    int n_bad = 0;
+    for (int v = 0; v < m_nvoxels; v++)
+    {
+        const int code = m_status[v] & 0xff;
+        if (code == 0)
+            continue;
+        const bool in_setup = (m_status[v] & 0x100) != 0;
+        const string msg = reasons[code < 6 ? code : 4];
+        if (n_bad < 20)
+            LOG << "Vb::Internal error for voxel " << v + 1 << " at " << coords.at0(0, v) << " " << coords.at0(1, v) << " "
+                << coords.at0(2, v) << " : " << msg << endl;
+        n_bad++;
+        // the initial ReCentre sits outside the reference's try block (inference_vb.cc:235)
+        if (m_halt_bad_voxel || in_setup)
+            throw FabberInternalError(msg);
+    }
+    if (n_bad)
+        LOG << "Vb::" << n_bad << " voxels had numerical errors and were stopped early" << endl;
+
+    if (m_saveFsHistory)
+    {
+        // pad each voxel's history with its last value up to the longest (inference_vb.cc:1016-1046)
+        int longest = 0;
+        for (int v = 0; v < m_nvoxels; v++)
+            longest = std::max(longest, std::min(hist_len[v], cfg.f_history_rows));
+        Matrix hist(longest, m_nvoxels);
+        for (int v = 0; v < m_nvoxels; v++)
+        {
+            const int n = std::min(hist_len[v], cfg.f_history_rows);
+            for (int r = 0; r < longest; r++)
+                hist.at0(r, v) = m_f_history.at0(r < n ? r : n - 1, v);
+        }
+        m_f_history = hist;
+    }
+}
+
+static void save_rows(FabberRunData &rundata, const string &name, const vector<double> &buf, int rows, int row0, int n_rows, int V)
+{
+    Matrix m(n_rows, V);
+    (void)rows;
+    for (int r = 0; r < n_rows; r++)
+        for (int v = 0; v < V; v++)
+            m.at0(r, v) = buf[(size_t)(row0 + r) * V + v];
+    rundata.SaveVoxelData(name, m);
+}
+
+void Vb::SaveResults(FabberRunData &rundata) const
+{
+    LOG << "Vb::Preparing to save results..." << endl;
+    InferenceTechnique::SaveResults(rundata); // finalMVN
+
+    const fvb_config &cfg = m_store->cfg;
+    const int V = m_nvoxels, P = cfg.n_params, T = cfg.n_times, N = m_noise_params;
+    const bool want_mean = rundata.GetBool("save-mean"), want_std = rundata.GetBool("save-std");
+    const bool want_zstat = rundata.GetBool("save-zstat"), want_var = rundata.GetBool("save-var");
+    const bool want_nmean = rundata.GetBool("save-noise-mean"), want_nstd = rundata.GetBool("save-noise-std");
+    const bool want_fit = rundata.GetBool("save-model-fit"), want_resid = rundata.GetBool("save-residuals");
+
+    vector<double> mean, var, sd, zstat, fit, resid, nmean, nstd;
+    fvb_postproc pp;
+    memset(&pp, 0, sizeof(pp));
+    const size_t PV = (size_t)P * V, TV = (size_t)T * V, NV = (size_t)N * V;
+    if (want_mean)
+        mean.resize(PV), pp.mean = mean.data();
+    if (want_var)
+        var.resize(PV), pp.var = var.data();
+    if (want_std)
+        sd.resize(PV), pp.std = sd.data();
+    if (want_zstat)
+        zstat.resize(PV), pp.zstat = zstat.data();
+    if (want_fit)
+        fit.resize(TV), pp.modelfit = fit.data();
+    if (want_resid)
+        resid.resize(TV), pp.residuals = resid.data();
+    if (want_nmean && N > 0)
+        nmean.resize(NV), pp.noise_mean = nmean.data();
+    if (want_nstd && N > 0)
+        nstd.resize(NV), pp.noise_std = nstd.data();
+
+    if (V > 0)
+    {
+        const Matrix &data = rundata.GetMainVoxelData();
+        int rc = fabber_vb_postproc_host(&cfg, data.Store(), m_result_image.Store(), &pp, rundata.GetIntDefault("device", 0, 0));
+        if (rc != 0)
+            throw FabberInternalError(string("MI355X engine failed in post-processing: ") + fabber_vb_last_error());
+    }
+    for (int k = 0; k < P; k++)
+    {
+        const string &name = m_store->params[k].name;
+        if (want_mean)
+            save_rows(rundata, "mean_" + name, mean, P, k, 1, V);
+        if (want_zstat)
+            save_rows(rundata, "zstat_" + name, zstat, P, k, 1, V);
+        if (want_std)
+            save_rows(rundata, "std_" + name, sd, P, k, 1, V);
+        if (want_var)
+            save_rows(rundata, "var_" + name, var, P, k, 1, V);
+    }
+    if (want_resid)
+        save_rows(rundata, "residuals", resid, T, 0, T, V);
+    if (want_fit)
+        save_rows(rundata, "modelfit", fit, T, 0, T, V);
+    if (want_nmean && N > 0)
+        save_rows(rundata, "noise_means", nmean, N, 0, N, V);
+    if (want_nstd && N > 0)
+        save_rows(rundata, "noise_stdevs", nstd, N, 0, N, V);
+
+    // model-specific extra outputs are defined by host code only (FwdModel::EvaluateModel with
+    // a key): evaluate them on the host, like inference.cc:181-252
+    vector<string> outputs;
+    m_model->GetOutputs(outputs);
+    if (rundata.GetBool("save-model-extras") && !outputs.empty() && V > 0)
+    {
+        const Matrix &data = rundata.GetMainVoxelData();
+        const Matrix &coords = rundata.GetVoxelCoords();
+        const int nCov = (P + N) * (P + N + 1) / 2;
+        for (size_t o = 0; o < outputs.size(); o++)
+        {
+            if (outputs[o] == "")
+                continue;
+            Matrix result;
+            ColumnVector tmp, means(P);
+            for (int v = 0; v < V; v++)
+            {
+                try
+                {
+                    m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)));
+                    for (int k = 0; k < P; k++)
+                        means(k + 1) = m_result_image.at0(nCov + k, v);
+                    m_model->EvaluateFabber(means, tmp, outputs[o]);
+                    if (result.Nrows() != tmp.Nrows())
+                        result.ReSize(tmp.Nrows(), V);
+                    result.Column(v + 1) = tmp;
+                }
+                catch (std::exception &e)
+                {
+                    LOG << "InferenceTechnique::Error generating output " << outputs[o] << " for voxel " << v + 1 << " : " << e.what() << endl;
+                }
+            }
+            rundata.SaveVoxelData(outputs[o], result);
+        }
+    }
+
+    if (m_saveF && m_needF && !m_free_energy.empty())
+    {
+        Matrix F(1, V);
+        for (int v = 0; v < V; v++)
+            F.at0(0, v) = m_free_energy[v];
+        rundata.SaveVoxelData("freeEnergy", F);
+    }
+    else
+    {
+        LOG << "Vb::Free energy wasn't recorded, so no freeEnergy data saved" << endl;
+    }
+    if (V > 0 && m_saveFsHistory && m_f_history.Nrows() > 0)
+    {
+        Matrix hist = m_f_history;
+        rundata.SaveVoxelData("freeEnergyHistory", hist);
+    }
+    LOG << "Vb::Done writing results." << endl;
+}

@@ -1,0 +1,304 @@
+"""The drop-in boundary: libfabbercore_amd.so through the reference's C ABI (include/fabber_capi.h).
+
+CPU part (-m "not gpu"): the library loads, exports every declared symbol, honours the error
+conventions of the reference's fabber_capi.cc, resolves options / parameters on the host, and
+refuses loudly to run without a GPU. GPU part (-m gpu): the reference's known-answer tests
+(test/test_inference.cc, test/test_vb.cc) driven through the C ABI like its Python wrapper does.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from fabber_core_amd import fabber, hiplib, vbabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs_lib = pytest.mark.skipif(not os.path.exists(fabber.DEFAULT_LIB), reason="libfabbercore_amd.so not built")
+VAL = np.float32(7.32)
+
+
+def volume(shape, series):
+    """Constant-in-space volume [x,y,z,t] from one time series."""
+    return np.broadcast_to(np.asarray(series, dtype=np.float32), tuple(shape) + (len(series),)).copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU: symbols, conventions, host logic
+# ---------------------------------------------------------------------------------------------
+@needs_lib
+def test_library_exports_every_declared_symbol():
+    for header, libname in (("fabber_capi.h", "libfabbercore_amd.so"), ("fabber_vb.h", "libfabber_vb_hip.so")):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names = set(re.findall(r"\b(fabber_[a-z_]+)\s*\(", text))
+        assert len(names) >= 10
+        L = C.CDLL(os.path.join(ROOT, "fabber_core_amd", "lib", libname))
+        for n in sorted(names):
+            assert hasattr(L, n), (libname, n)
+    assert set(fabber.CAPI_SYMBOLS) <= set(re.findall(r"\b(fabber_[a-z_]+)\s*\(", open(os.path.join(ROOT, "include", "fabber_capi.h")).read()))
+
+
+@needs_lib
+def test_error_conventions():
+    L = fabber.load_library()
+    err = C.create_string_buffer(255)
+    assert L.fabber_set_opt(None, b"a", b"b", err) == fabber.ERR_FATAL and b"NULL" in err.value
+    with fabber.Fabber() as fab:
+        assert L.fabber_set_extent(fab.handle, 2, 2, 2, None, err) == fabber.ERR_FATAL  # NULL mask rejected
+        assert L.fabber_set_extent(fab.handle, 0, 2, 2, (C.c_int * 8)(), err) == fabber.ERR_FATAL
+        assert L.fabber_set_opt(fab.handle, None, b"x", err) == fabber.ERR_FATAL
+        assert L.fabber_get_data_size(fab.handle, b"nonexistent", err) == -1
+        assert b"Voxel data not found" in err.value
+        small = C.create_string_buffer(4)
+        assert L.fabber_get_models(fab.handle, 4, small, err) == -1 and b"Buffer too small" in err.value
+        assert L.fabber_dorun(fab.handle, 10, None, err, None) == fabber.ERR_FATAL
+        assert L.fabber_dorun(fab.handle, 10, C.create_string_buffer(10), None, None) == fabber.ERR_FATAL
+        # err_buf is optional everywhere else
+        assert L.fabber_set_opt(fab.handle, b"model", b"poly", None) == 0
+        L.fabber_destroy(None)  # ignored
+
+
+@needs_lib
+def test_registry_and_option_tables():
+    with fabber.Fabber() as fab:
+        assert {"poly", "linear", "exp"} <= set(fab.get_models())
+        assert {"vb", "spatialvb"} <= set(fab.get_methods())
+        desc, opts = fab.get_options()
+        assert any(o["name"] == "save-mvn" and o["type"] == "BOOL" for o in opts)
+        desc, opts = fab.get_options("model", "exp")
+        assert "exponential" in desc
+        assert [o["name"] for o in opts] == ["dt", "num-exps"] and opts[1]["default"] == "1" and opts[1]["optional"]
+        desc, opts = fab.get_options("method", "vb")
+        assert any(o["name"] == "max-iterations" for o in opts)
+        with pytest.raises(fabber.FabberError):
+            fab.get_options("model", "nosuchmodel")
+
+
+@needs_lib
+def test_model_parameters_and_prior_grammar():
+    with fabber.Fabber() as fab:
+        fab.set_options({"model": "exp", "num-exps": 2, "dt": 0.02})
+        assert fab.get_model_params() == ["amp1", "r1", "amp2", "r2"]
+        assert fab.get_model_outputs() == []
+    with fabber.Fabber() as fab:
+        fab.set_options({"model": "poly", "degree": 2, "param-spatial-priors": "NA+"})
+        assert fab.get_model_params() == ["c0", "c1", "c2"]
+    for bad in ("NNNN", "N++"):  # too many types / two '+': priors.cc:35-92, test_priors.cc:125-142
+        with fabber.Fabber() as fab:
+            fab.set_options({"model": "poly", "degree": 2, "param-spatial-priors": bad})
+            with pytest.raises(fabber.FabberError):
+                fab.get_model_params()
+    with fabber.Fabber() as fab:
+        fab.set_options({"model": "poly"})  # mandatory option missing
+        with pytest.raises(fabber.FabberError, match="degree"):
+            fab.get_model_params()
+
+
+@needs_lib
+def test_model_evaluate_matches_oracle_models():
+    with fabber.Fabber() as fab:
+        fab.set_options({"model": "exp", "num-exps": 2, "dt": 0.02})
+        got = fab.model_evaluate([1.0, 0.8, 0.5, 6.0], 100)
+    h = vbabi.build_config(vbabi.MODEL_EXP, 1, 100, num_exps=2, dt=0.02,
+                           param_overrides={k: dict(transform="I") for k in ("amp1", "r1", "amp2", "r2")})
+    ref = np.zeros(100)
+    p = np.array([1.0, 0.8, 0.5, 6.0])
+    assert oracle.lib().oracle_evaluate_fabber(C.byref(h.cfg), p.ctypes.data, ref.ctypes.data) == 0
+    assert np.allclose(got, ref, rtol=1e-6)
+    with fabber.Fabber() as fab:
+        fab.set_options({"model": "poly", "degree": 3})
+        got = fab.model_evaluate([2, 0, 3, -4], 10, indata=np.zeros(10))
+    n = np.arange(1, 11)
+    assert np.allclose(got, 2 + 3 * n ** 2 - 4 * n ** 3)
+
+
+@needs_lib
+def test_data_round_trip_through_mask():
+    """set_data gathers through the mask, get_data scatters back with zeros outside
+    (rundata_array.cc:68-133); voxel order is x fastest."""
+    rng = np.random.default_rng(0)
+    shape = (4, 3, 2)
+    mask = rng.integers(0, 2, shape)
+    vol = rng.normal(size=shape + (5,)).astype(np.float32)
+    with fabber.Fabber() as fab:
+        fab.set_extent(shape, mask)
+        fab.set_data("thing", vol)
+        assert fab.data_size("thing") == 5
+        back = fab.get_data("thing")
+        assert np.array_equal(back, vol * (mask != 0)[..., None])
+        coords = fab.get_data("coords")
+        assert fab.data_size("coords") == 3
+        for d in range(3):  # 0-based grid indices (rundata_array.cc:54-56)
+            assert np.array_equal(coords[..., d][mask != 0], np.nonzero(mask)[d])
+
+
+@needs_lib
+@pytest.mark.skipif(hiplib.available() and hiplib.device_count() > 0, reason="a GPU is present")
+def test_run_without_gpu_fails_loudly():
+    with fabber.Fabber() as fab:
+        fab.set_extent((2, 2, 2))
+        fab.set_options({"model": "poly", "degree": 0, "noise": "white", "method": "vb"})
+        fab.set_data("data", volume((2, 2, 2), [VAL] * 10))
+        with pytest.raises(fabber.FabberError) as e:
+            fab.run()
+        assert e.value.code == fabber.ERR_FATAL
+        assert "no HIP device" in e.value.message and "no CPU fallback" in e.value.message
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: the reference's known-answer tests through the C ABI
+# ---------------------------------------------------------------------------------------------
+def run_poly(data, degree, mask=None, extra=None, **options):
+    opts = {"model": "poly", "degree": degree, "noise": "white", "method": "vb", "save-mean": True, "save-mvn": True}
+    opts.update({(k if k.startswith("PSP_") else k.replace("_", "-")): v for k, v in options.items()})
+    return fabber.run(data, opts, mask=mask, extra_data=extra)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vb"])
+def test_constant_and_alternating_data(method):
+    """test_inference.cc:108-238"""
+    out = run_poly(volume((5, 5, 5), [VAL] * 10), 0, method=method)
+    assert out["mean_c0"].shape == (5, 5, 5)
+    assert np.all(np.abs(out["mean_c0"] - VAL) <= 4 * np.spacing(VAL))
+    series = [VAL if n % 2 == 0 else VAL * np.float32(3) for n in range(10)]
+    out = run_poly(volume((5, 5, 5), series), 0, method=method)
+    assert np.all(np.abs(out["mean_c0"] - VAL * 2) <= 4 * np.spacing(VAL * 2))
+
+
+@pytest.mark.gpu
+def test_no_voxels():
+    """test_inference.cc:57-74 / 'some chunks have no ROI': an empty mask gives empty outputs."""
+    data = volume((3, 3, 3), [VAL] * 10)
+    out = run_poly(data, 0, mask=np.zeros((3, 3, 3), dtype=int))
+    assert np.all(out["mean_c0"] == 0)
+
+
+@pytest.mark.gpu
+def test_polynomial_fit_and_model_fit_output():
+    """test_inference.cc:353-482"""
+    n = np.arange(1, 11, dtype=np.float64)
+    series = 2 + 3 * n * n - 4 * n * n * n
+    out = run_poly(volume((5, 5, 5), series), 3, max_iterations=50, save_model_fit=True, save_residuals=True)
+    for name, want in (("mean_c0", 2), ("mean_c1", 0), ("mean_c2", 3), ("mean_c3", -4)):
+        assert np.all(np.abs(out[name] - want) < 1e-3), name
+    assert out["modelfit"].shape == (5, 5, 5, 10)
+    assert np.allclose(out["modelfit"][0, 0, 0], series, rtol=1e-5)
+    assert np.all(np.abs(out["residuals"]) < 0.05)
+
+
+@pytest.mark.gpu
+def test_masked_timepoints():
+    """test_inference.cc:485-561"""
+    series = np.full(10, 2.0)
+    out = run_poly(volume((5, 5, 5), series), 1)
+    assert np.all(np.abs(out["mean_c0"] - 2) < 1e-3)
+    series[2] = series[6] = 4.0
+    assert np.all(run_poly(volume((5, 5, 5), series), 1)["mean_c0"] > 2)
+    out = run_poly(volume((5, 5, 5), series), 1, mt1=3, mt2=7)
+    assert np.all(np.abs(out["mean_c0"] - 2) < 1e-3)
+
+
+@pytest.mark.gpu
+def test_restart_chain_through_float_mvn():
+    """test_vb.cc:305-409 through the C ABI: the MVN travels as float32 between the 51 runs."""
+    n = np.arange(1, 11, dtype=np.float64)
+    data = volume((3, 3, 3), float(VAL) + 1.5 * float(VAL) * n * n)
+    out = run_poly(data, 5, max_iterations=1)
+    assert out["mean_c0"][0, 0, 0] != VAL
+    for _ in range(50):
+        out = run_poly(data, 5, max_iterations=1, extra={"mvns": out["finalMVN"]}, continue_from_mvn="mvns")
+    assert np.all(np.abs(out["mean_c0"] - VAL) < 2e-3)
+    assert np.all(np.abs(out["mean_c1"]) < 2e-3)
+    assert np.all(np.abs(out["mean_c2"] - 1.5 * VAL) < 1e-4)
+
+
+@pytest.mark.gpu
+def test_output_only_from_mvn():
+    """test_vb.cc:412-498"""
+    n = np.arange(1, 11, dtype=np.float64)
+    data = volume((3, 3, 3), float(VAL) + 1.5 * float(VAL) * n * n)
+    first = run_poly(data, 2, max_iterations=100)
+    out = fabber.run(data, {"model": "poly", "degree": 2, "noise": "white", "method": "vb", "save-mean": True,
+                            "save-model-fit": True, "output-only": True, "continue-from-mvn": "mvns"},
+                     extra_data={"mvns": first["finalMVN"]})
+    assert "finalMVN" not in out
+    assert np.all(np.abs(out["mean_c0"] - VAL) < 1e-4)
+    assert np.all(np.abs(out["mean_c1"]) < 1e-4)
+    assert np.all(np.abs(out["mean_c2"] - 1.5 * VAL) < 1e-4)
+    assert out["modelfit"].shape == (3, 3, 3, 10)
+
+
+@pytest.mark.gpu
+def test_image_priors():
+    """test_vb.cc:71-232"""
+    series = [VAL if n % 2 == 0 else VAL * np.float32(3) for n in range(10)]
+    data = volume((5, 5, 5), series)
+    img = np.full((5, 5, 5), VAL * 1.5, dtype=np.float32)
+    base = {"PSP_byname1": "c0", "PSP_byname1_type": "I"}
+    out = run_poly(data, 0, extra={"PSP_byname1_image": img}, **base, PSP_byname1_prec="1e12")
+    assert np.all(np.abs(out["mean_c0"] - VAL * 1.5) < VAL * 0.1)
+    out = run_poly(data, 0, extra={"PSP_byname1_image": img}, **base, PSP_byname1_prec="1e-5")
+    assert np.all(np.abs(out["mean_c0"] - VAL * 2) < VAL * 0.1)
+
+
+@pytest.mark.gpu
+def test_outputs_gated_by_save_options_and_match_engine():
+    rng = np.random.default_rng(5)
+    shape, T = (6, 5, 4), 50
+    t = np.arange(T) * 0.04
+    data = (np.exp(-t)[None, None, None, :] + rng.normal(0, 0.05, shape + (T,))).astype(np.float32)
+    mask = rng.integers(0, 4, shape) > 0
+    opts = {"model": "exp", "dt": 0.04, "noise": "white", "method": "vb", "max-iterations": 10, "save-mean": True,
+            "save-std": True, "save-zstat": True, "save-var": True, "save-mvn": True, "save-noise-mean": True,
+            "save-noise-std": True, "save-free-energy": True, "save-free-energy-history": True}
+    out = fabber.run(data, opts, mask=mask)
+    assert out["finalMVN"].shape == shape + (10,)
+    assert np.all(out["finalMVN"][~mask] == 0) and np.all(out["finalMVN"][mask][:, -1] == 1)
+    assert out["freeEnergyHistory"].shape[3] == 11
+    assert np.allclose(out["zstat_amp1"][mask], out["mean_amp1"][mask] / out["std_amp1"][mask], rtol=1e-5)
+    assert np.allclose(out["var_r1"][mask], out["std_r1"][mask] ** 2, rtol=1e-5)
+    assert "modelfit" not in out and "residuals" not in out
+    # same numbers as the engine called directly on the masked voxels
+    from fabber_core_amd import hiplib
+    V = int(mask.sum())
+    y = data.transpose(3, 2, 1, 0).reshape(T, -1)[:, mask.transpose(2, 1, 0).ravel()]
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, T, num_exps=1, dt=0.04, max_iterations=10, need_f=True)
+    direct = hiplib.run_host(h, y.astype(np.float64))
+    got = out["finalMVN"].transpose(3, 2, 1, 0).reshape(10, -1)[:, mask.transpose(2, 1, 0).ravel()]
+    assert np.allclose(got, direct["mvn"].astype(np.float32), rtol=1e-6, atol=0)
+    F = out["freeEnergy"].transpose(2, 1, 0).ravel()[mask.transpose(2, 1, 0).ravel()]
+    assert np.allclose(F, direct["free_energy"], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_bad_voxels_halt_or_continue():
+    """inference.cc:93-109, inference_vb.cc:529-544: a numerical failure is fatal unless
+    allow-bad-voxels is set; a failure of the very first re-linearisation is always fatal."""
+    rng = np.random.default_rng(1)
+    T = 50
+    t = np.arange(T) * 0.04
+    data = (np.exp(-t)[None, None, None, :] + rng.normal(0, 0.05, (4, 4, 2, T))).astype(np.float32)
+    data[1, 1, 1, 3] = np.nan  # becomes non-finite inside the loop (iteration 1)
+    opts = {"model": "exp", "dt": 0.04, "noise": "white", "method": "vb", "save-mean": True}
+    with pytest.raises(fabber.FabberError, match="Non-finite"):
+        fabber.run(data, opts)
+    out = fabber.run(data, dict(opts, **{"allow-bad-voxels": True}))
+    assert "numerical errors" in out["log"]
+    assert np.isfinite(out["mean_amp1"][0, 0, 0])
+    data[2, 2, 0, :] = -1.0  # log of a negative amplitude: fails in setup -> fatal regardless
+    with pytest.raises(fabber.FabberError, match="Non-finite"):
+        fabber.run(data, dict(opts, **{"allow-bad-voxels": True}))
+
+
+@pytest.mark.gpu
+def test_progress_callback_and_unused_option_warning():
+    calls = []
+    out = fabber.run(volume((2, 2, 2), [VAL] * 10), {"model": "poly", "degree": 0, "noise": "white", "method": "vb",
+                                                     "save-mean": True, "bogus-option": "1"},
+                     progress_cb=lambda v, n: calls.append((v, n)))
+    assert calls[0] == (0, 8) and calls[-1] == (8, 8)
+    assert "Unused option specified: bogus-option" in out["log"]
