@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--need-f", action="store_true", help="also evaluate the free energy 4x per iteration (CLI default of the reference)")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="voxels timed on the CPU oracle (0 = skip)")
     ap.add_argument("--variant", default="auto", choices=["auto", "lane", "wave"])
+    ap.add_argument("--residual", default="auto", choices=["auto", "exact", "moments"],
+                    help="how k'Qk is obtained (fabber_vb_set_residual_mode); default adaptive")
+    ap.add_argument("--residual-tol", type=float, default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,10 +83,13 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import cases
-    from fabber_core_amd import hiplib
+    from fabber_core_amd import hiplib, parallel
     from fabber_core_amd.device import DeviceProblem
 
     hiplib.set_variant(args.variant)
+    hiplib.set_residual_mode(args.residual)
+    if args.residual_tol is not None:
+        hiplib.set_residual_tolerance(args.residual_tol)
     w = WORKLOADS[args.workload]
     V = args.voxels or w["voxels"]
     T, P = w["T"], 2 * w["num_exps"]
@@ -101,8 +107,7 @@ def main():
         summary[0] = prob.free_energy.sum() if args.need_f else prob.mvn[noise_row].sum()
         summary[1] = prob.iterations.sum(dtype=torch.float64)
         summary[2] = (prob.status != 0).sum(dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(summary, op=dist.ReduceOp.SUM)
+        parallel.global_summary(summary)
 
     def barrier():
         if world > 1:
@@ -124,15 +129,11 @@ def main():
         summary[0] = prob.free_energy.sum() if args.need_f else prob.mvn[noise_row].sum()
         summary[1] = prob.iterations.sum(dtype=torch.float64)
         summary[2] = (prob.status != 0).sum(dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(summary, op=dist.ReduceOp.SUM)
+        parallel.global_summary(summary)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = parallel.global_max(elapsed, device)
     summ = summary.cpu().numpy()
 
     result = None

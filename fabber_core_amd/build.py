@@ -67,7 +67,7 @@ def _compile_one(args):
 def build_hip(force=False, jobs=None, verbose=True, extra_flags=()):
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    flags = HIP_FLAGS + list(extra_flags)
+    flags = HIP_FLAGS + list(extra_flags) + os.environ.get("FVB_EXTRA_HIPCC_FLAGS", "").split()
     work = [(os.path.join(CSRC, s), flags, force) for s in HIP_SOURCES]
     jobs = jobs or min(len(work), os.cpu_count() or 4)
     objs, rebuilt = [], False

@@ -21,6 +21,8 @@ namespace
 {
 thread_local std::string g_last_error;
 int g_variant = 0; // 0 auto, 1 lane, 2 wave
+int g_residual_mode = 0; // 0 adaptive, 1 always exact, 2 moments only
+double g_residual_tol = 1e-10; // moments value keeps >= 6 significant digits where it is used
 
 int fail(int code, const std::string &msg)
 {
@@ -217,6 +219,16 @@ void fabber_vb_set_variant(int32_t variant)
     g_variant = variant;
 }
 
+void fabber_vb_set_residual_mode(int32_t mode)
+{
+    g_residual_mode = mode;
+}
+
+void fabber_vb_set_residual_tolerance(double tol)
+{
+    g_residual_tol = tol;
+}
+
 const char *fabber_vb_kernel_name(const fvb_config *cfg)
 {
     if (validate(cfg) != 0)
@@ -246,6 +258,8 @@ int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const f
     ka.data = data;
     ka.save = nullptr;
     ka.n_unmasked = n_unmasked;
+    ka.residual_mode = g_residual_mode;
+    ka.residual_tol = g_residual_tol;
 
     LaneKernelInfo lk = select_lane(cfg);
     if (lk.fn)

@@ -24,6 +24,13 @@
 #include "vb_math.h"
 #include "vb_models.h"
 
+// Minimum waves per SIMD the register allocator must leave room for (2nd argument of
+// __launch_bounds__ = waves per SIMD/EU on gfx950). One wave alone cannot keep a SIMD's fp64
+// pipe busy; see DESIGN.md section 4 for the measured effect.
+#ifndef FVB_LANE_WAVES_PER_SIMD
+#define FVB_LANE_WAVES_PER_SIMD 3
+#endif
+
 namespace fvb
 {
 struct KernelArgs
@@ -33,6 +40,8 @@ struct KernelArgs
     const void *data;
     double *save;      // [lane_save_rows(P)][V] scratch for save/revert, or NULL
     int32_t n_unmasked; // T - #masked timepoints
+    int32_t residual_mode; // k'Qk: 0 = moments with exact fallback, 1 = always exact, 2 = moments only
+    double residual_tol;   // mode 0: fall back when k'Qk < residual_tol * (s + 2|d'u| + |d'Ad|)
 };
 
 template <int P>
@@ -290,8 +299,27 @@ __device__ __forceinline__ bool update_theta(VoxelState<P> &st, const Moments<P>
 }
 
 // k'Qk and tr(Sigma J'QJ) from the moments
+// tr(Sigma J'QJ) = tr(Sigma A)  (noisemodel_white.cc:252,417)
 template <int P>
-__device__ __forceinline__ void residual_terms(const VoxelState<P> &st, const Moments<P> &mo, double &kk, double &trSA)
+__device__ __forceinline__ double trace_SA(const VoxelState<P> &st, const Moments<P> &mo)
+{
+    double tr = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            tr += st.Sig[tri(i, j)] * mo.A[tri(i, j)];
+    return tr;
+}
+
+// k'Qk and tr(Sigma J'QJ) from the moments. k'Qk = s - 2 d'u + d'A d is algebraically the
+// reference's sum of squares, but it cancels when the linear step explains away a residual that
+// is orders of magnitude larger (voxels passing through huge parameter values): `lost` is set
+// when the result is below tol x the magnitude of its terms (or not positive), and the caller
+// then replaces it by the directly summed value (exact_residual below).
+template <int P>
+__device__ __forceinline__ void residual_terms(
+    const VoxelState<P> &st, const Moments<P> &mo, double tol, double &kk, double &trSA, bool &lost)
 {
     double d[P];
 #pragma unroll
@@ -311,39 +339,106 @@ __device__ __forceinline__ void residual_terms(const VoxelState<P> &st, const Mo
         }
     }
     kk = mo.s - 2 * du + dAd;
-    // k'Qk is a sum of squares in the reference. The expanded form can come out slightly
-    // negative (zero-residual data) or, when a voxel has wandered into astronomically large
-    // parameter values, hugely negative by cancellation; a negative value would make the noise
-    // scale b negative and every later logarithm NaN, which the reference never does.
-    kk = (kk > 0.0) ? kk : ((kk <= 0.0) ? 0.0 : kk); // NaN passes through
+    const double scale = mo.s + 2 * fabs(du) + fabs(dAd);
+    lost = !(kk > tol * scale) && (scale > 0); // also true for NaN / negative values
+}
+
+// The reference's k = y - g(ml) + J (ml - m) summed directly (noisemodel_white.cc:235,252):
+// one more streaming pass that re-evaluates the model and its finite-difference Jacobian about
+// the OLD centre ml. Only run for wavefronts in which some voxel's moment form lost precision.
+template <class Model, int P>
+__device__ __forceinline__ double exact_residual(
+    const KernelArgs &ka, const ModelArgs &ma, int v, const Moments<P> &mo, const double (&m)[P])
+{
+    const int T = ka.cfg.n_times;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    double tp[P], tp2[P], tp3[P], rden[P], nd[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        const int tr = ka.cfg.transform[i];
+        double delta = mo.ml[i] * 1e-5;
+        if (delta < 0)
+            delta = -delta;
+        if (delta < 1e-10)
+            delta = 1e-10;
+        const double c2 = mo.ml[i] + delta;
+        const double c3 = mo.ml[i] - delta;
+        tp[i] = to_model(tr, mo.ml[i]);
+        tp2[i] = to_model(tr, c2);
+        tp3[i] = to_model(tr, c3);
+        rden[i] = 1.0 / (c2 - c3);
+        nd[i] = mo.ml[i] - m[i];
+    }
+    double kk = 0;
+    const uint8_t *phi_index = ka.cfg.phi_index;
+    for (int t = 0; t < T; t++)
+    {
+        const double g = Model::eval(ma, t, tp);
+        double Jd = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            FVB_NO_CONTRACT
+            double q[P];
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                q[j] = tp[j];
+            q[i] = tp2[i];
+            const double f2 = Model::eval(ma, t, q);
+            q[i] = tp3[i];
+            const double f3 = Model::eval(ma, t, q);
+            Jd += ((f2 - f3) * rden[i]) * nd[i];
+        }
+        const bool unmasked = phi_index ? (phi_index[t] != 255) : true;
+        if (unmasked)
+        {
+            const double k = load_data(ka, (size_t)t * V + v) - g + Jd;
+            kk += k * k;
+        }
+    }
+    return kk;
+}
+
+// k'Qk (moments, or exact where needed) and tr(Sigma J'QJ) for the current (m, Sigma, ml)
+template <class Model, int P>
+__device__ __forceinline__ void residual_and_trace(const KernelArgs &ka, const ModelArgs &ma, int v,
+    const VoxelState<P> &st, const Moments<P> &mo, double &kk, double &trSA)
+{
+    bool lost;
+    residual_terms<P>(st, mo, ka.residual_tol, kk, trSA, lost);
+    const int mode = ka.residual_mode; // 0 adaptive, 1 always exact, 2 never (moments only)
+    const bool want = (mode == 1) || (mode == 0 && lost);
+    if (__any(want)) // wave-uniform: the pass is taken by the whole wavefront or not at all
+    {
+        const double exact = exact_residual<Model, P>(ka, ma, v, mo, st.m);
+        if (want)
+            kk = exact; // per-voxel decision: a voxel's result never depends on its wave-mates
+    }
+    else if (mode == 2)
+    {
+        kk = (kk > 0.0) ? kk : ((kk <= 0.0) ? 0.0 : kk); // keep b positive; NaN passes through
+    }
 }
 
 // WhiteNoiseModel::UpdateNoise (noisemodel_white.cc:228-273), one phi
 template <int P>
-__device__ __forceinline__ bool update_noise(const KernelArgs &ka, VoxelState<P> &st, const Moments<P> &mo)
+__device__ __forceinline__ void update_noise(const KernelArgs &ka, VoxelState<P> &st, double kk, double trSA)
 {
-    if (!ensure_cov<P>(st))
-        return false;
-    double kk, trSA;
-    residual_terms<P>(st, mo, kk, trSA);
     const double tmp = kk + trSA;
     st.b = 1 / (tmp * 0.5 + 1 / ka.cfg.noise_prior_b[0]);                   // eq (22)
     st.c = ((double)ka.n_unmasked - 1) * 0.5 + ka.cfg.noise_prior_c[0];     // eq (21)
     if (ka.cfg.locked_noise_stdev > 0)
         st.b = 1 / st.c / ka.cfg.locked_noise_stdev / ka.cfg.locked_noise_stdev;
-    return true;
 }
 
 // WhiteNoiseModel::CalcFreeEnergy (noisemodel_white.cc:365-454), one phi. Returns false if
 // a NEWMAT-type failure happened; *finite is cleared if F is not finite.
 template <int P>
 __device__ __forceinline__ bool calc_free_energy(
-    const KernelArgs &ka, VoxelState<P> &st, const Moments<P> &mo, double Fprior, double &F, bool &finite)
+    const KernelArgs &ka, VoxelState<P> &st, double kk, double trSA, double Fprior, double &F, bool &finite)
 {
-    bool ok = ensure_cov<P>(st);
-    ok &= ensure_prec<P>(st);
-    double kk, trSA;
-    residual_terms<P>(st, mo, kk, trSA);
+    bool ok = ensure_prec<P>(st);
     const double si = st.b, ci = st.c;
     const double siPrior = ka.cfg.noise_prior_b[0], ciPrior = ka.cfg.noise_prior_c[0];
     const double nq = (double)ka.n_unmasked;
@@ -439,7 +534,7 @@ __device__ __forceinline__ void restore_state(const KernelArgs &ka, int v, Voxel
 }
 
 template <class Model, int P, bool NEEDF>
-__global__ __launch_bounds__(64) void vb_lane_kernel(const KernelArgs ka)
+__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int v = blockIdx.x * 64 + threadIdx.x;
@@ -537,6 +632,24 @@ __global__ __launch_bounds__(64) void vb_lane_kernel(const KernelArgs ka)
         if (ka.save)
             save_state<P>(ka, v, st); // :432-434
         bool stop = false;
+// CalculateF (inference_vb.cc:302-318) with the given residual terms; a failure ends the voxel's
+// loop exactly where the reference's exception would (F keeps its previous value).
+#define FVB_EVAL_F(KK, TR)                                                                                   \
+    {                                                                                                        \
+        double Fn_;                                                                                          \
+        bool fin_ = true;                                                                                    \
+        if (!calc_free_energy<P>(ka, st, (KK), (TR), Fprior, Fn_, fin_))                                     \
+        {                                                                                                    \
+            status = FVB_BAD_RESULT;                                                                         \
+            break;                                                                                           \
+        }                                                                                                    \
+        if (!fin_)                                                                                           \
+        {                                                                                                    \
+            status = FVB_BAD_FREE_ENERGY;                                                                    \
+            break;                                                                                           \
+        }                                                                                                    \
+        F = Fn_;                                                                                             \
+    }
         do
         {
             if (ka.save && conv_need_save(conv)) // :451-458
@@ -546,80 +659,32 @@ __global__ __launch_bounds__(64) void vb_lane_kernel(const KernelArgs ka)
                 status = FVB_BAD_RESULT;
                 break;
             }
-            bool finite = true;
-            if (NEEDF)
+            if (NEEDF) // "before" :468 - the centre is the current mean, so k = y - g
             {
-                double Fn; // "before" :468
-                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
+                if (!ensure_cov<P>(st))
                 {
                     status = FVB_BAD_RESULT;
                     break;
                 }
-                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
-                {
-                    status = FVB_BAD_FREE_ENERGY;
-                    break;
-                }
-                F = Fn;
+                FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
             }
-            if (!update_theta<P>(st, mo, conv_lm_alpha(conv))) // :470
+            if (!update_theta<P>(st, mo, conv_lm_alpha(conv)) || !ensure_cov<P>(st)) // :470
             {
                 status = FVB_BAD_RESULT;
                 break;
             }
-            if (NEEDF)
-            {
-                double Fn; // "theta" :477
-                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
-                {
-                    status = FVB_BAD_RESULT;
-                    break;
-                }
-                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
-                {
-                    status = FVB_BAD_FREE_ENERGY;
-                    break;
-                }
-                F = Fn;
-            }
-            if (!update_noise<P>(ka, st, mo)) // :479
-            {
-                status = FVB_BAD_RESULT;
-                break;
-            }
-            if (NEEDF)
-            {
-                double Fn; // "phi" :485
-                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
-                {
-                    status = FVB_BAD_RESULT;
-                    break;
-                }
-                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
-                {
-                    status = FVB_BAD_FREE_ENERGY;
-                    break;
-                }
-                F = Fn;
-            }
+            double kk, trSA;
+            residual_and_trace<Model, P>(ka, ma, v, st, mo, kk, trSA);
+            if (NEEDF) // "theta" :477
+                FVB_EVAL_F(kk, trSA)
+            update_noise<P>(ka, st, kk, trSA); // :479
+            if (NEEDF) // "phi" :485
+                FVB_EVAL_F(kk, trSA)
             status = recentre<Model, P>(ka, ma, v, st.m, mo); // :490
             if (status != FVB_OK)
                 break;
-            if (NEEDF)
-            {
-                double Fn; // "lin" :495
-                if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
-                {
-                    status = FVB_BAD_RESULT;
-                    break;
-                }
-                if (!finite) // CalcFreeEnergy throws, F keeps its previous value
-                {
-                    status = FVB_BAD_FREE_ENERGY;
-                    break;
-                }
-                F = Fn;
-            }
+            if (NEEDF) // "lin" :495
+                FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
             if (ka.out.f_history && hist_len < ka.cfg.f_history_rows) // :496-497
                 ka.out.f_history[(size_t)hist_len * V + v] = F;
             hist_len++;
@@ -637,17 +702,19 @@ __global__ __launch_bounds__(64) void vb_lane_kernel(const KernelArgs ka)
                 status = recentre<Model, P>(ka, ma, v, st.m, mo);
                 if (status == FVB_OK && NEEDF)
                 {
-                    bool finite = true;
-                    double Fn;
-                    if (!calc_free_energy<P>(ka, st, mo, Fprior, Fn, finite))
-                        status = FVB_BAD_RESULT;
-                    else if (!finite)
-                        status = FVB_BAD_FREE_ENERGY;
-                    else
-                        F = Fn;
+                    do
+                    {
+                        if (!ensure_cov<P>(st))
+                        {
+                            status = FVB_BAD_RESULT;
+                            break;
+                        }
+                        FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
+                    } while (false);
                 }
             }
         }
+#undef FVB_EVAL_F
     }
 
     // ---- result MVN: MVNDist(fwd_post, noise.OutputAsMVN()) packed as MVNDist::Save does

@@ -39,6 +39,8 @@ def lib():
         L.fabber_vb_kernel_name.restype = C.c_char_p
         L.fabber_vb_kernel_name.argtypes = [cfgp]
         L.fabber_vb_set_variant.argtypes = [C.c_int32]
+        L.fabber_vb_set_residual_mode.argtypes = [C.c_int32]
+        L.fabber_vb_set_residual_tolerance.argtypes = [C.c_double]
         L.fabber_vb_run_device.restype = C.c_int32
         L.fabber_vb_run_device.argtypes = [cfgp, C.c_void_p, outp, C.c_void_p]
         L.fabber_vb_run_device_ex.restype = C.c_int32
@@ -80,6 +82,15 @@ def kernel_name(holder):
 
 def set_variant(variant):
     lib().fabber_vb_set_variant({"auto": 0, "lane": 1, "wave": 2}.get(variant, variant))
+
+
+def set_residual_mode(mode):
+    """k'Qk: 'auto' (moments + exact fallback), 'exact' (always direct), 'moments' (never)."""
+    lib().fabber_vb_set_residual_mode({"auto": 0, "exact": 1, "moments": 2}.get(mode, mode))
+
+
+def set_residual_tolerance(tol):
+    lib().fabber_vb_set_residual_tolerance(float(tol))
 
 
 def n_unmasked(holder):

@@ -222,6 +222,15 @@ int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const d
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);
 
+/* How k'Qk (the residual sum of squares of the linearised model, noisemodel_white.cc:235,252) is
+ * obtained, for A/B measurement: 0 (default) = from the streamed moments, replaced by a direct
+ * re-summation for the voxels where the moment form has lost precision; 1 = always the direct
+ * re-summation (one more model pass per iteration); 2 = moments only, clamped at zero. */
+void fabber_vb_set_residual_mode(int32_t mode);
+/* mode 0: the direct re-summation is used where k'Qk < tol * (s + 2|d'u| + |d'Ad|); default 1e-10,
+ * i.e. the moments value is only kept where it still has >= 6 significant digits */
+void fabber_vb_set_residual_tolerance(double tol);
+
 #ifdef __cplusplus
 }
 #endif

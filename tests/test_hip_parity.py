@@ -78,12 +78,13 @@ def test_c3_biexponential_single_iteration_from_identical_state(k):
     assert ok.mean() > 0.99
     e_mean, e_cov, _ = parity.voxel_errors(h1, a, b, ok)
     if hiplib.kernel_name(h1).startswith("lane<"):
-        # The lane kernel gets k'k from the streamed moments (s - 2d'u + d'Ad). Voxels that are
-        # passing through astronomically large parameter values ("wild" phase of the
-        # bi-exponential fit, up to ~17 % of the voxels around iteration 8) lose that quantity
-        # to cancellation, so their noise update differs from the oracle's; the parameter
-        # means still agree. Thresholds: median 1e-7, 90th percentile 1e-5 over all entries,
-        # 99th percentile 1e-3 on the parameter means.
+        # Up to ~17 % of the voxels are, around iteration 8, passing through astronomically
+        # large parameter values ("wild" phase of the bi-exponential fit). One step from such a
+        # state is itself ill-conditioned: even with k'k re-summed directly (the lane kernel's
+        # fallback when the moment form s - 2d'u + d'Ad cancels) the 99th percentile of the
+        # one-step difference to the oracle is ~1e-3 there, while the typical voxel agrees to
+        # 1e-10. Thresholds: median 1e-7, 90th percentile 1e-5 over all entries, 99th
+        # percentile 5e-3 on the parameter means.
         n = h1.cfg.n_params + 1
         ca, ma = oracle.unpack_mvn(a["mvn"][:, ok], n)
         cb, mb = oracle.unpack_mvn(b["mvn"][:, ok], n)
