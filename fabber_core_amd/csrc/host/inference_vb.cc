@@ -467,9 +467,9 @@ void Vb::SaveResults(FabberRunData &rundata) const
     if (want_fit)
         save_rows(rundata, "modelfit", fit, T, 0, T, V);
     if (want_nmean && N > 0)
-        save_rows(rundata, "noise_means", nmean, N, 0, N, V);
+        save_rows(rundata, "noise_means", nmean, N, 0, m_noise->NumParams(), V); // first NumParams() noise entries (inference_vb.cc:981-989)
     if (want_nstd && N > 0)
-        save_rows(rundata, "noise_stdevs", nstd, N, 0, N, V);
+        save_rows(rundata, "noise_stdevs", nstd, N, 0, m_noise->NumParams(), V);
 
     // model-specific extra outputs are defined by host code only (FwdModel::EvaluateModel with
     // a key): evaluate them on the host, like inference.cc:181-252

@@ -10,6 +10,7 @@
 #include "inference_vb.h"
 #include "noisemodel.h"
 #include "noisemodel_white.h"
+#include "noisemodel_ar.h"
 
 void FabberSetup::SetupDefaultInferenceTechniques()
 {
@@ -20,6 +21,7 @@ void FabberSetup::SetupDefaultInferenceTechniques()
 void FabberSetup::SetupDefaultNoiseModels()
 {
     NoiseModelFactory::GetInstance()->Add("white", &WhiteNoiseModel::NewInstance);
+    NoiseModelFactory::GetInstance()->Add("ar", &Ar1cNoiseModel::NewInstance);
 }
 void FabberSetup::SetupDefaultFwdModels()
 {

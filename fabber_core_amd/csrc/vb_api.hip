@@ -55,8 +55,10 @@ int validate(const fvb_config *cfg)
         return fail(-4, "n_params out of range");
     if (cfg->n_phis <= 0 || cfg->n_phis > FVB_MAX_PHIS)
         return fail(-5, "n_phis out of range");
-    if (cfg->noise != FVB_NOISE_WHITE)
+    if (cfg->noise != FVB_NOISE_WHITE && cfg->noise != FVB_NOISE_AR1)
         return fail(-6, "noise model not supported by this build");
+    if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis != 1)
+        return fail(-6, "AR(1) noise: only num-echoes = 1 with ar1-cross-terms = none is built");
     if (cfg->convergence < FVB_CONV_MAXITS || cfg->convergence > FVB_CONV_LM)
         return fail(-7, "unknown convergence detector");
     if (cfg->max_iterations <= 0)
@@ -84,6 +86,20 @@ LaneKernelInfo select_lane(const fvb_config *cfg)
     if (g_variant == 2 || cfg->n_phis != 1)
         return LaneKernelInfo{ nullptr, 0, nullptr };
     const bool need_f = cfg->need_f != 0;
+    if (cfg->noise == FVB_NOISE_AR1)
+    {
+        switch (cfg->model)
+        {
+        case FVB_MODEL_POLY:
+            return get_lane_ar_kernel_poly(cfg->n_params, need_f);
+        case FVB_MODEL_LINEAR:
+            return get_lane_ar_kernel_linear(cfg->n_params, need_f);
+        case FVB_MODEL_EXP:
+            return get_lane_ar_kernel_exp(cfg->n_params, need_f);
+        default:
+            return LaneKernelInfo{ nullptr, 0, nullptr };
+        }
+    }
     switch (cfg->model)
     {
     case FVB_MODEL_POLY:
@@ -251,6 +267,8 @@ int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const f
         return 0;
     if (!data)
         return fail(-21, "data is NULL");
+    if (cfg->noise == FVB_NOISE_AR1 && n_unmasked != cfg->n_times)
+        return fail(-15, "Masked time points are not supported for the AR noise model"); // noisemodel_ar.cc:351-355
     hipStream_t stream = (hipStream_t)stream_;
     KernelArgs ka;
     ka.cfg = *cfg;

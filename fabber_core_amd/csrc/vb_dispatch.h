@@ -1,5 +1,5 @@
-/* vb_dispatch.h - lookup of the templated lane kernels, one translation unit per model so that
- * the instantiations compile in parallel. */
+/* vb_dispatch.h - lookup of the templated lane kernels, one translation unit per model and noise
+ * model so that the instantiations compile in parallel. */
 #pragma once
 
 #include "vb_lane_kernel.h"
@@ -20,6 +20,10 @@ struct LaneKernelInfo
 LaneKernelInfo get_lane_kernel_poly(int P, bool need_f);
 LaneKernelInfo get_lane_kernel_linear(int P, bool need_f);
 LaneKernelInfo get_lane_kernel_exp(int P, bool need_f);
+// AR(1) noise (vb_lane_ar_kernel.h)
+LaneKernelInfo get_lane_ar_kernel_poly(int P, bool need_f);
+LaneKernelInfo get_lane_ar_kernel_linear(int P, bool need_f);
+LaneKernelInfo get_lane_ar_kernel_exp(int P, bool need_f);
 } // namespace fvb
 
 #define FVB_LANE_CASE(MODEL, TAG, PP)                                                                        \
@@ -28,3 +32,11 @@ LaneKernelInfo get_lane_kernel_exp(int P, bool need_f);
             return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, true>, lane_save_rows<PP>(),                \
                 "lane<" TAG "," #PP ",F>" };                                                                 \
         return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, false>, lane_save_rows<PP>(), "lane<" TAG "," #PP ">" };
+
+#define FVB_LANE_AR_CASE(MODEL, TAG, PP)                                                                     \
+    case PP:                                                                                                 \
+        if (need_f)                                                                                          \
+            return LaneKernelInfo{ vb_lane_ar_kernel<MODEL<PP>, PP, true>, lane_ar_save_rows<PP>(),          \
+                "lane_ar1<" TAG "," #PP ",F>" };                                                             \
+        return LaneKernelInfo{ vb_lane_ar_kernel<MODEL<PP>, PP, false>, lane_ar_save_rows<PP>(),             \
+            "lane_ar1<" TAG "," #PP ">" };

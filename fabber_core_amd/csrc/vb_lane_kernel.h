@@ -145,8 +145,14 @@ __device__ __forceinline__ int recentre(
     mo.s = 0;
     bool bad_offset = false, bad_jac = false;
     const uint8_t *phi_index = ka.cfg.phi_index;
+    // The sample for t+1 is requested while timepoint t is being evaluated (~200 VALU
+    // instructions), so the L2 / Infinity-Cache latency of the re-read never stalls the wave.
+    double y_next = load_data(ka, (size_t)v);
     for (int t = 0; t < T; t++)
     {
+        const double y_cur = y_next;
+        if (t + 1 < T)
+            y_next = load_data(ka, (size_t)(t + 1) * V + v);
         const double g = Model::eval(ma, t, tp);
         double J[P];
 #pragma unroll
@@ -168,7 +174,7 @@ __device__ __forceinline__ int recentre(
         const bool unmasked = phi_index ? (phi_index[t] != 255) : true; // wave-uniform
         if (unmasked)
         {
-            const double r = load_data(ka, (size_t)t * V + v) - g;
+            const double r = y_cur - g;
 #pragma unroll
             for (int i = 0; i < P; i++)
             {
@@ -372,8 +378,12 @@ __device__ __forceinline__ double exact_residual(
     }
     double kk = 0;
     const uint8_t *phi_index = ka.cfg.phi_index;
+    double y_next = load_data(ka, (size_t)v);
     for (int t = 0; t < T; t++)
     {
+        const double y_cur = y_next;
+        if (t + 1 < T)
+            y_next = load_data(ka, (size_t)(t + 1) * V + v);
         const double g = Model::eval(ma, t, tp);
         double Jd = 0;
 #pragma unroll
@@ -393,7 +403,7 @@ __device__ __forceinline__ double exact_residual(
         const bool unmasked = phi_index ? (phi_index[t] != 255) : true;
         if (unmasked)
         {
-            const double k = load_data(ka, (size_t)t * V + v) - g + Jd;
+            const double k = y_cur - g + Jd;
             kk += k * k;
         }
     }

@@ -1193,6 +1193,8 @@ static inline double load_data(const fvb_config *cfg, const void *data, size_t i
     return cfg->data_f64 ? ((const double *)data)[idx] : (double)((const float *)data)[idx];
 }
 
+#include "vb_oracle_ar.inc"
+
 } // namespace
 
 // =============================================================================================
@@ -1212,7 +1214,7 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
 {
     if (cfg->abi_version != FVB_ABI_VERSION)
         return -1;
-    if (cfg->noise != FVB_NOISE_WHITE)
+    if (cfg->noise != FVB_NOISE_WHITE && cfg->noise != FVB_NOISE_AR1)
         return -2;
     const int T = cfg->n_times, P = cfg->n_params, N = cfg->n_phis;
     const size_t V = cfg->n_voxels;
@@ -1221,6 +1223,28 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
     model.T = T;
     model.P = P;
     model.data.assign(T, 0.0);
+    if (cfg->noise == FVB_NOISE_AR1)
+    {
+        if (cfg->phi_index)
+            for (int t = 0; t < T; t++)
+                if (cfg->phi_index[t] == 255)
+                    return -3; // masked timepoints are rejected for AR noise (noisemodel_ar.cc:351-355)
+        int32_t first = 0;
+        for (int v = v_begin; v < v_end; v++)
+        {
+            vec y(T);
+            for (int t = 0; t < T; t++)
+                y[t] = load_data(cfg, data, (size_t)t * V + v);
+            model.data = y;
+            int st = run_voxel_ar(cfg, out, v, model, y, cfg->need_f != 0);
+            if (st != FVB_OK && halt_bad_voxel && first == 0)
+            {
+                first = v + 1;
+                break;
+            }
+        }
+        return first;
+    }
     WhiteNoise noise_model;
     noise_model.init(cfg);
 

@@ -295,6 +295,25 @@ def test_bad_voxels_halt_or_continue():
 
 
 @pytest.mark.gpu
+def test_ar_noise_through_the_c_abi():
+    """test_inference.cc:564-633 (MaskedTimepointsArNoise) + noise image quirk: with the AR
+    model `noise_means` holds alpha_1 (noisemodel_ar.cc:362-365, inference_vb.cc:981-989)."""
+    series = np.full(10, 2.0)
+    opts = {"model": "poly", "degree": 1, "noise": "ar", "method": "vb", "max-iterations": 10, "save-mean": True,
+            "save-mvn": True, "save-noise-mean": True}
+    out = fabber.run(volume((5, 5, 5), series), opts)
+    assert np.all(np.abs(out["mean_c0"] - 2) < 1e-3)
+    assert out["finalMVN"].shape[3] == vbabi.mvn_rows(2 + 3)
+    assert out["noise_means"].shape == (5, 5, 5)
+    n = 5
+    assert np.allclose(out["noise_means"], out["finalMVN"][..., n * (n + 1) // 2 + 2])
+    series[2] = series[6] = 4.0
+    assert np.all(fabber.run(volume((5, 5, 5), series), opts)["mean_c0"] > 2)
+    with pytest.raises(fabber.FabberError, match="Masked time points are not supported"):
+        fabber.run(volume((5, 5, 5), series), dict(opts, mt1=3, mt2=7))
+
+
+@pytest.mark.gpu
 def test_progress_callback_and_unused_option_warning():
     calls = []
     out = fabber.run(volume((2, 2, 2), [VAL] * 10), {"model": "poly", "degree": 0, "noise": "white", "method": "vb",
