@@ -310,6 +310,15 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
     }
 }
 
+// The engine's per-iteration callback carries no context pointer: the run data whose
+// ProgressCheck should hear about spatial iterations (inference_vb.cc:610) is kept per thread.
+static thread_local FabberRunData *s_progress_rundata = NULL;
+static void spatial_progress(int it, int maxits)
+{
+    if (s_progress_rundata)
+        s_progress_rundata->Progress(it, maxits);
+}
+
 void Vb::DoCalculations(FabberRunData &rundata)
 {
     fvb_config &cfg = m_store->cfg;
@@ -321,8 +330,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
     m_status.assign(m_nvoxels, 0);
 
     const bool output_only = rundata.GetBool("output-only");
-    if (IsSpatial(rundata) && !output_only)
-        throw FabberInternalError("Spatial VB (method=spatialvb / spatial priors M m P p) is not part of this build yet");
+    const bool spatial = IsSpatial(rundata);
     if (m_nvoxels == 0)
         return;
 
@@ -352,10 +360,48 @@ void Vb::DoCalculations(FabberRunData &rundata)
         out.f_history = m_f_history.Store();
         out.f_history_len = hist_len.data();
     }
-    LOG << "Vb::Voxelwise calculations on the MI355X engine, kernel " << fabber_vb_kernel_name(&cfg) << ", " << m_nvoxels
-        << " voxels x " << cfg.n_times << " timepoints" << endl;
     const int device = rundata.GetIntDefault("device", 0, 0);
-    int rc = fabber_vb_run_host(&cfg, data.Store(), &out, device);
+    const Matrix &coords = rundata.GetVoxelCoords();
+    int rc;
+    if (spatial)
+    {
+        // Vb::DoCalculationsSpatial (inference_vb.cc:578-767): whole-volume sweeps with the counting
+        // detector; options as SpatialPrior reads them (priors.cc:190-211)
+        fvb_spatial sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.spatial_dims = rundata.GetIntDefault("spatial-dims", 3, 0, 3);
+        if (sp.spatial_dims == 1)
+            WARN_ONCE("spatial-dims=1 is weird... hope you're just testing!");
+        else if (sp.spatial_dims == 2)
+            WARN_ONCE("spatial-dims=2 may not work the way you expect");
+        sp.spatial_speed = rundata.GetDoubleDefault("spatial-speed", -1);
+        sp.update_first_iter = rundata.GetBool("update-spatial-prior-on-first-iteration") ? 1 : 0;
+        sp.q1 = rundata.GetDoubleDefault("spatial-q1", 10.0);
+        sp.q2 = rundata.GetDoubleDefault("spatial-q2", 1.0);
+        if (coords.Nrows() < 3 || coords.Ncols() != m_nvoxels)
+            throw FabberInternalError("Vb::CalcNeighbours: voxel co-ordinates do not match the data");
+        vector<int32_t> grid((size_t)3 * m_nvoxels);
+        for (int d = 0; d < 3; d++)
+            for (int v = 0; v < m_nvoxels; v++)
+                grid[(size_t)d * m_nvoxels + v] = (int32_t)coords.at0(d, v);
+        sp.coords = grid.data();
+        cfg.convergence = FVB_CONV_MAXITS;
+        cfg.max_iterations = convertTo<int>(rundata.GetStringDefault("max-iterations", "10"));
+        cfg.f_history_rows = 0;
+        out.f_history = NULL;
+        out.f_history_len = NULL;
+        LOG << "Vb::Spatial calculations on the MI355X engine, " << m_nvoxels << " voxels x " << cfg.n_times
+            << " timepoints, " << cfg.max_iterations << " iterations" << endl;
+        s_progress_rundata = &rundata;
+        rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
+        s_progress_rundata = NULL;
+    }
+    else
+    {
+        LOG << "Vb::Voxelwise calculations on the MI355X engine, kernel " << fabber_vb_kernel_name(&cfg) << ", "
+            << m_nvoxels << " voxels x " << cfg.n_times << " timepoints" << endl;
+        rc = fabber_vb_run_host(&cfg, data.Store(), &out, device);
+    }
     if (rc != 0)
         throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
 
@@ -363,7 +409,6 @@ void Vb::DoCalculations(FabberRunData &rundata)
     static const char *reasons[] = { "", "LinearizedFwdModel::ReCentre: Non-finite values found in offset",
         "LinearizedFwdModel::ReCentre: Non-finite values found in jacobian", "WhiteNoiseModel::Non-finite free energy!",
         "NEWMAT exception: matrix is singular", "Ar1cNoiseModel: negative variance" };
-    const Matrix &coords = rundata.GetVoxelCoords();
     int n_bad = 0;
     for (int v = 0; v < m_nvoxels; v++)
     {

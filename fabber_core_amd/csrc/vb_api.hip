@@ -43,7 +43,7 @@ int noise_outputs(const fvb_config *cfg)
     return cfg->noise == FVB_NOISE_WHITE ? cfg->n_phis : 3;
 }
 
-int validate(const fvb_config *cfg)
+int validate(const fvb_config *cfg, bool allow_spatial = false)
 {
     if (!cfg)
         return fail(-1, "config is NULL");
@@ -75,8 +75,10 @@ int validate(const fvb_config *cfg)
     {
         if (cfg->prior_type[k] == FVB_PRIOR_IMAGE && !cfg->image_prior[k])
             return fail(-13, "image prior without an image");
-        if (cfg->prior_type[k] > FVB_PRIOR_ARD)
-            return fail(-14, "spatial priors are not handled by the voxelwise engine");
+        if (cfg->prior_type[k] > FVB_PRIOR_ARD && !allow_spatial)
+            return fail(-14, "spatial priors are not handled by the voxelwise engine (use fabber_vb_run_spatial_*)");
+        if (cfg->prior_type[k] < 0 || cfg->prior_type[k] > FVB_PRIOR_SPATIAL_p)
+            return fail(-14, "unknown prior type");
     }
     return 0;
 }
@@ -204,6 +206,27 @@ struct DevBuf
 };
 
 } // namespace
+
+// helpers shared with vb_spatial_api.hip
+namespace fvb
+{
+int api_fail(int code, const std::string &msg)
+{
+    return fail(code, msg);
+}
+int api_validate(const fvb_config *cfg, bool allow_spatial)
+{
+    return validate(cfg, allow_spatial);
+}
+int api_residual_mode()
+{
+    return g_residual_mode;
+}
+double api_residual_tol()
+{
+    return g_residual_tol;
+}
+} // namespace fvb
 
 extern "C" {
 
@@ -407,7 +430,7 @@ int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_ou
 int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp,
     void *stream)
 {
-    int rc = validate(cfg);
+    int rc = validate(cfg, true); // the output images do not depend on the prior types
     if (rc)
         return rc;
     if (!mvn || !pp)
@@ -426,7 +449,7 @@ int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const
 int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp,
     int32_t device)
 {
-    int rc = validate(cfg);
+    int rc = validate(cfg, true);
     if (rc)
         return rc;
     if (fabber_vb_device_count() <= 0)

@@ -1,0 +1,517 @@
+/*
+ * vb_spatial.h - spatial VB (Vb::DoCalculationsSpatial, inference_vb.cc:578-767) on MI355X.
+ *
+ * The reference sweeps the voxels in index order twice per iteration. In the first sweep voxel
+ * v's spatial prior (SpatialPrior::ApplyToMVN, priors.cc:346-488) reads its neighbours' CURRENT
+ * posterior means - already updated for u < v, previous iteration for u > v (Gauss-Seidel) -
+ * and then UpdateTheta changes v's own mean. That order is kept EXACTLY: with
+ * level(v) = x + 2y + 4z every first or second neighbour of v with a smaller index has a
+ * strictly smaller level and every one with a larger index a strictly larger level (all twelve
+ * stencil offsets have non-zero level difference of the right sign), so voxels of one level are
+ * independent and the levels are processed in ascending order, one launch each
+ * (vb_spatial_theta_kernel). The second sweep (UpdateNoise, ReCentre, F) has no coupling and is
+ * one lane-per-voxel launch over all voxels (vb_spatial_noise_kernel) sharing its device
+ * functions with the voxelwise kernel. The global smoothing precisions aK (CalculateaK,
+ * priors.cc:221-344) are two deterministic tree reductions per spatial parameter per iteration.
+ *
+ * Per-voxel state lives in HBM between launches as a [rows][V] image (SpLayout).
+ */
+#pragma once
+
+#include "vb_lane_kernel.h"
+
+namespace fvb
+{
+// Row offsets of the persistent per-voxel state image
+template <int P>
+struct SpLayout
+{
+    static constexpr int PT = P * (P + 1) / 2;
+    static constexpr int M = 0;            // posterior means [P]
+    static constexpr int SIG = M + P;      // posterior covariance [PT]
+    static constexpr int LOGDET = SIG + PT; // log|det Lambda|
+    static constexpr int PM = LOGDET + 1;  // prior means [P]
+    static constexpr int PPREC = PM + P;   // prior precisions (diagonal) [P]
+    static constexpr int B = PPREC + P;    // noise scale
+    static constexpr int C = B + 1;        // noise shape
+    static constexpr int A = C + 1;        // J'J [PT]
+    static constexpr int U = A + PT;       // J'r [P]
+    static constexpr int S = U + P;        // r'r
+    static constexpr int ML = S + 1;       // linearisation centre [P]
+    static constexpr int ROWS = ML + P;
+};
+
+struct SpatialArgs
+{
+    KernelArgs ka;
+    double *state;          // [SpLayout<P>::ROWS][V]
+    const int32_t *nn;      // [V][6] first neighbours (0-based, -1 = none), reference order
+    const int32_t *order;   // voxel ids sorted by level
+    double *aK;             // [P] smoothing precision per (spatial) parameter
+    double *partials;       // [n_blocks][P][2] reduction scratch
+    double *fprior_last;    // F contribution of the priors of the LAST voxel of the first sweep
+    int32_t *status;        // [V]
+    int32_t spatial_dims;
+    int32_t update_first_iter;
+    double spatial_speed, q1, q2;
+    int32_t it;
+    int32_t level_begin, level_count;
+    int32_t n_blocks;
+};
+
+#if defined(__HIPCC__)
+
+template <int P>
+__device__ __forceinline__ void sp_load(const SpatialArgs &sa, int v, VoxelState<P> &st, Moments<P> &mo)
+{
+    typedef SpLayout<P> L;
+    const size_t V = (size_t)sa.ka.cfg.n_voxels;
+    const double *p = sa.state + v;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        st.m[i] = p[(size_t)(L::M + i) * V];
+        st.pm[i] = p[(size_t)(L::PM + i) * V];
+        st.pprec[i] = p[(size_t)(L::PPREC + i) * V];
+        mo.u[i] = p[(size_t)(L::U + i) * V];
+        mo.ml[i] = p[(size_t)(L::ML + i) * V];
+    }
+#pragma unroll
+    for (int i = 0; i < L::PT; i++)
+    {
+        st.Sig[i] = p[(size_t)(L::SIG + i) * V];
+        mo.A[i] = p[(size_t)(L::A + i) * V];
+    }
+    st.logdetLam = p[(size_t)L::LOGDET * V];
+    st.b = p[(size_t)L::B * V];
+    st.c = p[(size_t)L::C * V];
+    mo.s = p[(size_t)L::S * V];
+    st.covValid = true;
+    st.precValid = false;
+}
+
+template <int P>
+__device__ __forceinline__ void sp_store_theta(const SpatialArgs &sa, int v, const VoxelState<P> &st)
+{
+    typedef SpLayout<P> L;
+    const size_t V = (size_t)sa.ka.cfg.n_voxels;
+    double *p = sa.state + v;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        p[(size_t)(L::M + i) * V] = st.m[i];
+        p[(size_t)(L::PM + i) * V] = st.pm[i];
+        p[(size_t)(L::PPREC + i) * V] = st.pprec[i];
+    }
+#pragma unroll
+    for (int i = 0; i < L::PT; i++)
+        p[(size_t)(L::SIG + i) * V] = st.Sig[i];
+    p[(size_t)L::LOGDET * V] = st.logdetLam;
+}
+
+template <int P>
+__device__ __forceinline__ void sp_store_noise(const SpatialArgs &sa, int v, const VoxelState<P> &st, const Moments<P> &mo)
+{
+    typedef SpLayout<P> L;
+    const size_t V = (size_t)sa.ka.cfg.n_voxels;
+    double *p = sa.state + v;
+    p[(size_t)L::B * V] = st.b;
+    p[(size_t)L::C * V] = st.c;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        p[(size_t)(L::U + i) * V] = mo.u[i];
+        p[(size_t)(L::ML + i) * V] = mo.ml[i];
+    }
+#pragma unroll
+    for (int i = 0; i < L::PT; i++)
+        p[(size_t)(L::A + i) * V] = mo.A[i];
+    p[(size_t)L::S * V] = mo.s;
+}
+
+__device__ __forceinline__ bool is_spatial_type(int t)
+{
+    return t >= FVB_PRIOR_SPATIAL_M;
+}
+
+// ---- setup: Vb::SetupPerVoxelDists (inference_vb.cc:207-247), one lane per voxel --------------
+template <class Model, int P>
+__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_spatial_setup_kernel(const SpatialArgs sa)
+{
+    const KernelArgs &ka = sa.ka;
+    constexpr int PT = P * (P + 1) / 2;
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    const int T = ka.cfg.n_times;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    if (v >= ka.cfg.n_voxels)
+        return;
+    ModelArgs ma;
+    ma.iopt0 = ka.cfg.model_iopt[0];
+    ma.dopt0 = ka.cfg.model_dopt[0];
+    ma.design = ka.cfg.design;
+    VoxelState<P> st;
+    Moments<P> mo;
+    if (ka.cfg.init_mvn)
+    {
+        constexpr int n = P + 1;
+        constexpr int nCov = n * (n + 1) / 2;
+        const double *src = ka.cfg.init_mvn + v;
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            st.Sig[i] = src[(size_t)i * V];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            st.m[i] = src[(size_t)(nCov + i) * V];
+        const double nm = src[(size_t)(nCov + P) * V];
+        const double nv = src[(size_t)tri(P, P) * V];
+        st.b = nv / nm;
+        st.c = nm / st.b;
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            st.Sig[i] = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            st.m[i] = (ka.cfg.prior_type[i] == FVB_PRIOR_IMAGE) ? ka.cfg.image_prior[i][v] : ka.cfg.post_mean[i];
+            st.Sig[tri(i, i)] = ka.cfg.post_var[i];
+        }
+        if (Model::needs_data_max)
+        {
+            double data_max = load_data(ka, v);
+            for (int t = 1; t < T; t++)
+            {
+                const double y = load_data(ka, (size_t)t * V + v);
+                data_max = (y > data_max) ? y : data_max;
+            }
+            Model::init_posterior(ma, data_max, st.m);
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            const int tr = ka.cfg.transform[i];
+            st.m[i] = to_fabber(tr, st.m[i]);
+            st.Sig[tri(i, i)] = to_fabber_var(tr, st.Sig[tri(i, i)]);
+        }
+        st.b = ka.cfg.noise_post_b[0];
+        st.c = ka.cfg.noise_post_c[0];
+    }
+    st.covValid = true;
+    st.precValid = false;
+    st.logdetLam = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        st.pm[i] = 0;
+        st.pprec[i] = 1;
+    }
+    const int status = recentre<Model, P>(ka, ma, v, st.m, mo);
+    sa.status[v] = status ? (status | 0x100) : 0;
+    sp_store_theta<P>(sa, v, st);
+    sp_store_noise<P>(sa, v, st, mo);
+}
+
+// ---- CalculateaK (priors.cc:221-344): per-block partial sums of (trace_term, term2) ------------
+template <int P>
+__global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const SpatialArgs sa)
+{
+    typedef SpLayout<P> L;
+    const KernelArgs &ka = sa.ka;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    const int dims = sa.spatial_dims;
+    __shared__ double red[256];
+    for (int k = 0; k < P; k++)
+    {
+        const int type = ka.cfg.prior_type[k];
+        if (!is_spatial_type(type))
+            continue;
+        double trace_term = 0, term2 = 0;
+        for (int v = blockIdx.x * 256 + threadIdx.x; v < (int)V; v += gridDim.x * 256)
+        {
+            const double sigmaK = sa.state[(size_t)(L::SIG + tri(k, k)) * V + v];
+            const double wK = sa.state[(size_t)(L::M + k) * V + v];
+            int nn = 0;
+            double SwK = 0;
+            for (int i = 0; i < 6; i++)
+            {
+                const int u = sa.nn[(size_t)v * 6 + i];
+                if (u >= 0)
+                {
+                    nn++;
+                    SwK += wK - sa.state[(size_t)(L::M + k) * V + u];
+                }
+            }
+            if (type == FVB_PRIOR_SPATIAL_m)
+                trace_term += sigmaK * dims * 2;
+            else if (type == FVB_PRIOR_SPATIAL_M)
+                trace_term += sigmaK * (nn + 1e-8);
+            else if (type == FVB_PRIOR_SPATIAL_p)
+                trace_term += sigmaK * (4 * dims * dims + 2 * dims);
+            else
+                trace_term += sigmaK * (nn * nn + nn);
+            if (type == FVB_PRIOR_SPATIAL_p || type == FVB_PRIOR_SPATIAL_m)
+                SwK += wK * (dims * 2 - nn);
+            if (type == FVB_PRIOR_SPATIAL_m || type == FVB_PRIOR_SPATIAL_M)
+                term2 += SwK * wK;
+            else
+                term2 += SwK * SwK;
+        }
+        for (int which = 0; which < 2; which++)
+        {
+            red[threadIdx.x] = which ? term2 : trace_term;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1)
+            {
+                if ((int)threadIdx.x < s)
+                    red[threadIdx.x] += red[threadIdx.x + s];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0)
+                sa.partials[((size_t)blockIdx.x * P + k) * 2 + which] = red[0];
+            __syncthreads();
+        }
+    }
+}
+
+template <int P>
+__global__ void vb_spatial_ak_final_kernel(const SpatialArgs sa)
+{
+    const KernelArgs &ka = sa.ka;
+    const int k = threadIdx.x;
+    if (k >= P || !is_spatial_type(ka.cfg.prior_type[k]))
+        return;
+    double trace_term = 0, term2 = 0;
+    for (int b = 0; b < sa.n_blocks; b++) // fixed order: deterministic
+    {
+        trace_term += sa.partials[((size_t)b * P + k) * 2 + 0];
+        term2 += sa.partials[((size_t)b * P + k) * 2 + 1];
+    }
+    const double gk = 1 / (0.5 * trace_term + 0.5 * term2 + 1 / sa.q1);
+    const double hK = ka.cfg.n_voxels * 0.5 + sa.q2;
+    double aK = gk * hK;
+    if (aK < 1e-50)
+        aK = 1e-50;
+    double aKMax = aK * sa.spatial_speed;
+    if (aKMax < 0.5)
+        aKMax = 0.5;
+    if ((sa.spatial_speed > 0) && (aK > aKMax))
+        aK = aKMax;
+    sa.aK[k] = aK;
+}
+
+// ---- first sweep, one level: priors + UpdateTheta (inference_vb.cc:614-672) -------------------
+template <int P>
+__global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs sa)
+{
+    typedef SpLayout<P> L;
+    const KernelArgs &ka = sa.ka;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= sa.level_count)
+        return;
+    const int v = sa.order[sa.level_begin + i];
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    if (sa.status[v] != 0)
+        return;
+    VoxelState<P> st;
+    Moments<P> mo;
+    sp_load<P>(sa, v, st, mo);
+    const int dims = sa.spatial_dims;
+    double Fprior = 0;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+    {
+        const int type = ka.cfg.prior_type[k];
+        if (is_spatial_type(type))
+        {
+            // SpatialPrior::ApplyToMVN (priors.cc:362-482)
+            const double *mk = sa.state + (size_t)(L::M + k) * V;
+            int nn = 0, nn2 = 0;
+            double contrib_nn = 0, contrib_nn2 = 0;
+            for (int a = 0; a < 6; a++)
+            {
+                const int u = sa.nn[(size_t)v * 6 + a];
+                if (u < 0)
+                    continue;
+                nn++;
+                contrib_nn += mk[u];
+                if (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p)
+                    for (int b = 0; b < 6; b++)
+                    {
+                        const int w = sa.nn[(size_t)u * 6 + b];
+                        if (w >= 0 && w != v)
+                        {
+                            nn2++;
+                            contrib_nn2 += -mk[w];
+                        }
+                    }
+            }
+            if (type == FVB_PRIOR_SPATIAL_p || type == FVB_PRIOR_SPATIAL_m)
+            {
+                nn = 2 * dims;
+                nn2 = 4 * dims * dims - nn;
+            }
+            const double aK = sa.aK[k];
+            double spatial_prec;
+            if (type == FVB_PRIOR_SPATIAL_M)
+                spatial_prec = aK * (nn + 1e-8);
+            else if (type == FVB_PRIOR_SPATIAL_m)
+                spatial_prec = aK * nn;
+            else
+                spatial_prec = aK * (nn * nn + nn);
+            const double prec0 = ka.cfg.prior_prec[k], mean0 = ka.cfg.prior_mean[k];
+            if (type == FVB_PRIOR_SPATIAL_p || type == FVB_PRIOR_SPATIAL_m)
+                st.pprec[k] = spatial_prec;
+            else
+                st.pprec[k] = prec0 + spatial_prec;
+            double spatial_mean;
+            if (type == FVB_PRIOR_SPATIAL_m || type == FVB_PRIOR_SPATIAL_M)
+            {
+                const double rec = 1 / double(nn);
+                spatial_mean = contrib_nn * rec;
+            }
+            else if (nn != 0)
+            {
+                const double rec = 1 / double(8 * nn - nn2);
+                spatial_mean = (8 * contrib_nn + contrib_nn2) * rec;
+            }
+            else
+                spatial_mean = 0;
+            const double pcov = 1.0 / st.pprec[k]; // (prior precisions are diagonal)
+            if (type == FVB_PRIOR_SPATIAL_m || type == FVB_PRIOR_SPATIAL_M)
+                st.pm[k] = pcov * spatial_prec * spatial_mean;
+            else
+                st.pm[k] = pcov * (spatial_prec * spatial_mean + prec0 * mean0);
+        }
+        else if (type == FVB_PRIOR_ARD) // priors.cc:150-181
+        {
+            const double new_cov = st.m[k] * st.m[k] + st.Sig[tri(k, k)];
+            if (sa.it == 0)
+            {
+                st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
+                st.pm[k] = ka.cfg.prior_mean[k];
+            }
+            else
+                st.pprec[k] = 1.0 / new_cov;
+            const double bb = 2 / new_cov;
+            Fprior += -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
+        }
+        else if (type == FVB_PRIOR_IMAGE)
+        {
+            st.pm[k] = ka.cfg.image_prior[k][v];
+            st.pprec[k] = ka.cfg.prior_prec[k];
+        }
+        else
+        {
+            st.pm[k] = ka.cfg.prior_mean[k];
+            st.pprec[k] = ka.cfg.prior_prec[k];
+        }
+    }
+    if (v == ka.cfg.n_voxels - 1)
+        *sa.fprior_last = Fprior;
+    if (!update_theta<P>(st, mo, 0.0)) // LMalpha = 0 in the spatial loop (:649)
+        sa.status[v] = FVB_BAD_RESULT;
+    sp_store_theta<P>(sa, v, st);
+}
+
+// ---- second sweep: UpdateNoise, ReCentre, F (inference_vb.cc:674-722), all voxels -------------
+template <class Model, int P, bool NEEDF>
+__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_spatial_noise_kernel(const SpatialArgs sa)
+{
+    const KernelArgs &ka = sa.ka;
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= ka.cfg.n_voxels)
+        return;
+    if (sa.status[v] != 0)
+        return;
+    ModelArgs ma;
+    ma.iopt0 = ka.cfg.model_iopt[0];
+    ma.dopt0 = ka.cfg.model_dopt[0];
+    ma.design = ka.cfg.design;
+    VoxelState<P> st;
+    Moments<P> mo;
+    sp_load<P>(sa, v, st, mo);
+    double kk, trSA;
+    residual_and_trace<Model, P>(ka, ma, v, st, mo, kk, trSA);
+    update_noise<P>(ka, st, kk, trSA);
+    int status = recentre<Model, P>(ka, ma, v, st.m, mo);
+    if (status == FVB_OK && NEEDF)
+    {
+        // only the last of the reference's four F evaluations per iteration is observable
+        // (resultFs is overwritten each time); it uses the prior term of the LAST voxel of the
+        // first sweep (the reference reuses one local variable, inference_vb.cc:612,689,702)
+        st.covValid = true;
+        st.precValid = false;
+        double F;
+        bool finite = true;
+        if (!calc_free_energy<P>(ka, st, mo.s, trace_SA<P>(st, mo), *sa.fprior_last, F, finite))
+            status = FVB_BAD_RESULT;
+        else if (!finite)
+            status = FVB_BAD_FREE_ENERGY;
+        else if (ka.out.free_energy)
+            ka.out.free_energy[v] = F;
+    }
+    if (status != FVB_OK)
+        sa.status[v] = status;
+    sp_store_noise<P>(sa, v, st, mo);
+}
+
+// ---- result image (inference_vb.cc:757-762) ----------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void vb_spatial_pack_kernel(const SpatialArgs sa)
+{
+    typedef SpLayout<P> L;
+    const KernelArgs &ka = sa.ka;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= ka.cfg.n_voxels)
+        return;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    constexpr int n = P + 1;
+    constexpr int nCov = n * (n + 1) / 2;
+    const double *p = sa.state + v;
+    double *dst = ka.out.mvn + v;
+#pragma unroll
+    for (int i = 0; i < L::PT; i++)
+        dst[(size_t)i * V] = p[(size_t)(L::SIG + i) * V];
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        dst[(size_t)tri(P, j) * V] = 0.0;
+    const double b = p[(size_t)L::B * V], c = p[(size_t)L::C * V];
+    dst[(size_t)tri(P, P) * V] = b * b * c;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        dst[(size_t)(nCov + i) * V] = p[(size_t)(L::M + i) * V];
+    dst[(size_t)(nCov + P) * V] = b * c;
+    dst[(size_t)(nCov + n) * V] = 1.0;
+    if (ka.out.status)
+        ka.out.status[v] = sa.status[v];
+    if (ka.out.iterations)
+        ka.out.iterations[v] = sa.it;
+    if (ka.out.free_energy && !ka.cfg.need_f)
+        ka.out.free_energy[v] = 1234.5678;
+}
+
+#endif // __HIPCC__
+
+// Kernel table for one (model, P)
+typedef void (*SpatialKernelFn)(const SpatialArgs);
+struct SpatialKernels
+{
+    SpatialKernelFn setup, ak_partial, ak_final, theta, noise, pack;
+    int state_rows;
+    const char *name;
+};
+SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
+SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
+SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
+
+#define FVB_SPATIAL_CASE(MODEL, TAG, PP)                                                                     \
+    case PP:                                                                                                 \
+        return SpatialKernels{ vb_spatial_setup_kernel<MODEL<PP>, PP>, vb_spatial_ak_partial_kernel<PP>,     \
+            vb_spatial_ak_final_kernel<PP>, vb_spatial_theta_kernel<PP>,                                     \
+            need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true>                           \
+                   : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false>,                         \
+            vb_spatial_pack_kernel<PP>, SpLayout<PP>::ROWS, "spatial<" TAG "," #PP ">" };
+
+} // namespace fvb

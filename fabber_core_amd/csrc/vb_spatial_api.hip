@@ -1,0 +1,371 @@
+/*
+ * vb_spatial_api.hip - host driver of spatial VB: neighbour lists (Vb::CalcNeighbours,
+ * inference_vb.cc:830-964), level ordering, the iteration loop of Vb::DoCalculationsSpatial
+ * (inference_vb.cc:605-725) as a sequence of launches on one stream. See vb_spatial.h.
+ */
+#include "vb_spatial.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fvb;
+
+extern "C" const char *fabber_vb_last_error(void);
+namespace fvb
+{
+int api_fail(int code, const std::string &msg); // vb_api.hip
+int api_validate(const fvb_config *cfg, bool allow_spatial);
+int api_residual_mode();
+double api_residual_tol();
+}
+
+namespace
+{
+#define FVB_HIP_CHECK(expr)                                                                                  \
+    do                                                                                                       \
+    {                                                                                                        \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return api_fail(-100 - (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+int sign_of(int x)
+{
+    return (x > 0) - (x < 0);
+}
+
+// First-neighbour table in the reference's order (+x, -x, +y, -y, +z, -z, limited by
+// spatial-dims), -1 where there is no neighbour. Returns "" or an error message.
+std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector<int32_t> &nn)
+{
+    nn.assign((size_t)V * 6, -1);
+    if (V == 0)
+        return "";
+    const int32_t *X = coords, *Y = coords + V, *Z = coords + 2 * (size_t)V;
+    for (int v = 0; v + 1 < V; v++) // CheckCoordMatrixCorrectlyOrdered, :769-793
+        if (sign_of(X[v + 1] - X[v]) + 10 * sign_of(Y[v + 1] - Y[v]) + 100 * sign_of(Z[v + 1] - Z[v]) <= 0)
+            return "Coordinate matrix must be in correct order to use adjacency-based priors.";
+    int xsize = 0, ysize = 0;
+    for (int v = 0; v < V; v++)
+    {
+        xsize = std::max(xsize, (int)X[v] + 1);
+        ysize = std::max(ysize, (int)Y[v] + 1);
+    }
+    std::vector<long long> offsets(V);
+    for (int v = 0; v < V; v++)
+        offsets[v] = (long long)Z[v] * xsize * ysize + (long long)Y[v] * xsize + X[v];
+    const long long delta[6] = { 1, -1, xsize, -xsize, (long long)xsize * ysize, -(long long)xsize * ysize };
+    const int max_delta = dims * 2 - 1;
+    for (int v = 0; v < V; v++)
+    {
+        const long long pos = offsets[v];
+        for (int n = 0; n <= max_delta; n++)
+        {
+            auto it = std::lower_bound(offsets.begin(), offsets.end(), pos + delta[n]);
+            if (it == offsets.end() || *it != pos + delta[n])
+                continue;
+            if (n < 4) // wrap-around test, :906-925
+            {
+                bool ignore = false;
+                if (delta[n] > 0)
+                {
+                    const long long test = delta[n + 2];
+                    if (test > 0)
+                        ignore = (pos % test) >= test - delta[n];
+                }
+                else
+                {
+                    const long long test = -delta[n + 2];
+                    if (test > 0)
+                        ignore = (pos % test) < -delta[n];
+                }
+                if (ignore)
+                    continue;
+            }
+            // keep the reference's list order: entries are appended, so compact to the front
+            int32_t *row = &nn[(size_t)v * 6];
+            int slot = 0;
+            while (row[slot] >= 0)
+                slot++;
+            row[slot] = (int32_t)(it - offsets.begin());
+        }
+    }
+    // every neighbour relation must be mutual (:958-962)
+    for (int v = 0; v < V; v++)
+        for (int a = 0; a < 6 && nn[(size_t)v * 6 + a] >= 0; a++)
+        {
+            const int u = nn[(size_t)v * 6 + a];
+            int back = 0;
+            for (int b = 0; b < 6; b++)
+                back += (nn[(size_t)u * 6 + b] == v);
+            if (back != 1)
+                return "Each of this voxel's neighbours must have this voxel as a neighbour";
+        }
+    return "";
+}
+
+struct DevMem
+{
+    void *p = nullptr;
+    ~DevMem()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes)
+    {
+        return hipMalloc(&p, bytes ? bytes : 8);
+    }
+};
+
+int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data, const fvb_outputs *d_out,
+    hipStream_t stream, void (*progress_cb)(int, int))
+{
+    const int V = cfg->n_voxels, P = cfg->n_params;
+    const bool need_f = cfg->need_f != 0;
+    SpatialKernels k;
+    switch (cfg->model)
+    {
+    case FVB_MODEL_POLY:
+        k = get_spatial_kernels_poly(P, need_f);
+        break;
+    case FVB_MODEL_LINEAR:
+        k = get_spatial_kernels_linear(P, need_f);
+        break;
+    case FVB_MODEL_EXP:
+        k = get_spatial_kernels_exp(P, need_f);
+        break;
+    default:
+        k = SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+    }
+    if (!k.setup)
+        return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
+
+    // ---- host-side geometry ----
+    std::vector<int32_t> nn;
+    std::string err = build_neighbours(sp->coords, V, sp->spatial_dims, nn);
+    if (!err.empty())
+        return api_fail(-41, err);
+    const int32_t *X = sp->coords, *Y = sp->coords + V, *Z = sp->coords + 2 * (size_t)V;
+    std::vector<long long> level(V);
+    for (int v = 0; v < V; v++)
+        level[v] = (long long)X[v] + 2LL * Y[v] + 4LL * Z[v];
+    std::vector<int32_t> order(V);
+    for (int v = 0; v < V; v++)
+        order[v] = v;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
+    std::vector<int32_t> level_begin;
+    for (int i = 0; i < V; i++)
+        if (i == 0 || level[order[i]] != level[order[i - 1]])
+            level_begin.push_back(i);
+    level_begin.push_back(V);
+
+    // ---- device memory ----
+    const int n_blocks = std::max(1, std::min(1024, (V + 255) / 256));
+    DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status;
+    FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V));
+    FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6));
+    FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * (size_t)V));
+    FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS));
+    FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)n_blocks * P * 2));
+    FVB_HIP_CHECK(d_fprior.alloc(sizeof(double)));
+    FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V));
+    FVB_HIP_CHECK(hipMemcpyAsync(d_nn.p, nn.data(), sizeof(int32_t) * (size_t)V * 6, hipMemcpyHostToDevice, stream));
+    FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
+    double aK0[FVB_MAX_PARAMS];
+    for (int i = 0; i < FVB_MAX_PARAMS; i++)
+        aK0[i] = 1e-8; // priors.cc:185
+    FVB_HIP_CHECK(hipMemcpyAsync(d_aK.p, aK0, sizeof(aK0), hipMemcpyHostToDevice, stream));
+    FVB_HIP_CHECK(hipMemsetAsync(d_fprior.p, 0, sizeof(double), stream));
+    FVB_HIP_CHECK(hipMemsetAsync(d_partials.p, 0, sizeof(double) * (size_t)n_blocks * P * 2, stream));
+
+    SpatialArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.ka.cfg = *cfg;
+    sa.ka.out = *d_out;
+    sa.ka.data = d_data;
+    sa.ka.save = nullptr;
+    sa.ka.n_unmasked = 0; // filled by the caller below
+    sa.ka.residual_mode = api_residual_mode();
+    sa.ka.residual_tol = api_residual_tol();
+    sa.state = (double *)d_state.p;
+    sa.nn = (const int32_t *)d_nn.p;
+    sa.order = (const int32_t *)d_order.p;
+    sa.aK = (double *)d_aK.p;
+    sa.partials = (double *)d_partials.p;
+    sa.fprior_last = (double *)d_fprior.p;
+    sa.status = (int32_t *)d_status.p;
+    sa.spatial_dims = sp->spatial_dims;
+    sa.update_first_iter = sp->update_first_iter;
+    sa.spatial_speed = sp->spatial_speed;
+    sa.q1 = sp->q1;
+    sa.q2 = sp->q2;
+    sa.n_blocks = n_blocks;
+    {
+        // number of unmasked timepoints: phi_index is a device pointer here, read it back once
+        int n_unmasked = cfg->n_times;
+        if (cfg->phi_index)
+        {
+            std::vector<uint8_t> h(cfg->n_times);
+            FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg->phi_index, h.size(), hipMemcpyDeviceToHost, stream));
+            FVB_HIP_CHECK(hipStreamSynchronize(stream));
+            n_unmasked = 0;
+            for (int t = 0; t < cfg->n_times; t++)
+                n_unmasked += (h[t] != 255);
+        }
+        sa.ka.n_unmasked = n_unmasked;
+
+        const unsigned grid64 = (unsigned)((V + 63) / 64), grid256 = (unsigned)((V + 255) / 256);
+        hipLaunchKernelGGL(k.setup, dim3(grid64), dim3(64), 0, stream, sa);
+        FVB_HIP_CHECK(hipGetLastError());
+        bool has_spatial = false;
+        for (int kk = 0; kk < P; kk++)
+            has_spatial |= cfg->prior_type[kk] >= FVB_PRIOR_SPATIAL_M;
+        for (int it = 0; it < cfg->max_iterations; it++)
+        {
+            if (progress_cb)
+                progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
+            sa.it = it;
+            if (has_spatial && (it > 0 || sp->update_first_iter))
+            {
+                hipLaunchKernelGGL(k.ak_partial, dim3(n_blocks), dim3(256), 0, stream, sa);
+                hipLaunchKernelGGL(k.ak_final, dim3(1), dim3(64), 0, stream, sa);
+            }
+            for (size_t l = 0; l + 1 < level_begin.size(); l++)
+            {
+                sa.level_begin = level_begin[l];
+                sa.level_count = level_begin[l + 1] - level_begin[l];
+                hipLaunchKernelGGL(k.theta, dim3((unsigned)((sa.level_count + 63) / 64)), dim3(64), 0, stream, sa);
+            }
+            hipLaunchKernelGGL(k.noise, dim3(grid64), dim3(64), 0, stream, sa);
+            FVB_HIP_CHECK(hipGetLastError());
+        }
+        sa.it = cfg->max_iterations;
+        hipLaunchKernelGGL(k.pack, dim3(grid256), dim3(256), 0, stream, sa);
+        FVB_HIP_CHECK(hipGetLastError());
+        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // the DevMem buffers are freed on return
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" {
+
+int32_t fabber_vb_run_spatial_device(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
+    const fvb_outputs *out, void *stream, void (*progress_cb)(int, int))
+{
+    int rc = api_validate(cfg, true);
+    if (rc)
+        return rc;
+    if (!sp || !sp->coords)
+        return api_fail(-42, "spatial description / coordinates missing");
+    if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
+        return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
+    if (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis != 1)
+        return api_fail(-44, "spatial VB is built for white noise with one noise parameter");
+    if (!out || !out->mvn)
+        return api_fail(-20, "outputs.mvn is required");
+    if (cfg->n_voxels == 0)
+        return 0;
+    if (!data)
+        return api_fail(-21, "data is NULL");
+    return run_spatial(cfg, sp, data, out, (hipStream_t)stream, progress_cb);
+}
+
+int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
+    const fvb_outputs *out, int32_t device, void (*progress_cb)(int, int))
+{
+    int rc = api_validate(cfg, true);
+    if (rc)
+        return rc;
+    if (!out || !out->mvn)
+        return api_fail(-20, "outputs.mvn is required");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return api_fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
+    FVB_HIP_CHECK(hipSetDevice(device));
+    const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times;
+    if (V == 0)
+        return 0;
+    const int P = cfg->n_params;
+    const int n = P + 1, rows = n * (n + 1) / 2 + n + 1;
+    const size_t esz = cfg->data_f64 ? 8 : 4;
+    fvb_config d = *cfg;
+    DevMem b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_status, b_it;
+    FVB_HIP_CHECK(b_data.alloc(T * V * esz));
+    FVB_HIP_CHECK(hipMemcpy(b_data.p, data, T * V * esz, hipMemcpyHostToDevice));
+    if (cfg->design)
+    {
+        FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P));
+        FVB_HIP_CHECK(hipMemcpy(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice));
+        d.design = (const double *)b_design.p;
+    }
+    if (cfg->phi_index)
+    {
+        FVB_HIP_CHECK(b_phi.alloc(T));
+        FVB_HIP_CHECK(hipMemcpy(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice));
+        d.phi_index = (const uint8_t *)b_phi.p;
+    }
+    if (cfg->init_mvn)
+    {
+        FVB_HIP_CHECK(b_init.alloc(sizeof(double) * rows * V));
+        FVB_HIP_CHECK(hipMemcpy(b_init.p, cfg->init_mvn, sizeof(double) * rows * V, hipMemcpyHostToDevice));
+        d.init_mvn = (const double *)b_init.p;
+    }
+    for (int kk = 0; kk < P; kk++)
+        if (cfg->image_prior[kk])
+        {
+            FVB_HIP_CHECK(b_img[kk].alloc(sizeof(double) * V));
+            FVB_HIP_CHECK(hipMemcpy(b_img[kk].p, cfg->image_prior[kk], sizeof(double) * V, hipMemcpyHostToDevice));
+            d.image_prior[kk] = (const double *)b_img[kk].p;
+        }
+    fvb_outputs dout;
+    memset(&dout, 0, sizeof(dout));
+    FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * V));
+    dout.mvn = (double *)b_mvn.p;
+    if (out->free_energy)
+    {
+        FVB_HIP_CHECK(b_f.alloc(sizeof(double) * V));
+        dout.free_energy = (double *)b_f.p;
+    }
+    if (out->status)
+    {
+        FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * V));
+        dout.status = (int32_t *)b_status.p;
+    }
+    if (out->iterations)
+    {
+        FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * V));
+        dout.iterations = (int32_t *)b_it.p;
+    }
+    rc = fabber_vb_run_spatial_device(&d, sp, b_data.p, &dout, nullptr, progress_cb);
+    if (rc)
+        return rc;
+    FVB_HIP_CHECK(hipDeviceSynchronize());
+    FVB_HIP_CHECK(hipMemcpy(out->mvn, dout.mvn, sizeof(double) * rows * V, hipMemcpyDeviceToHost));
+    if (dout.free_energy)
+        FVB_HIP_CHECK(hipMemcpy(out->free_energy, dout.free_energy, sizeof(double) * V, hipMemcpyDeviceToHost));
+    if (dout.status)
+        FVB_HIP_CHECK(hipMemcpy(out->status, dout.status, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    if (dout.iterations)
+        FVB_HIP_CHECK(hipMemcpy(out->iterations, dout.iterations, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+} // extern "C"
+
+// Host-only helper (no GPU needed): the first-neighbour table the spatial driver builds,
+// [n_voxels][6], 0-based ids, -1 = none. For the unit tests of the neighbour construction.
+extern "C" int32_t fabber_vb_neighbours(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t *nn_out)
+{
+    std::vector<int32_t> nn;
+    std::string err = build_neighbours(coords, n_voxels, spatial_dims, nn);
+    if (!err.empty())
+        return fvb::api_fail(-41, err);
+    std::copy(nn.begin(), nn.end(), nn_out);
+    return 0;
+}

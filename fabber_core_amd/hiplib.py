@@ -181,3 +181,45 @@ def ldl_inverse(a):
             out[i, j] = out[j, i] = inv[k]
             k += 1
     return out, logabs.value, sign.value, rc == 0
+
+
+# ---- spatial VB --------------------------------------------------------------------------------
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int)
+
+
+def run_spatial_host(holder, spatial, data, device=0, progress_cb=None):
+    """Spatial VB on the GPU from host arrays. spatial: vbabi.SpatialHolder."""
+    cfg = holder.cfg
+    data = _prepare_data(holder, data)
+    V = cfg.n_voxels
+    arrs = dict(
+        mvn=np.full((holder.n_mvn_rows, V), np.nan),
+        free_energy=np.full(V, np.nan),
+        status=np.full(V, -1, dtype=np.int32),
+        iterations=np.full(V, -1, dtype=np.int32),
+    )
+    out = vbabi.FvbOutputs()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    L = lib()
+    L.fabber_vb_run_spatial_host.restype = C.c_int32
+    L.fabber_vb_run_spatial_host.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbSpatial), C.c_void_p,
+                                             C.POINTER(vbabi.FvbOutputs), C.c_int32, C.c_void_p]
+    cb = PROGRESS_CB(progress_cb) if progress_cb else None
+    _check(L.fabber_vb_run_spatial_host(C.byref(cfg), C.byref(spatial.sp), data.ctypes.data, C.byref(out), device,
+                                        C.cast(cb, C.c_void_p) if cb else None))
+    arrs["setup_failed"] = (arrs["status"] & 0x100) != 0
+    arrs["status"] = arrs["status"] & 0xFF
+    return arrs
+
+
+def neighbours(coords, spatial_dims=3):
+    """First-neighbour table of the spatial driver (host code, no GPU): [V][6], -1 = none."""
+    coords = np.ascontiguousarray(coords, dtype=np.int32)
+    V = coords.shape[1]
+    nn = np.full((V, 6), -1, dtype=np.int32)
+    L = lib()
+    L.fabber_vb_neighbours.restype = C.c_int32
+    L.fabber_vb_neighbours.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    _check(L.fabber_vb_neighbours(coords.ctypes.data, V, spatial_dims, nn.ctypes.data))
+    return nn

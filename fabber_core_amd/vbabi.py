@@ -280,3 +280,37 @@ def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps
         keep["init_mvn"] = init_mvn
         cfg.init_mvn = init_mvn.ctypes.data
     return ConfigHolder(cfg, params, keep)
+
+
+# ---- spatial VB (include/fabber_vb.h: fvb_spatial) --------------------------------------------
+class FvbSpatial(C.Structure):
+    _fields_ = [
+        ("coords", C.c_void_p),
+        ("spatial_dims", C.c_int32),
+        ("update_first_iter", C.c_int32),
+        ("spatial_speed", C.c_double),
+        ("q1", C.c_double),
+        ("q2", C.c_double),
+    ]
+
+
+def grid_coords(shape, mask=None):
+    """[3][V] int32 grid coordinates of the masked voxels, x fastest then y then z
+    (rundata_array.cc:42-63)."""
+    nx, ny, nz = shape
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    keep = np.ones(nx * ny * nz, dtype=bool) if mask is None else (np.asarray(mask).transpose(2, 1, 0).ravel() != 0)
+    return np.ascontiguousarray(np.stack([x.ravel()[keep], y.ravel()[keep], z.ravel()[keep]]).astype(np.int32))
+
+
+class SpatialHolder:
+    def __init__(self, coords, spatial_dims=3, spatial_speed=-1.0, q1=10.0, q2=1.0, update_first_iter=False):
+        self.coords = np.ascontiguousarray(coords, dtype=np.int32)
+        assert self.coords.ndim == 2 and self.coords.shape[0] == 3
+        self.sp = FvbSpatial()
+        self.sp.coords = self.coords.ctypes.data
+        self.sp.spatial_dims = spatial_dims
+        self.sp.update_first_iter = int(update_first_iter)
+        self.sp.spatial_speed = spatial_speed
+        self.sp.q1 = q1
+        self.sp.q2 = q2

@@ -219,6 +219,32 @@ int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const
 int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const double *mvn,
     const fvb_postproc *pp, int32_t device);
 
+/*
+ * Spatial VB (Vb::DoCalculationsSpatial, inference_vb.cc:578-767; SpatialPrior, priors.cc:183-488;
+ * Vb::CalcNeighbours, inference_vb.cc:830-964). Selected by method=spatialvb or by any prior of
+ * type M, m, P, p. White noise only.
+ */
+typedef struct fvb_spatial
+{
+    const int32_t *coords;   /* [3][n_voxels] 0-based grid coordinates (x row, y row, z row), voxels
+                                ordered x fastest then y then z (inference_vb.cc:769-793). HOST pointer
+                                in every entry point: the neighbour lists and the sweep order are built
+                                on the host. */
+    int32_t spatial_dims;    /* 0..3, option spatial-dims (default 3) */
+    int32_t update_first_iter; /* option update-spatial-prior-on-first-iteration */
+    double spatial_speed;    /* option spatial-speed (default -1 = unlimited) */
+    double q1, q2;           /* options spatial-q1 (10), spatial-q2 (1) */
+} fvb_spatial;
+
+/* Same conventions as fabber_vb_run_device / fabber_vb_run_host. The iteration count is
+ * cfg->max_iterations (the spatial loop always uses the counting detector, inference_vb.cc:599).
+ * progress_cb (may be NULL) is called once per iteration with (iteration, max_iterations) as the
+ * reference does (inference_vb.cc:610). */
+int32_t fabber_vb_run_spatial_device(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
+    const fvb_outputs *out, void *stream, void (*progress_cb)(int, int));
+int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
+    const fvb_outputs *out, int32_t device, void (*progress_cb)(int, int));
+
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);
 

@@ -1194,6 +1194,7 @@ static inline double load_data(const fvb_config *cfg, const void *data, size_t i
 }
 
 #include "vb_oracle_ar.inc"
+#include "vb_oracle_spatial.inc"
 
 } // namespace
 
@@ -1441,6 +1442,54 @@ int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double
                     pp->residuals[(size_t)t * V + v] = model.data[t] - fit[t];
             }
         }
+    }
+    return 0;
+}
+
+// Vb::DoCalculationsSpatial. Returns 0, or < 0 with the exception text in oracle_last_error().
+static std::string g_oracle_error;
+int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out)
+{
+    if (cfg->abi_version != FVB_ABI_VERSION || cfg->noise != FVB_NOISE_WHITE)
+        return -1;
+    try
+    {
+        return run_spatial(cfg, sp, data, out);
+    }
+    catch (std::exception &e)
+    {
+        g_oracle_error = e.what();
+        return -10;
+    }
+}
+const char *oracle_last_error(void)
+{
+    return g_oracle_error.c_str();
+}
+
+// Neighbour lists as Vb::CalcNeighbours builds them: for voxel v (0-based) up to 6 first
+// neighbours into nn[v*6..] (1-based ids, 0 = none) and the number of second neighbours (with
+// duplicates) into n2count[v]; second neighbours themselves into nn2[v*30..].
+int32_t oracle_calc_neighbours(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t *nn,
+    int32_t *nn2, int32_t *n2count)
+{
+    SpatialCtx ctx;
+    try
+    {
+        calc_neighbours(coords, n_voxels, spatial_dims, ctx);
+    }
+    catch (std::exception &e)
+    {
+        g_oracle_error = e.what();
+        return -10;
+    }
+    for (int v = 0; v < n_voxels; v++)
+    {
+        for (int i = 0; i < 6; i++)
+            nn[v * 6 + i] = i < (int)ctx.neighbours[v].size() ? ctx.neighbours[v][i] : 0;
+        n2count[v] = (int)ctx.neighbours2[v].size();
+        for (int i = 0; i < 30; i++)
+            nn2[v * 30 + i] = i < (int)ctx.neighbours2[v].size() ? ctx.neighbours2[v][i] : 0;
     }
     return 0;
 }

@@ -44,6 +44,14 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
 int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double *mvn,
     const fvb_postproc *pp);
 
+/* Vb::DoCalculationsSpatial (inference_vb.cc:578-767), white noise; host pointers. */
+int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out);
+const char *oracle_last_error(void);
+/* Vb::CalcNeighbours (inference_vb.cc:830-964): nn [n_voxels][6], nn2 [n_voxels][30] 1-based ids
+ * (0 = none), n2count [n_voxels]. */
+int32_t oracle_calc_neighbours(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t *nn,
+    int32_t *nn2, int32_t *n2count);
+
 /* Scalar helpers exposed for unit tests. */
 double oracle_gammaln(double x);   /* tools.cc:87-98 */
 double oracle_digamma(double x);   /* MISCMATHS::digamma restated in fp64 */

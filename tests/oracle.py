@@ -168,3 +168,40 @@ def convergence_trace(conv, F, max_iterations=10, max_trials=10, min_fchange=0.0
                                        done.ctypes.data, save.ctypes.data, revert.ctypes.data, alpha.ctypes.data,
                                        int(stop_at_done))
     return done[:m].astype(bool), save[:m].astype(bool), revert[:m].astype(bool), alpha[:m]
+
+
+def run_spatial(holder, spatial, data, _lib=None):
+    """Spatial VB oracle. spatial: vbabi.SpatialHolder."""
+    cfg = holder.cfg
+    data = prepare_data(holder, data)
+    arrs, out = alloc_outputs(holder)
+    L = _lib or lib()
+    L.oracle_vb_run_spatial.restype = C.c_int32
+    L.oracle_vb_run_spatial.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbSpatial), C.c_void_p,
+                                        C.POINTER(vbabi.FvbOutputs)]
+    L.oracle_last_error.restype = C.c_char_p
+    rc = L.oracle_vb_run_spatial(C.byref(cfg), C.byref(spatial.sp), data.ctypes.data, C.byref(out))
+    if rc != 0:
+        raise RuntimeError("oracle_vb_run_spatial failed: %d %s" % (rc, L.oracle_last_error().decode()))
+    return arrs
+
+
+def run_spatial_fma(holder, spatial, data):
+    return run_spatial(holder, spatial, data, _lib=lib_fma())
+
+
+def calc_neighbours(coords, spatial_dims=3):
+    """Reference neighbour lists: (nn [V][6], nn2 [V][30], n2count [V]) with 1-based ids."""
+    coords = np.ascontiguousarray(coords, dtype=np.int32)
+    V = coords.shape[1]
+    nn = np.zeros((V, 6), dtype=np.int32)
+    nn2 = np.zeros((V, 30), dtype=np.int32)
+    n2c = np.zeros(V, dtype=np.int32)
+    L = lib()
+    L.oracle_calc_neighbours.restype = C.c_int32
+    L.oracle_calc_neighbours.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_last_error.restype = C.c_char_p
+    rc = L.oracle_calc_neighbours(coords.ctypes.data, V, spatial_dims, nn.ctypes.data, nn2.ctypes.data, n2c.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(L.oracle_last_error().decode())
+    return nn, nn2, n2c

@@ -158,7 +158,43 @@ def run_poly(data, degree, mask=None, extra=None, **options):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["vb"])
+def test_spatial_priors_through_the_c_abi():
+    """method=spatialvb with param-spatial-priors / PSP_byname types (test_inference.cc runs every
+    case for vb and spatialvb; test_priors.cc grammar): same numbers as the engine called directly
+    on the masked voxels, one progress call per spatial iteration (inference_vb.cc:610)."""
+    rng = np.random.default_rng(11)
+    shape, T = (9, 8, 5), 50
+    t = np.arange(T) * 0.04
+    gx = np.arange(shape[0])[:, None, None]
+    amp = 1.0 + 0.3 * np.sin(gx / 2.0) + np.zeros(shape)
+    data = (amp[..., None] * np.exp(-t) + rng.normal(0, 0.1, shape + (T,))).astype(np.float32)
+    mask = rng.random(shape) < 0.85
+    opts = {"model": "exp", "dt": 0.04, "noise": "white", "method": "spatialvb", "max-iterations": 6, "save-mean": True,
+            "save-mvn": True, "param-spatial-priors": "MN", "save-free-energy": True}
+    calls = []
+    out = fabber.run(data, opts, mask=mask, progress_cb=lambda i, n: calls.append((i, n)))
+    assert [c for c in calls if c[1] == 6] == [(i, 6) for i in range(6)]
+    sel = mask.transpose(2, 1, 0).ravel()
+    y = data.transpose(3, 2, 1, 0).reshape(T, -1)[:, sel].astype(np.float64)
+    h = vbabi.build_config(vbabi.MODEL_EXP, int(mask.sum()), T, num_exps=1, dt=0.04, max_iterations=6, need_f=True,
+                           param_overrides={"amp1": dict(type="M")})
+    direct = hiplib.run_spatial_host(h, vbabi.SpatialHolder(vbabi.grid_coords(shape, mask)), y)
+    got = out["finalMVN"].transpose(3, 2, 1, 0).reshape(10, -1)[:, sel]
+    assert np.allclose(got, direct["mvn"].astype(np.float32), rtol=1e-6, atol=0)
+    F = out["freeEnergy"].transpose(2, 1, 0).ravel()[sel]
+    assert np.allclose(F, direct["free_energy"], rtol=1e-6)
+    # the same prior chosen by name, without method=spatialvb: Vb::IsSpatial switches loops
+    byname = dict(opts, method="vb", PSP_byname1="amp1", PSP_byname1_type="M")
+    del byname["param-spatial-priors"]
+    out2 = fabber.run(data, byname, mask=mask)
+    assert np.array_equal(out2["finalMVN"], out["finalMVN"])
+    # and it differs from the voxelwise answer
+    plain = fabber.run(data, dict(byname, PSP_byname1_type="N"), mask=mask)
+    assert not np.allclose(plain["mean_amp1"], out["mean_amp1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vb", "spatialvb"])
 def test_constant_and_alternating_data(method):
     """test_inference.cc:108-238"""
     out = run_poly(volume((5, 5, 5), [VAL] * 10), 0, method=method)

@@ -1,0 +1,175 @@
+"""Spatial VB (Vb::DoCalculationsSpatial, SpatialPrior, Vb::CalcNeighbours): oracle pinned on CPU,
+HIP path against the oracle on the GPU. BASELINE config 5 model: bi-exponential + MRF prior (type
+M) on a parameter; here at oracle-sized volumes with irregular masks."""
+import numpy as np
+import pytest
+
+import golden_utils as gu
+import oracle
+import parity
+from fabber_core_amd import hiplib, vbabi
+
+gpu = pytest.mark.gpu
+needs_lib = pytest.mark.skipif(not hiplib.available(), reason="libfabber_vb_hip.so not built")
+
+
+def masked_volume(shape, seed, keep=0.85):
+    rng = np.random.default_rng(seed)
+    mask = rng.random(shape) < keep
+    return mask, vbabi.grid_coords(shape, mask)
+
+
+def smooth_exp_data(coords, T, dt, seed, noise_sd=0.1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) * dt
+    amp = 1.0 + 0.3 * np.sin(coords[0] / 3.0) * np.cos(coords[1] / 4.0) + 0.1 * np.sin(coords[2] / 2.0)
+    return amp, amp[None, :] * np.exp(-1.0 * t[:, None]) + rng.normal(0, noise_sd, (T, coords.shape[1]))
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU
+# ---------------------------------------------------------------------------------------------
+def test_neighbour_lists_on_a_full_grid():
+    """3x3x3 block: corner 3, edge 4, face 5, centre 6 first neighbours; second neighbours with
+    duplicates excluding the voxel itself (inference_vb.cc:830-964)."""
+    coords = vbabi.grid_coords((3, 3, 3))
+    nn, nn2, n2c = oracle.calc_neighbours(coords)
+    counts = (nn > 0).sum(axis=1)
+    assert sorted(np.bincount(counts)[3:].tolist()) == sorted([8, 12, 6, 1])
+    centre = 13
+    assert counts[centre] == 6 and set(nn[centre]) == {15, 13, 17, 11, 23, 5}
+    assert list(nn[0][:3]) == [2, 4, 10]          # +x, +y, +z in the reference's order (1-based)
+    assert n2c[centre] == 6 * 4                   # each face voxel has 4 other neighbours
+    # 2D: no z neighbours
+    nn2d, _, _ = oracle.calc_neighbours(coords, spatial_dims=2)
+    assert (nn2d[centre] > 0).sum() == 4
+
+
+def test_no_wrap_around_between_rows():
+    """The last voxel of a row and the first of the next have consecutive offsets but are not
+    neighbours (wrap-around test, inference_vb.cc:906-925)."""
+    coords = vbabi.grid_coords((4, 3, 1))
+    nn, _, _ = oracle.calc_neighbours(coords)
+    assert 5 not in nn[3]  # voxel 4 (x=3,y=0) vs voxel 5 (x=0,y=1)
+    assert set(nn[3][nn[3] > 0]) == {3, 8}
+
+
+def test_misordered_coordinates_are_rejected():
+    coords = vbabi.grid_coords((3, 3, 1))[:, ::-1].copy()
+    with pytest.raises(RuntimeError, match="correct order"):
+        oracle.calc_neighbours(coords)
+
+
+@needs_lib
+@pytest.mark.parametrize("dims", [3, 2, 1])
+def test_driver_neighbour_table_matches_reference(dims):
+    mask, coords = masked_volume((9, 7, 5), seed=dims)
+    ref, _, _ = oracle.calc_neighbours(coords, dims)
+    got = hiplib.neighbours(coords, dims)
+    assert np.array_equal(got + 1, ref)  # same neighbours in the same order (reference is 1-based, 0 = none)
+
+
+def test_oracle_spatial_loop_reproduces_reference_spatialvb_output():
+    """test/outdata_linear_spatialvb (method=spatialvb, all-N priors): the spatial loop's fixed
+    point, replayed from data with the same sufficient statistics."""
+    ref = gu.load_reference_outdata()
+    J, mvn = ref["linear_design"], ref["linear_spatialvb/finalMVN"].astype(np.float64)
+    cov, means = gu.unpack(mvn, 5)
+    y = gu.data_with_same_sufficient_statistics(J, cov, means)
+    idx, (nx, ny, nz) = ref["mask_index"], [int(s) for s in ref["mask_shape"]]
+    coords = np.stack([idx % nx, (idx // nx) % ny, idx // (nx * ny)]).astype(np.int32)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, 147, 106, design=J)
+    r = oracle.run_spatial(h, vbabi.SpatialHolder(coords), y)
+    gc, gm = gu.unpack(r["mvn"], 5)
+    sd = np.sqrt(np.einsum("vii->vi", cov))
+    assert np.max(np.abs(gm - means) / np.maximum(sd, np.abs(means))) < 1e-5
+    assert np.max(np.abs(gc - cov) / (sd[:, :, None] * sd[:, None, :])) < 1e-5
+
+
+@pytest.mark.parametrize("typ", ["M", "m", "P", "p"])
+def test_oracle_spatial_prior_smooths(typ):
+    mask, coords = masked_volume((8, 7, 6), seed=0)
+    V = coords.shape[1]
+    amp, y = smooth_exp_data(coords, 50, 0.04, seed=1)
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=10, param_overrides={"amp1": dict(type=typ)})
+    r = oracle.run_spatial(h, vbabi.SpatialHolder(coords), y)
+    hv = vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=10)
+    rv = oracle.run(hv, y)
+    rmse = lambda res: np.sqrt(np.mean((np.exp(res["mvn"][6]) - amp) ** 2))
+    assert np.isfinite(r["mvn"]).all()
+    assert rmse(r) < 0.95 * rmse(rv)
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------
+def spatial_check(h, sp, y, what, **kw):
+    cpu = oracle.run_spatial(h, sp, y)
+    got = hiplib.run_spatial_host(h, sp, y)
+    cpu2 = oracle.run_spatial_fma(h, sp, y)
+    for r in (cpu, cpu2):
+        r.setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
+    return parity.strict(h, cpu, got, what=what, cpu2=cpu2, **kw)
+
+
+@gpu
+@pytest.mark.parametrize("typ", ["M", "m", "P", "p"])
+def test_spatial_prior_types_single_exponential(typ):
+    mask, coords = masked_volume((11, 9, 7), seed=3)
+    V = coords.shape[1]
+    _, y = smooth_exp_data(coords, 50, 0.04, seed=4)
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=8, param_overrides={"amp1": dict(type=typ)})
+    spatial_check(h, vbabi.SpatialHolder(coords), y, "spatial " + typ)
+
+
+@gpu
+def test_spatial_options_dims_speed_first_iteration_and_free_energy():
+    mask, coords = masked_volume((10, 8, 6), seed=5)
+    V = coords.shape[1]
+    rng = np.random.default_rng(6)
+    t = np.arange(1, 21.0)
+    c0 = 2.0 + np.sin(coords[0] / 2.0)
+    y = c0[None, :] + 0.3 * t[:, None] + rng.normal(0, 0.2, (20, V))
+    h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=1, max_iterations=6, need_f=True,
+                           param_overrides={"c0": dict(type="M"), "c1": dict(type="A")})
+    spatial_check(h, vbabi.SpatialHolder(coords, spatial_dims=2, update_first_iter=True), y, "dims2+first-iter+ARD", check_f=True)
+    h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=1, max_iterations=6,
+                           param_overrides={"c0": dict(type="P"), "c1": dict(type="m")})
+    spatial_check(h, vbabi.SpatialHolder(coords, spatial_speed=1.5, q1=5.0, q2=2.0), y, "speed+q1q2, two spatial params")
+
+
+@gpu
+def test_spatialvb_method_with_nonspatial_priors_reproduces_reference_output():
+    ref = gu.load_reference_outdata()
+    J, mvn = ref["linear_design"], ref["linear_spatialvb/finalMVN"].astype(np.float64)
+    cov, means = gu.unpack(mvn, 5)
+    y = gu.data_with_same_sufficient_statistics(J, cov, means)
+    idx, (nx, ny, nz) = ref["mask_index"], [int(s) for s in ref["mask_shape"]]
+    coords = np.stack([idx % nx, (idx // nx) % ny, idx // (nx * ny)]).astype(np.int32)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, 147, 106, design=J)
+    r = hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), y)
+    gc, gm = gu.unpack(r["mvn"], 5)
+    sd = np.sqrt(np.einsum("vii->vi", cov))
+    assert np.all(r["status"] == 0)
+    assert np.max(np.abs(gm - means) / np.maximum(sd, np.abs(means))) < 1e-3
+    assert np.max(np.abs(gc - cov) / (sd[:, :, None] * sd[:, None, :])) < 1e-3
+
+
+@gpu
+def test_c5_biexponential_mrf_population():
+    """BASELINE config 5 model on a 16x14x12 masked block: bi-exponential with an MRF prior (M) on
+    amp1. The bi-exponential fit is chaotic per voxel, so population parity."""
+    mask, coords = masked_volume((16, 14, 12), seed=7, keep=0.9)
+    V = coords.shape[1]
+    rng = np.random.default_rng(8)
+    t = np.arange(100) * 0.02
+    amp1 = 0.75 + 0.25 * np.sin(coords[0] / 4.0) * np.cos(coords[2] / 3.0)
+    y = amp1[None, :] * np.exp(-1.0 * t[:, None]) + 0.5 * np.exp(-6.0 * t[:, None]) + rng.normal(0, 0.1, (100, V))
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 100, num_exps=2, dt=0.02, max_iterations=10, param_overrides={"amp1": dict(type="M")})
+    sp = vbabi.SpatialHolder(coords)
+    cpu, cpu2, got = oracle.run_spatial(h, sp, y), oracle.run_spatial_fma(h, sp, y), hiplib.run_spatial_host(h, sp, y)
+    floor = parity.population_stats(h, cpu, cpu2)
+    parity.population(h, cpu, got, floor, what="C5")
+    calls = []
+    hiplib.run_spatial_host(h, sp, y, progress_cb=lambda i, n: calls.append((i, n)))
+    assert calls == [(i, 10) for i in range(10)]
