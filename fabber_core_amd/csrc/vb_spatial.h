@@ -302,15 +302,19 @@ __global__ void vb_spatial_ak_final_kernel(const SpatialArgs sa)
 }
 
 // ---- first sweep, one level: priors + UpdateTheta (inference_vb.cc:614-672) -------------------
+// There are hundreds of these launches per iteration, so the (large) argument block stays in
+// device memory and only the level range travels with the launch.
 template <int P>
-__global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs sa)
+__global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs *__restrict__ sap, int level_begin,
+    int level_count, int it)
 {
     typedef SpLayout<P> L;
+    const SpatialArgs &sa = *sap;
     const KernelArgs &ka = sa.ka;
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= sa.level_count)
+    if (i >= level_count)
         return;
-    const int v = sa.order[sa.level_begin + i];
+    const int v = sa.order[level_begin + i];
     const size_t V = (size_t)ka.cfg.n_voxels;
     if (sa.status[v] != 0)
         return;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
         else if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
             const double new_cov = st.m[k] * st.m[k] + st.Sig[tri(k, k)];
-            if (sa.it == 0)
+            if (it == 0)
             {
                 st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
                 st.pm[k] = ka.cfg.prior_mean[k];
@@ -496,9 +500,12 @@ __global__ __launch_bounds__(256) void vb_spatial_pack_kernel(const SpatialArgs 
 
 // Kernel table for one (model, P)
 typedef void (*SpatialKernelFn)(const SpatialArgs);
+typedef void (*SpatialThetaFn)(const SpatialArgs *, int, int, int);
 struct SpatialKernels
 {
-    SpatialKernelFn setup, ak_partial, ak_final, theta, noise, pack;
+    SpatialKernelFn setup, ak_partial, ak_final;
+    SpatialThetaFn theta;
+    SpatialKernelFn noise, pack;
     int state_rows;
     const char *name;
 };

@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,13 +63,62 @@ std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector
         offsets[v] = (long long)Z[v] * xsize * ysize + (long long)Y[v] * xsize + X[v];
     const long long delta[6] = { 1, -1, xsize, -xsize, (long long)xsize * ysize, -(long long)xsize * ysize };
     const int max_delta = dims * 2 - 1;
+    // The reference finds "the voxel at offset pos + delta" by binary search in the (sorted)
+    // offsets. For a mask that fills a fair share of its bounding box the same question is one
+    // look-up in a dense offset -> voxel map; the search is kept for sparse / odd geometries.
+    const long long span = offsets[V - 1] - offsets[0] + 1;
+    std::vector<int32_t> dense;
+    if (span > 0 && span <= std::max<long long>(64LL * V, 1 << 20))
+    {
+        dense.assign((size_t)span, -1);
+        for (int v = 0; v < V; v++)
+            dense[(size_t)(offsets[v] - offsets[0])] = v;
+    }
+    auto find = [&](long long target) -> int {
+        if (!dense.empty())
+        {
+            const long long rel = target - offsets[0];
+            return (rel < 0 || rel >= span) ? -1 : dense[(size_t)rel];
+        }
+        auto it = std::lower_bound(offsets.begin(), offsets.end(), target);
+        return (it == offsets.end() || *it != target) ? -1 : (int)(it - offsets.begin());
+    };
+    bool non_negative = true;
+    for (int v = 0; v < V && non_negative; v++)
+        non_negative = X[v] >= 0 && Y[v] >= 0 && Z[v] >= 0;
+    if (non_negative && !dense.empty())
+    {
+        // With non-negative co-ordinates pos % xsize == x and pos % (xsize ysize) == y xsize + x,
+        // so the four wrap-around tests (:906-925) read "x is on the last/first column" and "y is
+        // on the last/first row"; and every relation found this way is mutual by construction
+        // (the voxel found at pos + delta finds this one at its pos - delta), which is what the
+        // reference verifies at :958-962.
+        const long long base = offsets[0];
+        for (int v = 0; v < V; v++)
+        {
+            const bool ok[6] = { X[v] < xsize - 1, X[v] > 0, Y[v] < ysize - 1, Y[v] > 0, true, true };
+            const long long rel0 = offsets[v] - base;
+            int32_t *row = &nn[(size_t)v * 6];
+            int slot = 0;
+            for (int n = 0; n <= max_delta; n++)
+            {
+                const long long rel = rel0 + delta[n];
+                if (!ok[n] || rel < 0 || rel >= span)
+                    continue;
+                const int32_t found = dense[(size_t)rel];
+                if (found >= 0)
+                    row[slot++] = found;
+            }
+        }
+        return "";
+    }
     for (int v = 0; v < V; v++)
     {
         const long long pos = offsets[v];
         for (int n = 0; n <= max_delta; n++)
         {
-            auto it = std::lower_bound(offsets.begin(), offsets.end(), pos + delta[n]);
-            if (it == offsets.end() || *it != pos + delta[n])
+            const int found = find(pos + delta[n]);
+            if (found < 0)
                 continue;
             if (n < 4) // wrap-around test, :906-925
             {
@@ -91,7 +143,7 @@ std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector
             int slot = 0;
             while (row[slot] >= 0)
                 slot++;
-            row[slot] = (int32_t)(it - offsets.begin());
+            row[slot] = (int32_t)found;
         }
     }
     // every neighbour relation must be mutual (:958-962)
@@ -146,23 +198,62 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
         return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
 
     // ---- host-side geometry ----
+    const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_start = now();
     std::vector<int32_t> nn;
     std::string err = build_neighbours(sp->coords, V, sp->spatial_dims, nn);
     if (!err.empty())
         return api_fail(-41, err);
     const int32_t *X = sp->coords, *Y = sp->coords + V, *Z = sp->coords + 2 * (size_t)V;
+    // Level function a x + b y + c z: a stencil offset that leads to a smaller voxel index must
+    // lower the level, one that leads to a larger index must raise it. First neighbours only
+    // (types M, m): (1,1,1). Second neighbours too (types P, p read neighbours of neighbours, e.g.
+    // (x+1, y-1) which has a smaller index): b > a and c > b, so (1,2,3).
+    bool second_neighbours = false;
+    for (int kk = 0; kk < P; kk++)
+        second_neighbours |= (cfg->prior_type[kk] == FVB_PRIOR_SPATIAL_P || cfg->prior_type[kk] == FVB_PRIOR_SPATIAL_p);
+    const long long cy = second_neighbours ? 2 : 1, cz = second_neighbours ? 3 : 1;
     std::vector<long long> level(V);
+    long long lmin = 0, lmax = 0;
     for (int v = 0; v < V; v++)
-        level[v] = (long long)X[v] + 2LL * Y[v] + 4LL * Z[v];
-    std::vector<int32_t> order(V);
-    for (int v = 0; v < V; v++)
-        order[v] = v;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
-    std::vector<int32_t> level_begin;
-    for (int i = 0; i < V; i++)
-        if (i == 0 || level[order[i]] != level[order[i - 1]])
-            level_begin.push_back(i);
-    level_begin.push_back(V);
+    {
+        level[v] = (long long)X[v] + cy * Y[v] + cz * Z[v];
+        lmin = (v == 0 || level[v] < lmin) ? level[v] : lmin;
+        lmax = (v == 0 || level[v] > lmax) ? level[v] : lmax;
+    }
+    std::vector<int32_t> order(V), level_begin;
+    if (lmax - lmin < (1LL << 24))
+    {
+        // counting sort (stable: voxels of a level stay in index order)
+        const size_t nl = (size_t)(lmax - lmin + 1);
+        std::vector<int32_t> start(nl + 1, 0);
+        for (int v = 0; v < V; v++)
+            start[(size_t)(level[v] - lmin) + 1]++;
+        for (size_t l = 0; l < nl; l++)
+            start[l + 1] += start[l];
+        for (size_t l = 0; l < nl; l++)
+            if (start[l + 1] > start[l])
+                level_begin.push_back(start[l]);
+        level_begin.push_back(V);
+        for (int v = 0; v < V; v++)
+            order[start[(size_t)(level[v] - lmin)]++] = v;
+    }
+    else
+    {
+        for (int v = 0; v < V; v++)
+            order[v] = v;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
+        for (int i = 0; i < V; i++)
+            if (i == 0 || level[order[i]] != level[order[i - 1]])
+                level_begin.push_back(i);
+        level_begin.push_back(V);
+    }
+
+    const auto t_geom = now();
 
     // ---- device memory ----
     const int n_blocks = std::max(1, std::min(1024, (V + 255) / 256));
@@ -219,6 +310,13 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
         }
         sa.ka.n_unmasked = n_unmasked;
 
+        DevMem d_sa; // the argument block the per-level launches read (nothing in it changes per launch)
+        FVB_HIP_CHECK(d_sa.alloc(sizeof(SpatialArgs)));
+        FVB_HIP_CHECK(hipMemcpyAsync(d_sa.p, &sa, sizeof(SpatialArgs), hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // `sa` is pageable host memory and is modified below
+        const SpatialArgs *sap = (const SpatialArgs *)d_sa.p;
+
+        const auto t_alloc = now();
         const unsigned grid64 = (unsigned)((V + 63) / 64), grid256 = (unsigned)((V + 255) / 256);
         hipLaunchKernelGGL(k.setup, dim3(grid64), dim3(64), 0, stream, sa);
         FVB_HIP_CHECK(hipGetLastError());
@@ -237,9 +335,8 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
             }
             for (size_t l = 0; l + 1 < level_begin.size(); l++)
             {
-                sa.level_begin = level_begin[l];
-                sa.level_count = level_begin[l + 1] - level_begin[l];
-                hipLaunchKernelGGL(k.theta, dim3((unsigned)((sa.level_count + 63) / 64)), dim3(64), 0, stream, sa);
+                const int begin = level_begin[l], count = level_begin[l + 1] - level_begin[l];
+                hipLaunchKernelGGL(k.theta, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, sap, begin, count, it);
             }
             hipLaunchKernelGGL(k.noise, dim3(grid64), dim3(64), 0, stream, sa);
             FVB_HIP_CHECK(hipGetLastError());
@@ -247,7 +344,11 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
         sa.it = cfg->max_iterations;
         hipLaunchKernelGGL(k.pack, dim3(grid256), dim3(256), 0, stream, sa);
         FVB_HIP_CHECK(hipGetLastError());
+        const auto t_enq = now();
         FVB_HIP_CHECK(hipStreamSynchronize(stream)); // the DevMem buffers are freed on return
+        if (timing)
+            fprintf(stderr, "[fvb spatial] V=%d levels=%zu: geometry %.1f ms, alloc+upload %.1f ms, enqueue %.1f ms, drain %.1f ms\n", V,
+                level_begin.size() - 1, ms(t_start, t_geom), ms(t_geom, t_alloc), ms(t_alloc, t_enq), ms(t_enq, now()));
     }
     return 0;
 }

@@ -67,6 +67,20 @@ class DeviceProblem:
         if rc != 0:
             raise hiplib.HipEngineError("fabber_vb_run_device_ex: %d %s" % (rc, hiplib.lib().fabber_vb_last_error().decode()))
 
+    def run_spatial(self, spatial, stream=None):
+        """One complete spatial VB run (all max_iterations sweeps) on `stream`; returns after the
+        stream has drained (the driver frees its work buffers on return). spatial: SpatialHolder."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        L = hiplib.lib()
+        L.fabber_vb_run_spatial_device.restype = C.c_int32
+        L.fabber_vb_run_spatial_device.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbSpatial), C.c_void_p,
+                                                   C.POINTER(vbabi.FvbOutputs), C.c_void_p, C.c_void_p]
+        rc = L.fabber_vb_run_spatial_device(C.byref(self.cfg), C.byref(spatial.sp), self.data.data_ptr(), C.byref(self.out),
+                                            C.c_void_p(stream.cuda_stream), None)
+        if rc != 0:
+            raise hiplib.HipEngineError("fabber_vb_run_spatial_device: %d %s" % (rc, L.fabber_vb_last_error().decode()))
+
     def results(self):
         torch.cuda.synchronize(self.device)
         st = self.status.cpu().numpy()

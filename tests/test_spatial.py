@@ -69,6 +69,28 @@ def test_driver_neighbour_table_matches_reference(dims):
     assert np.array_equal(got + 1, ref)  # same neighbours in the same order (reference is 1-based, 0 = none)
 
 
+@needs_lib
+def test_driver_neighbour_table_sparse_and_large_geometries():
+    """The driver answers 'which voxel sits at offset pos + delta' from a dense map when the mask
+    fills its bounding box reasonably and by the reference's binary search otherwise."""
+    rng = np.random.default_rng(0)
+    # a few small blobs scattered through a 400^3 box: bounding span >> 64 V -> binary search
+    pts = set()
+    for cx, cy, cz in rng.integers(5, 395, (6, 3)):
+        for dx, dy, dz in np.ndindex(3, 3, 3):
+            if rng.random() < 0.8:
+                pts.add((int(cx + dx), int(cy + dy), int(cz + dz)))
+    pts = sorted(pts, key=lambda p: (p[2], p[1], p[0]))
+    coords = np.array(pts, dtype=np.int32).T.copy()
+    ref, _, _ = oracle.calc_neighbours(coords, 3)
+    assert np.array_equal(hiplib.neighbours(coords, 3) + 1, ref)
+    assert (ref > 0).sum() > 100
+    # a full 40^3 block through the dense map
+    coords = vbabi.grid_coords((40, 40, 40))
+    ref, _, _ = oracle.calc_neighbours(coords, 3)
+    assert np.array_equal(hiplib.neighbours(coords, 3) + 1, ref)
+
+
 def test_oracle_spatial_loop_reproduces_reference_spatialvb_output():
     """test/outdata_linear_spatialvb (method=spatialvb, all-N priors): the spatial loop's fixed
     point, replayed from data with the same sufficient statistics."""
