@@ -83,9 +83,18 @@ int validate(const fvb_config *cfg, bool allow_spatial = false)
     return 0;
 }
 
+// Below this many voxels the lane kernel (V/64 wavefronts, each taking the full per-voxel latency)
+// leaves most of the 1024 SIMDs empty and the wave-per-voxel kernel (V wavefronts) finishes
+// first; measured crossovers on MI355X: ~17k voxels for the bi-exponential C3 fit, ~8k for the
+// single-exponential C2 fit (profiles/r1_lane_vs_wave.jsonl).
+constexpr int WAVE_KERNEL_BELOW_VOXELS = 8192;
+
 LaneKernelInfo select_lane(const fvb_config *cfg)
 {
     if (g_variant == 2 || cfg->n_phis != 1)
+        return LaneKernelInfo{ nullptr, 0, nullptr };
+    if (g_variant == 0 && cfg->noise == FVB_NOISE_WHITE && cfg->n_voxels < WAVE_KERNEL_BELOW_VOXELS
+        && wave_layout(cfg->n_times, cfg->n_params, cfg->n_phis).bytes <= 160 * 1024)
         return LaneKernelInfo{ nullptr, 0, nullptr };
     const bool need_f = cfg->need_f != 0;
     if (cfg->noise == FVB_NOISE_AR1)

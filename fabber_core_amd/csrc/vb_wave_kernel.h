@@ -12,9 +12,9 @@
  *     k = y - g(ml) + J (ml - m) is formed directly (noisemodel_white.cc:235) - no moment
  *     cancellation, no second pass;
  *   - the contractions over t (J'Q_iJ, J'Q_i r, r'Q_i r, k'Q_i k) put one OUTPUT ENTRY on each
- *     lane and run over t in order: the same summation order as the reference's matrix products
- *     and as the lane kernel, bit-reproducible, no shuffles needed (the entries outnumber the
- *     lanes from P = 8 up; below that the idle lanes cost nothing the wave would otherwise use);
+ *     lane, which runs over t in order (from P = 7 up the entries outnumber the lanes); with few
+ *     entries the spare lanes take contiguous chunks of the t range and the chunk sums are added
+ *     in chunk order - a fixed association, so results are reproducible run to run;
  *   - P x P work (eq 19-20, the inverse, traces) puts one matrix ENTRY on each lane; the inverse
  *     is the symmetric sweep operator in LDS, whose pivots are the D of the lane kernel's LDL^T;
  *   - scalars (noise posterior, free energy, convergence state machine) are computed redundantly
@@ -37,6 +37,7 @@ struct WaveLayout
     int T, P, N, Ps, PT, PP;
     int y, gl, r, k, J, pv, rden, A, u, s, kq, trs, cnt, b, c, m, ml, pm, pprec, rhs, Lam, Sig, W, W2;
     int sv_m, sv_Lam, sv_Sig, sv_pm, sv_pprec, sv_b, sv_c;
+    int part; // 64 partial sums of the chunked contractions
     int n_doubles;
     size_t bytes;
 };
@@ -85,6 +86,7 @@ FVB_HD WaveLayout wave_layout(int T, int P, int N)
     FVB_WL(sv_pprec, P)
     FVB_WL(sv_b, N)
     FVB_WL(sv_c, N)
+    FVB_WL(part, 64)
 #undef FVB_WL
     L.n_doubles = o;
     L.bytes = sizeof(double) * (size_t)o + sizeof(int32_t) * (size_t)T;
@@ -244,36 +246,61 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
         sh[L.r + t] = sh[L.y + t] - g;
     }
     wave_sync();
+    // One output entry per lane; with fewer than 33 entries the spare lanes split each entry's
+    // t range into C chunks whose partial sums are added in chunk order (fixed, so the result is
+    // reproducible run to run).
     const int per_phi = PT + P + 1;
-    FVB_WAVE_FOR(e, N * per_phi)
+    const int E = N * per_phi;
+    const int C = (E <= 32) ? 64 / E : 1;
+    const int chunk = (T + C - 1) / C;
+    for (int slot = cx.lane; slot < E * C; slot += 64)
     {
+        const int e = slot / C, t0 = (slot % C) * chunk;
+        const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
         const int phi = e / per_phi, q = e % per_phi;
         double acc = 0;
+        int dst;
         if (q < PT)
         {
             int a = 0;
             while ((a + 1) * (a + 2) / 2 <= q)
                 a++;
             const int b = q - a * (a + 1) / 2;
-            for (int t = 0; t < T; t++)
-                if (cx.phi[t] == phi)
-                    acc += sh[L.J + t * Ps + a] * sh[L.J + t * Ps + b];
-            sh[L.A + phi * PT + q] = acc;
+#pragma unroll 4
+            for (int t = t0; t < t1; t++)
+                acc += (cx.phi[t] == phi) ? sh[L.J + t * Ps + a] * sh[L.J + t * Ps + b] : 0.0;
+            dst = L.A + phi * PT + q;
         }
         else if (q < PT + P)
         {
             const int a = q - PT;
-            for (int t = 0; t < T; t++)
-                if (cx.phi[t] == phi)
-                    acc += sh[L.J + t * Ps + a] * sh[L.r + t];
-            sh[L.u + phi * P + a] = acc;
+#pragma unroll 4
+            for (int t = t0; t < t1; t++)
+                acc += (cx.phi[t] == phi) ? sh[L.J + t * Ps + a] * sh[L.r + t] : 0.0;
+            dst = L.u + phi * P + a;
         }
         else
         {
-            for (int t = 0; t < T; t++)
-                if (cx.phi[t] == phi)
-                    acc += sh[L.r + t] * sh[L.r + t];
-            sh[L.s + phi] = acc;
+#pragma unroll 4
+            for (int t = t0; t < t1; t++)
+                acc += (cx.phi[t] == phi) ? sh[L.r + t] * sh[L.r + t] : 0.0;
+            dst = L.s + phi;
+        }
+        if (C == 1)
+            sh[dst] = acc;
+        else
+            sh[L.part + slot] = acc;
+    }
+    if (C > 1)
+    {
+        wave_sync();
+        FVB_WAVE_FOR(e, E)
+        {
+            const int phi = e / per_phi, q = e % per_phi;
+            double acc = 0;
+            for (int c = 0; c < C; c++)
+                acc += sh[L.part + e * C + c];
+            sh[(q < PT) ? (L.A + phi * PT + q) : ((q < PT + P) ? (L.u + phi * P + q - PT) : (L.s + phi))] = acc;
         }
     }
     wave_sync();
@@ -423,27 +450,42 @@ __device__ __forceinline__ void wave_residuals(WaveCtx &cx, bool at_centre)
         }
         wave_sync();
     }
-    FVB_WAVE_FOR(e, 2 * N)
+    // entries: (k'Q_i k, tr(Sigma A_i)) per phi, each split into C chunks as in wave_recentre
+    const int E = 2 * N; // <= 16
+    const int C = 64 / E;
+    for (int slot = cx.lane; slot < E * C; slot += 64)
     {
-        const int phi = e >> 1;
+        const int e = slot / C, c = slot % C, phi = e >> 1;
         double acc = 0;
         if ((e & 1) == 0)
         {
             if (at_centre)
-                acc = sh[L.s + phi];
+                acc = (c == 0) ? sh[L.s + phi] : 0.0;
             else
-                for (int t = 0; t < T; t++)
-                    if (cx.phi[t] == phi)
-                        acc += sh[L.k + t] * sh[L.k + t];
-            sh[L.kq + phi] = acc;
+            {
+                const int chunk = (T + C - 1) / C, t0 = c * chunk;
+                const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
+#pragma unroll 4
+                for (int t = t0; t < t1; t++)
+                    acc += (cx.phi[t] == phi) ? sh[L.k + t] * sh[L.k + t] : 0.0;
+            }
         }
         else
         {
-            for (int i = 0; i < P; i++)
-                for (int j = 0; j < P; j++)
-                    acc += sh[L.Sig + i * P + j] * sh[L.A + phi * PT + tri(i, j)];
-            sh[L.trs + phi] = acc;
+            const int PP = L.PP, chunk = (PP + C - 1) / C, q0 = c * chunk;
+            const int q1 = (q0 + chunk < PP) ? q0 + chunk : PP;
+            for (int q = q0; q < q1; q++)
+                acc += sh[L.Sig + q] * sh[L.A + phi * PT + tri(q / P, q % P)];
         }
+        sh[L.part + slot] = acc;
+    }
+    wave_sync();
+    FVB_WAVE_FOR(e, E)
+    {
+        double acc = 0;
+        for (int c = 0; c < C; c++)
+            acc += sh[L.part + e * C + c];
+        sh[((e & 1) == 0 ? L.kq : L.trs) + (e >> 1)] = acc;
     }
     wave_sync();
 }

@@ -24,6 +24,11 @@ def _require_gpu():
     # Fail loudly (not skip) if the native path is not there: a silent fallback is not acceptable
     assert hiplib.available(), "libfabber_vb_hip.so is not built"
     assert hiplib.device_count() > 0, "no HIP device visible"
+    # These problems are oracle-sized, i.e. below the voxel count at which "auto" prefers the
+    # wave-per-voxel kernel (tests/test_wave_kernel.py); this module is about the lane kernels.
+    hiplib.set_variant("lane")
+    yield
+    hiplib.set_variant("auto")
 
 
 def both(h, y):

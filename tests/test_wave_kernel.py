@@ -90,6 +90,20 @@ def test_parameter_counts_without_a_lane_instantiation():
     assert np.median(e_mean) < 1e-7 and np.quantile(e_mean, 0.95) < 1e-4
 
 
+def test_automatic_choice_between_the_two_mappings():
+    hiplib.set_variant("auto")
+    small, _ = cases.exp_problem(4096, 50, 1, 0.04, seed=1)
+    large, _ = cases.exp_problem(8192, 50, 1, 0.04, seed=1)
+    assert hiplib.kernel_name(small) == "wave" and hiplib.kernel_name(large) == "lane<exp,2>"
+    # a series too long for the LDS stays on the lane kernel however few voxels there are
+    rng = np.random.default_rng(0)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, 64, 6000, design=rng.normal(0, 1, (6000, 4)))
+    assert hiplib.kernel_name(h) == "lane<linear,4>"
+    # AR(1) noise has lane kernels only
+    h, _ = cases.poly_problem(100, 20, 2, seed=1, noise=vbabi.NOISE_AR1)
+    assert hiplib.kernel_name(h).startswith("lane_ar1<")
+
+
 def test_series_too_long_for_lds_fails_loudly():
     V, T, P = 8, 4000, 16
     rng = np.random.default_rng(0)
