@@ -73,6 +73,7 @@ struct Moments
     double u[P];
     double s;
     double ml[P];
+    bool precise; // how the sweep that produced these moments evaluated the model
 };
 
 __device__ __forceinline__ double load_data(const KernelArgs &ka, size_t idx)
@@ -111,9 +112,13 @@ __device__ __forceinline__ bool ensure_prec(VoxelState<P> &st)
 // accumulations of UpdateTheta / UpdateNoise / CalcFreeEnergy. J(t,i) = (f(c + d e_i)(t) -
 // f(c - d e_i)(t)) / (c2_i - c3_i) exactly as the reference, except that the division is a
 // multiplication by the once-computed reciprocal (<= 1 ulp per Jacobian entry).
+// precise: ask the model's sweep for its most precise evaluation (vb_models.h). The kernels do
+// so for the FIRST linearisation of a run: parameters that start at a Fabber-space mean of
+// exactly 0 (log of a rate of 1) get the reference's minimum step of 1e-10 there, f2 - f3 is then
+// ~1e-10 of f, and every rounding in f shows up a million-fold in J.
 template <class Model, int P>
-__device__ __forceinline__ int recentre(
-    const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P], Moments<P> &mo)
+__device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P],
+    Moments<P> &mo, bool precise = false)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int T = ka.cfg.n_times;
@@ -148,26 +153,22 @@ __device__ __forceinline__ int recentre(
     // The sample for t+1 is requested while timepoint t is being evaluated (~200 VALU
     // instructions), so the L2 / Infinity-Cache latency of the re-read never stalls the wave.
     double y_next = load_data(ka, (size_t)v);
+    typename Model::Sweep sweep;
+    sweep.init(ma, tp, tp2, tp3);
+    sweep.set_precise(precise);
+    mo.precise = precise;
     for (int t = 0; t < T; t++)
     {
         const double y_cur = y_next;
         if (t + 1 < T)
             y_next = load_data(ka, (size_t)(t + 1) * V + v);
-        const double g = Model::eval(ma, t, tp);
-        double J[P];
+        double g, f2[P], f3[P], J[P];
+        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
             FVB_NO_CONTRACT
-            double q[P];
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                q[j] = tp[j];
-            q[i] = tp2[i];
-            const double f2 = Model::eval(ma, t, q);
-            q[i] = tp3[i];
-            const double f3 = Model::eval(ma, t, q);
-            J[i] = (f2 - f3) * rden[i];
+            J[i] = (f2[i] - f3[i]) * rden[i];
             bad_jac |= !is_finite(J[i]);
         }
         bad_offset |= !is_finite(g);
@@ -379,26 +380,22 @@ __device__ __forceinline__ double exact_residual(
     double kk = 0;
     const uint8_t *phi_index = ka.cfg.phi_index;
     double y_next = load_data(ka, (size_t)v);
+    typename Model::Sweep sweep;
+    sweep.init(ma, tp, tp2, tp3);
+    sweep.set_precise(mo.precise); // the Jacobian as the re-centre about ml computed it
     for (int t = 0; t < T; t++)
     {
         const double y_cur = y_next;
         if (t + 1 < T)
             y_next = load_data(ka, (size_t)(t + 1) * V + v);
-        const double g = Model::eval(ma, t, tp);
+        double g, f2[P], f3[P];
+        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
         double Jd = 0;
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
             FVB_NO_CONTRACT
-            double q[P];
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                q[j] = tp[j];
-            q[i] = tp2[i];
-            const double f2 = Model::eval(ma, t, q);
-            q[i] = tp3[i];
-            const double f3 = Model::eval(ma, t, q);
-            Jd += ((f2 - f3) * rden[i]) * nd[i];
+            Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
         }
         const bool unmasked = phi_index ? (phi_index[t] != 255) : true;
         if (unmasked)
@@ -630,7 +627,7 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
     bool setup_failed = false;
 
     // inference_vb.cc:235 and :443 re-centre about the same means: one pass gives both
-    status = recentre<Model, P>(ka, ma, v, st.m, mo);
+    status = recentre<Model, P>(ka, ma, v, st.m, mo, true);
     if (status != FVB_OK)
         setup_failed = true;
 

@@ -34,11 +34,47 @@ struct ModelArgs
     const double *design; // linear: [T][P] row-major
 };
 
+// A "sweep" produces, for t = 0, 1, 2, ... in order, the 2P + 1 predictions the central
+// difference needs: g = f(tp) and f2[i] / f3[i] = f(tp with entry i replaced by tp2[i] / tp3[i]).
+// The default sweep just calls Model::eval; a model may provide its own (ExpModel below) when
+// walking along t lets it share work between timepoints.
+template <class Model, int P>
+struct PointwiseSweep
+{
+    FVB_HD void init(const ModelArgs &, const double (&)[P], const double (&)[P], const double (&)[P])
+    {
+    }
+    // set_precise(true) asks for the most precise evaluation a sweep has (wave-uniform); the
+    // pointwise sweep has only one.
+    FVB_HD void set_precise(bool)
+    {
+    }
+    FVB_HD void eval(const ModelArgs &ma, int t, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P],
+        double &g, double (&f2)[P], double (&f3)[P])
+    {
+        FVB_NO_CONTRACT
+        g = Model::eval(ma, t, tp);
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            double q[P];
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                q[j] = tp[j];
+            q[i] = tp2[i];
+            f2[i] = Model::eval(ma, t, q);
+            q[i] = tp3[i];
+            f3[i] = Model::eval(ma, t, q);
+        }
+    }
+};
+
 // fwdmodel_poly.cc:62-80. The reference accumulates i^n in an int.
 template <int P>
 struct PolyModel
 {
     static constexpr int model_id = FVB_MODEL_POLY;
+    typedef PointwiseSweep<PolyModel<P>, P> Sweep;
     static FVB_HD double eval(const ModelArgs &, int t, const double (&p)[P])
     {
         FVB_NO_CONTRACT
@@ -64,6 +100,7 @@ template <int P>
 struct LinearModel
 {
     static constexpr int model_id = FVB_MODEL_LINEAR;
+    typedef PointwiseSweep<LinearModel<P>, P> Sweep;
     static FVB_HD double eval(const ModelArgs &a, int t, const double (&p)[P])
     {
         FVB_NO_CONTRACT
@@ -106,6 +143,96 @@ struct ExpModel
             means[2 * i] = data_max / (P / 2 + i);
     }
     static constexpr bool needs_data_max = true;
+
+    // The 2P + 1 parameter vectors of a central difference contain only 3 distinct rates per
+    // exponential (r, r + d, r - d), i.e. 3 P/2 distinct exp(-r t dt) per timepoint - and along
+    // t each of them is a geometric sequence. The sweep evaluates them exactly (the expression
+    // of eval above) every FVB_EXP_RESYNC timepoints and advances them by one multiplication
+    // with exp(-r dt) in between: at most FVB_EXP_RESYNC - 1 extra roundings (~1e-16 each) on a
+    // value whose own evaluation carries one. fp64 exp is ~25 of the ~30 instructions per
+    // exponential and the kernels are VALU-bound, see DESIGN.md. FVB_EXP_RESYNC = 1 is the
+    // pointwise evaluation.
+#ifndef FVB_EXP_RESYNC
+#define FVB_EXP_RESYNC 8
+#endif
+    struct Sweep
+    {
+        static constexpr int N = P / 2;
+        double e0[N], e2[N], e3[N], s0[N], s2[N], s3[N];
+        bool precise; // pointwise evaluation at every t (wave-uniform)
+        FVB_HD void init(const ModelArgs &a, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P])
+        {
+            FVB_NO_CONTRACT
+            precise = false;
+            if (FVB_EXP_RESYNC > 1)
+            {
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                {
+                    s0[i] = exp(-tp[2 * i + 1] * a.dopt0);
+                    s2[i] = exp(-tp2[2 * i + 1] * a.dopt0);
+                    s3[i] = exp(-tp3[2 * i + 1] * a.dopt0);
+                }
+            }
+        }
+        FVB_HD void set_precise(bool p)
+        {
+            precise = p;
+        }
+        FVB_HD void eval(const ModelArgs &a, int t, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P],
+            double &g, double (&f2)[P], double (&f3)[P])
+        {
+            FVB_NO_CONTRACT
+            if (FVB_EXP_RESYNC <= 1 || precise || (t % FVB_EXP_RESYNC) == 0) // wave-uniform
+            {
+                const double tt = double(t) * a.dopt0;
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                {
+                    e0[i] = exp(-tp[2 * i + 1] * tt);
+                    e2[i] = exp(-tp2[2 * i + 1] * tt);
+                    e3[i] = exp(-tp3[2 * i + 1] * tt);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                {
+                    e0[i] *= s0[i];
+                    e2[i] *= s2[i];
+                    e3[i] *= s3[i];
+                }
+            }
+            // the sums below add the terms in the order of eval(): res = 0; res += amp_j * exp_j
+            double val[N];
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                val[j] = tp[2 * j] * e0[j];
+            double res = 0;
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                res += val[j];
+            g = res;
+#pragma unroll
+            for (int i = 0; i < N; i++)
+            {
+                double a2 = 0, a3 = 0, r2 = 0, r3 = 0;
+#pragma unroll
+                for (int j = 0; j < N; j++)
+                {
+                    a2 += (j == i) ? tp2[2 * i] * e0[i] : val[j];
+                    a3 += (j == i) ? tp3[2 * i] * e0[i] : val[j];
+                    r2 += (j == i) ? tp[2 * i] * e2[i] : val[j];
+                    r3 += (j == i) ? tp[2 * i] * e3[i] : val[j];
+                }
+                f2[2 * i] = a2;
+                f3[2 * i] = a3;
+                f2[2 * i + 1] = r2;
+                f3[2 * i + 1] = r3;
+            }
+        }
+    };
 };
 
 // Runtime-P evaluation used by the generic (wave-per-voxel, post-processing) paths.

@@ -86,6 +86,7 @@ __device__ __forceinline__ void sp_load(const SpatialArgs &sa, int v, VoxelState
     st.b = p[(size_t)L::B * V];
     st.c = p[(size_t)L::C * V];
     mo.s = p[(size_t)L::S * V];
+    mo.precise = false;
     st.covValid = true;
     st.precValid = false;
 }
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_spatial_setup_
         st.pm[i] = 0;
         st.pprec[i] = 1;
     }
-    const int status = recentre<Model, P>(ka, ma, v, st.m, mo);
+    const int status = recentre<Model, P>(ka, ma, v, st.m, mo, true);
     sa.status[v] = status ? (status | 0x100) : 0;
     sp_store_theta<P>(sa, v, st);
     sp_store_noise<P>(sa, v, st, mo);

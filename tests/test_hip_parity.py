@@ -89,13 +89,17 @@ def test_c3_biexponential_single_iteration_from_identical_state(k):
         # fallback when the moment form s - 2d'u + d'Ad cancels) the 99th percentile of the
         # one-step difference to the oracle is ~1e-3 there, while the typical voxel agrees to
         # 1e-10. Thresholds: median 1e-7, 90th percentile 1e-5 over all entries, 99th
-        # percentile 5e-3 on the parameter means.
+        # percentile 5e-3 on the parameter means. In the very first iterations log r is still
+        # within 1e-5 of its initial 0, the finite-difference step sits on its 1e-10 floor and
+        # two CPU builds of the oracle already differ by more than that median (2e-7 at k = 1):
+        # the median bound is 2x that measured floor where it is higher.
         n = h1.cfg.n_params + 1
         ca, ma = oracle.unpack_mvn(a["mvn"][:, ok], n)
         cb, mb = oracle.unpack_mvn(b["mvn"][:, ok], n)
         sd = np.sqrt(np.abs(np.einsum("vii->vi", ca)))
         e_par = (np.abs(ma - mb) / np.maximum(np.abs(ma), sd))[:, :h1.cfg.n_params].max(axis=1)
-        assert np.median(e_mean) < 1e-7, np.median(e_mean)
+        floor_mean, _, _ = parity.voxel_errors(h1, a, oracle.run_fma(h1, y), ok)
+        assert np.median(e_mean) < max(1e-7, 2 * np.median(floor_mean)), (np.median(e_mean), np.median(floor_mean))
         assert np.quantile(e_mean, 0.90) < 1e-5, np.quantile(e_mean, 0.90)
         assert np.quantile(e_par, 0.99) < 5e-3, np.quantile(e_par, 0.99)
     else:
