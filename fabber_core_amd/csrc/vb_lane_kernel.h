@@ -81,6 +81,54 @@ __device__ __forceinline__ double load_data(const KernelArgs &ka, size_t idx)
     return ka.cfg.data_f64 ? ((const double *)ka.data)[idx] : (double)((const float *)ka.data)[idx];
 }
 
+// Software pipeline over a voxel's time series. At a million voxels the image (400 MB) does not
+// stay in the Infinity Cache between iterations, so every pass re-reads it from HBM (~2 us under
+// load) while one timepoint is only ~0.3 us of arithmetic: the sample for t + DEPTH is requested
+// while t is processed and travels through a shift register (DEPTH register moves per step, no
+// unrolling). Loads return in order, so the wait before using the oldest leaves DEPTH - 1 in
+// flight.
+#ifndef FVB_PREFETCH_DEPTH
+#define FVB_PREFETCH_DEPTH 2
+#endif
+struct DataPipe
+{
+    static constexpr int D = FVB_PREFETCH_DEPTH;
+    // raw bits as loaded (float -> double conversion would have to wait for the load)
+    unsigned long long q[D];
+    static __device__ __forceinline__ unsigned long long load_raw(const KernelArgs &ka, size_t idx)
+    {
+        return ka.cfg.data_f64 ? ((const unsigned long long *)ka.data)[idx]
+                               : (unsigned long long)((const unsigned int *)ka.data)[idx];
+    }
+    __device__ __forceinline__ void start(const KernelArgs &ka, int v, size_t V, int T)
+    {
+#pragma unroll
+        for (int j = 0; j < D; j++)
+            q[j] = (j < T) ? load_raw(ka, (size_t)j * V + v) : 0ull;
+    }
+    // sample t (which sits in slot j = t % D); the slot is refilled with sample t + D at once
+    __device__ __forceinline__ double take(const KernelArgs &ka, int v, size_t V, int T, int t, int j)
+    {
+        const unsigned long long raw = q[j];
+        if (t + D < T)
+            q[j] = load_raw(ka, (size_t)(t + D) * V + v);
+        return ka.cfg.data_f64 ? __longlong_as_double((long long)raw) : (double)__uint_as_float((unsigned int)raw);
+    }
+};
+
+// for (t = 0; t < T; t++) BODY(t, y_t) with the data pipeline: D copies of the body, slot j of the
+// pipe being a fixed register in copy j (a register that a load is still writing cannot be moved)
+#define FVB_FOR_EACH_TIMEPOINT(PIPE, KA, VOX, NV, NT, BODY)                                                  \
+    for (int t0_ = 0; t0_ < (NT); t0_ += DataPipe::D)                                                        \
+    {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < DataPipe::D; j_++)                                           \
+        {                                                                                                    \
+            const int t_ = t0_ + j_;                                                                         \
+            if (t_ < (NT))                                                                                   \
+                BODY(t_, (PIPE).take((KA), (VOX), (NV), (NT), t_, j_));                                      \
+        }                                                                                                    \
+    }
+
 // MVNDist::GetCovariance (dist_mvn.cc:232-265)
 template <int P>
 __device__ __forceinline__ bool ensure_cov(VoxelState<P> &st)
@@ -149,19 +197,15 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
         mo.u[i] = 0;
     mo.s = 0;
     bool bad_offset = false, bad_jac = false;
-    const uint8_t *phi_index = ka.cfg.phi_index;
-    // The sample for t+1 is requested while timepoint t is being evaluated (~200 VALU
-    // instructions), so the L2 / Infinity-Cache latency of the re-read never stalls the wave.
-    double y_next = load_data(ka, (size_t)v);
+    // (one phi here, so the index only marks masked timepoints: not read at all when there are none)
+    const uint8_t *phi_index = (ka.n_unmasked == T) ? nullptr : ka.cfg.phi_index;
+    DataPipe pipe;
+    pipe.start(ka, v, V, T);
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(precise);
     mo.precise = precise;
-    for (int t = 0; t < T; t++)
-    {
-        const double y_cur = y_next;
-        if (t + 1 < T)
-            y_next = load_data(ka, (size_t)(t + 1) * V + v);
+    auto step = [&](int t, double y_cur) {
         double g, f2[P], f3[P], J[P];
         sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
 #pragma unroll
@@ -186,7 +230,8 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
             }
             mo.s += r * r;
         }
-    }
+    };
+    FVB_FOR_EACH_TIMEPOINT(pipe, ka, v, V, T, step)
     return bad_offset ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
 }
 
@@ -378,16 +423,14 @@ __device__ __forceinline__ double exact_residual(
         nd[i] = mo.ml[i] - m[i];
     }
     double kk = 0;
-    const uint8_t *phi_index = ka.cfg.phi_index;
-    double y_next = load_data(ka, (size_t)v);
+    // (one phi here, so the index only marks masked timepoints: not read at all when there are none)
+    const uint8_t *phi_index = (ka.n_unmasked == T) ? nullptr : ka.cfg.phi_index;
+    DataPipe pipe;
+    pipe.start(ka, v, V, T);
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(mo.precise); // the Jacobian as the re-centre about ml computed it
-    for (int t = 0; t < T; t++)
-    {
-        const double y_cur = y_next;
-        if (t + 1 < T)
-            y_next = load_data(ka, (size_t)(t + 1) * V + v);
+    auto step = [&](int t, double y_cur) {
         double g, f2[P], f3[P];
         sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
         double Jd = 0;
@@ -403,22 +446,213 @@ __device__ __forceinline__ double exact_residual(
             const double k = y_cur - g + Jd;
             kk += k * k;
         }
-    }
+    };
+    FVB_FOR_EACH_TIMEPOINT(pipe, ka, v, V, T, step)
     return kk;
 }
 
-// k'Qk (moments, or exact where needed) and tr(Sigma J'QJ) for the current (m, Sigma, ml)
+// The same quantity for the FEW voxels of a wavefront that need it (about 1 % of the
+// voxel-iterations of the bi-exponential fit - but two in five wavefronts contain one). Instead
+// of every lane streaming over its own series, the whole wavefront works on one such voxel at a
+// time: its state is broadcast, the lanes that are still in the loop share out 64 timepoints at
+// a time (pointwise model evaluation), put k_t^2 into an LDS row, and the row is added up in t
+// order. ~0.6 k instructions per rescued voxel against ~10 k for the streaming pass. What a voxel
+// gets depends on nothing but that voxel: every k_t^2 is the same whichever lane computes it and
+// the additions run over t in order, as in the streaming pass and in the reference.
 template <class Model, int P>
+__device__ __forceinline__ double rescue_residual(const KernelArgs &ka, const ModelArgs &ma, int v,
+    const Moments<P> &mo, const double (&m)[P], bool want, double *row /* LDS, 64 doubles per wave */)
+{
+    const int T = ka.cfg.n_times;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    const int lane = threadIdx.x & 63;
+    const uint8_t *phi_index = (ka.n_unmasked == T) ? nullptr : ka.cfg.phi_index;
+    const unsigned long long active = __ballot(1);
+    const int n_active = __popcll(active);
+    const int rank = __popcll(active & ((1ull << lane) - 1ull));
+    double result = 0;
+    unsigned long long todo = __ballot(want);
+    while (todo) // wave-uniform
+    {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int vs = __shfl(v, src);
+        double tp[P], tp2[P], tp3[P], rden[P], nd[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            const double ml = __shfl(mo.ml[i], src);
+            const double mi = __shfl(m[i], src);
+            const int tr = ka.cfg.transform[i];
+            double delta = ml * 1e-5;
+            if (delta < 0)
+                delta = -delta;
+            if (delta < 1e-10)
+                delta = 1e-10;
+            const double c2 = ml + delta;
+            const double c3 = ml - delta;
+            tp[i] = to_model(tr, ml);
+            tp2[i] = to_model(tr, c2);
+            tp3[i] = to_model(tr, c3);
+            rden[i] = 1.0 / (c2 - c3);
+            nd[i] = ml - mi;
+        }
+        PointwiseSweep<Model, P> sweep;
+        double acc = 0;
+        for (int t_base = 0; t_base < T; t_base += 64)
+        {
+            for (int slot = rank; slot < 64; slot += n_active)
+            {
+                const int t = t_base + slot;
+                double kk_t = 0;
+                const bool unmasked = (t < T) && (phi_index ? (phi_index[t] != 255) : true);
+                if (unmasked)
+                {
+                    const double y = load_data(ka, (size_t)t * V + vs);
+                    double g, f2[P], f3[P];
+                    sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
+                    double Jd = 0;
+#pragma unroll
+                    for (int i = 0; i < P; i++)
+                    {
+                        FVB_NO_CONTRACT
+                        Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
+                    }
+                    const double k = y - g + Jd;
+                    kk_t = k * k;
+                }
+                row[slot] = kk_t;
+            }
+            // one wavefront per workgroup: its LDS operations complete in order; the fences keep
+            // the compiler from moving the reads above the writes (and the next writes above the reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int n = (T - t_base < 64) ? T - t_base : 64;
+            for (int i = 0; i < n; i++)
+                acc += row[i]; // masked timepoints hold 0: adding it changes nothing
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == src)
+            result = acc;
+    }
+    return result;
+}
+
+// The streaming passes over t need ~130 VGPRs of their own (sweep state, perturbed parameter
+// vectors, moments); the P x P posterior is not touched while they run. With three waves per
+// SIMD (170 VGPRs each) the register allocator would push it to scratch - which is HBM traffic
+// and a long-latency reload every iteration - so the kernel parks it in LDS itself: one wave per
+// workgroup, row i of the parked state at park[i * 64 + lane] (bank-conflict free), 26 rows =
+// 13 KB per wave = the LDS share of a wave at 12 waves per CU.
+// What is parked, in this order while it fits in 26 rows: Sigma; Lambda where it is live across
+// the pass (only the kernels that evaluate F keep it); the prior means; the prior precisions.
+template <int P, bool NEEDF>
+struct ParkPlan
+{
+    static constexpr int PT = P * (P + 1) / 2;
+    static constexpr int BUDGET = 26;
+    static constexpr int SIG = 0;
+    static constexpr bool HAS_LAM = NEEDF && (2 * PT <= BUDGET);
+    static constexpr int LAM = PT;
+    static constexpr int PM = PT + (HAS_LAM ? PT : 0);
+    static constexpr bool HAS_PM = (PM + P <= BUDGET);
+    static constexpr int PPREC = PM + (HAS_PM ? P : 0);
+    static constexpr bool HAS_PPREC = HAS_PM && (PPREC + P <= BUDGET);
+    static constexpr int ROWS = PPREC + (HAS_PPREC ? P : 0);
+};
+
+template <int P, bool NEEDF>
+__device__ __forceinline__ void park_state(double *park, const VoxelState<P> &st)
+{
+    typedef ParkPlan<P, NEEDF> PL;
+    if (!park)
+        return;
+#pragma unroll
+    for (int i = 0; i < PL::PT; i++)
+        park[(PL::SIG + i) * 64] = st.Sig[i];
+    if (PL::HAS_LAM)
+    {
+#pragma unroll
+        for (int i = 0; i < PL::PT; i++)
+            park[(PL::LAM + i) * 64] = st.Lam[i];
+    }
+    if (PL::HAS_PM)
+    {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            park[(PL::PM + i) * 64] = st.pm[i];
+    }
+    if (PL::HAS_PPREC)
+    {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            park[(PL::PPREC + i) * 64] = st.pprec[i];
+    }
+}
+
+template <int P, bool NEEDF>
+__device__ __forceinline__ void unpark_state(const double *park, VoxelState<P> &st)
+{
+    typedef ParkPlan<P, NEEDF> PL;
+    if (!park)
+        return;
+#pragma unroll
+    for (int i = 0; i < PL::PT; i++)
+        st.Sig[i] = park[(PL::SIG + i) * 64];
+    if (PL::HAS_LAM)
+    {
+#pragma unroll
+        for (int i = 0; i < PL::PT; i++)
+            st.Lam[i] = park[(PL::LAM + i) * 64];
+    }
+    if (PL::HAS_PM)
+    {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            st.pm[i] = park[(PL::PM + i) * 64];
+    }
+    if (PL::HAS_PPREC)
+    {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            st.pprec[i] = park[(PL::PPREC + i) * 64];
+    }
+}
+
+// k'Qk (moments, or exact where needed) and tr(Sigma J'QJ) for the current (m, Sigma, ml)
+template <class Model, int P, bool NEEDF = true>
 __device__ __forceinline__ void residual_and_trace(const KernelArgs &ka, const ModelArgs &ma, int v,
-    const VoxelState<P> &st, const Moments<P> &mo, double &kk, double &trSA)
+    VoxelState<P> &st, const Moments<P> &mo, double &kk, double &trSA, double *park = nullptr, double *row = nullptr)
 {
     bool lost;
     residual_terms<P>(st, mo, ka.residual_tol, kk, trSA, lost);
     const int mode = ka.residual_mode; // 0 adaptive, 1 always exact, 2 never (moments only)
     const bool want = (mode == 1) || (mode == 0 && lost);
+    if (mode == 0 && row)
+    {
+        if (__any(want)) // wave-uniform
+        {
+            park_state<P, NEEDF>(park, st);
+            const double exact = rescue_residual<Model, P>(ka, ma, v, mo, st.m, want, row);
+            unpark_state<P, NEEDF>(park, st);
+            if (want)
+                kk = exact;
+        }
+        return;
+    }
+#ifdef FVB_DEBUG_LOST
+    if (want)
+        atomicAdd((unsigned int *)ka.out.iterations + v, 1u << 8);
+    if (__any(want))
+        atomicAdd((unsigned int *)ka.out.iterations + v, 1u << 20);
+#endif
     if (__any(want)) // wave-uniform: the pass is taken by the whole wavefront or not at all
     {
+        park_state<P, NEEDF>(park, st);
         const double exact = exact_residual<Model, P>(ka, ma, v, mo, st.m);
+        unpark_state<P, NEEDF>(park, st);
         if (want)
             kk = exact; // per-voxel decision: a voxel's result never depends on its wave-mates
     }
@@ -558,6 +792,9 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
     VoxelState<P> st;
     Moments<P> mo;
     int status = FVB_OK;
+    __shared__ double park_lds[ParkPlan<P, NEEDF>::ROWS * 64];
+    __shared__ double rescue_row[64];
+    double *park = park_lds + threadIdx.x;
 
     // ---- Vb::SetupPerVoxelDists, per-voxel part (inference_vb.cc:207-247) ----
     if (ka.cfg.init_mvn)
@@ -627,7 +864,9 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
     bool setup_failed = false;
 
     // inference_vb.cc:235 and :443 re-centre about the same means: one pass gives both
+    park_state<P, NEEDF>(park, st);
     status = recentre<Model, P>(ka, ma, v, st.m, mo, true);
+    unpark_state<P, NEEDF>(park, st);
     if (status != FVB_OK)
         setup_failed = true;
 
@@ -681,13 +920,15 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
                 break;
             }
             double kk, trSA;
-            residual_and_trace<Model, P>(ka, ma, v, st, mo, kk, trSA);
+            residual_and_trace<Model, P, NEEDF>(ka, ma, v, st, mo, kk, trSA, park, rescue_row);
             if (NEEDF) // "theta" :477
                 FVB_EVAL_F(kk, trSA)
             update_noise<P>(ka, st, kk, trSA); // :479
             if (NEEDF) // "phi" :485
                 FVB_EVAL_F(kk, trSA)
+            park_state<P, NEEDF>(park, st);
             status = recentre<Model, P>(ka, ma, v, st.m, mo); // :490
+            unpark_state<P, NEEDF>(park, st);
             if (status != FVB_OK)
                 break;
             if (NEEDF) // "lin" :495
@@ -706,7 +947,9 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
             if (ka.save && conv_need_revert(conv)) // :516-525
             {
                 restore_state<P>(ka, v, st);
+                park_state<P, NEEDF>(park, st);
                 status = recentre<Model, P>(ka, ma, v, st.m, mo);
+                unpark_state<P, NEEDF>(park, st);
                 if (status == FVB_OK && NEEDF)
                 {
                     do
@@ -761,8 +1004,12 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
         ka.out.free_energy[v] = F;
     if (ka.out.status)
         ka.out.status[v] = status | (setup_failed ? 0x100 : 0);
+#ifdef FVB_DEBUG_LOST
+    atomicAdd((unsigned int *)ka.out.iterations + v, (unsigned int)it);
+#else
     if (ka.out.iterations)
         ka.out.iterations[v] = it;
+#endif
 }
 
 #endif // __HIPCC__

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Summarise the passes of tools/pmc_passes.sh into one JSON (per-launch averages for the VB
+kernel, calibration factors for FETCH_SIZE / WRITE_SIZE at the kernels' access widths).
+
+    python tools/pmc_summary.py gpurun_out/pmc_<tag> [kernel-substring] > profiles/<name>.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def counters(d, match):
+    """{counter: [value per dispatch]} for kernels whose name contains `match`."""
+    out = {}
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        per = {}
+        for row in csv.DictReader(open(f)):
+            if match not in row["Kernel_Name"]:
+                continue
+            key = (row["Dispatch_Id"], row["Counter_Name"])
+            per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+        for (disp, name), val in per.items():
+            out.setdefault(name, []).append(val)
+    return out
+
+
+def mean(xs):
+    return sum(xs) / len(xs) if xs else None
+
+
+def kernel_stats(d, match):
+    for f in glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")):
+        for row in csv.DictReader(open(f)):
+            if match in row["Name"]:
+                return dict(name=row["Name"], calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]),
+                            min_ns=float(row["MinNs"]), max_ns=float(row["MaxNs"]), percentage=float(row["Percentage"]))
+    return None
+
+
+def main():
+    root = sys.argv[1]
+    match = sys.argv[2] if len(sys.argv) > 2 else "vb_lane_kernel"
+    out = {"kernel_match": match}
+    out["kernel_trace"] = kernel_stats(os.path.join(root, "trace"), match)
+    # calibration: bytes actually moved / counter value, per access pattern (counter unit: KB? -> derive)
+    expect = {"read_rows<float>": 512 * (1 << 20) * 4, "read_rows<double>": 512 * (1 << 20) * 8,
+              "write_rows<float>": 512 * (1 << 20) * 4, "write_rows<double>": 512 * (1 << 20) * 8}
+    calib = {}
+    for which, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+        for kern, nbytes in expect.items():
+            vals = counters(os.path.join(root, which), kern.replace("<", "I").split("I")[0]) if False else None
+        f = glob.glob(os.path.join(root, which, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        per = {}
+        for row in csv.DictReader(open(f[0])):
+            if row["Counter_Name"] != ctr:
+                continue
+            key = (row["Kernel_Name"], row["Dispatch_Id"])
+            per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+        byk = {}
+        for (kn, _), v in per.items():
+            byk.setdefault(kn, []).append(v)
+        for kn, vals in byk.items():
+            for pat, nbytes in expect.items():
+                base, typ = pat.split("<")
+                typ = typ.rstrip(">")
+                if base in kn and (("IfE" in kn or "<float>" in kn) if typ == "float" else ("IdE" in kn or "<double>" in kn)):
+                    if (ctr == "FETCH_SIZE") == base.startswith("read"):
+                        calib[pat + " " + ctr] = dict(counter=mean(vals), true_bytes=nbytes, bytes_per_count=nbytes / mean(vals))
+    out["calibration"] = calib
+    res = {}
+    for which in ("fetch", "write", "sq"):
+        for name, vals in counters(os.path.join(root, which), match).items():
+            res[name] = dict(mean_per_launch=mean(vals), launches=len(vals))
+    out["counters"] = res
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
