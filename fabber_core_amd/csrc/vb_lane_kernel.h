@@ -241,6 +241,12 @@ template <int P, bool NEEDF>
 __device__ __forceinline__ bool apply_priors(const KernelArgs &ka, int v, int it, VoxelState<P> &st, double &Fprior)
 {
     bool ok = true;
+    bool any_ard = false; // wave-uniform: the covariance is made valid once, not once per parameter
+#pragma unroll
+    for (int k = 0; k < P; k++)
+        any_ard |= (ka.cfg.prior_type[k] == FVB_PRIOR_ARD);
+    if (any_ard)
+        ok = ensure_cov<P>(st);
 #pragma unroll
     for (int k = 0; k < P; k++)
     {
@@ -248,7 +254,6 @@ __device__ __forceinline__ bool apply_priors(const KernelArgs &ka, int v, int it
         double fk = 0;
         if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
-            ok &= ensure_cov<P>(st);
             const double post_mean = st.m[k];
             const double post_cov = st.Sig[tri(k, k)];
             const double new_cov = post_mean * post_mean + post_cov;
@@ -875,7 +880,10 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
         ConvState conv;
         conv_init(conv, ka.cfg.convergence, ka.cfg.max_iterations, ka.cfg.max_trials, ka.cfg.min_fchange);
         conv_reset(conv);
-        if (ka.save)
+        // Only the detectors that watch F save and revert, and they need F: the kernels built
+        // without it carry no save / revert code at all.
+        const bool use_save = NEEDF && (ka.save != nullptr);
+        if (use_save)
             save_state<P>(ka, v, st); // :432-434
         bool stop = false;
 // CalculateF (inference_vb.cc:302-318) with the given residual terms; a failure ends the voxel's
@@ -898,7 +906,7 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
     }
         do
         {
-            if (ka.save && conv_need_save(conv)) // :451-458
+            if (use_save && conv_need_save(conv)) // :451-458
                 save_state<P>(ka, v, st);
             if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
             {
@@ -942,9 +950,9 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(co
 
         if (status == FVB_OK)
         {
-            if (ka.save && conv_need_save(conv)) // :506-513
+            if (use_save && conv_need_save(conv)) // :506-513
                 save_state<P>(ka, v, st);
-            if (ka.save && conv_need_revert(conv)) // :516-525
+            if (use_save && conv_need_revert(conv)) // :516-525
             {
                 restore_state<P>(ka, v, st);
                 park_state<P, NEEDF>(park, st);

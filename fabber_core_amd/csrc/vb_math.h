@@ -147,64 +147,50 @@ FVB_HD constexpr int tri(int i, int j)
 template <int P>
 FVB_HD bool ldl_inverse(const double (&a)[P * (P + 1) / 2], double (&inv)[P * (P + 1) / 2], double &logabs, int &sign)
 {
-    double L[P * (P + 1) / 2]; // strictly lower part: multipliers; diagonal: D
-    double rD[P];
+    // In place, by sweeping every pivot (Goodnight 1979): sweeping k maps W_kk -> -1/d,
+    // W_ik -> W_ik / d, W_ij -> W_ij - W_ik W_jk / d (d = W_kk); with all pivots swept W = -A^-1.
+    // The pivots are the D of the LDL^T factorisation. Needs no storage beyond the result itself,
+    // which matters more than the flop count here: the kernels hold the whole voxel state in
+    // registers while they invert.
     bool ok = true;
     logabs = 0;
     sign = 1;
 #pragma unroll
-    for (int j = 0; j < P; j++)
-    {
-        double d = a[tri(j, j)];
+    for (int i = 0; i < P * (P + 1) / 2; i++)
+        inv[i] = a[i];
 #pragma unroll
-        for (int k = 0; k < j; k++)
-            d -= L[tri(j, k)] * L[tri(j, k)] * L[tri(k, k)];
-        L[tri(j, j)] = d;
+    for (int k = 0; k < P; k++)
+    {
+        const double d = inv[tri(k, k)];
         if (d == 0.0)
             ok = false;
         if (d < 0)
             sign = -sign;
         logabs += log(fabs(d));
         const double rd = 1.0 / d;
-        rD[j] = rd;
 #pragma unroll
-        for (int i = j + 1; i < P; i++)
+        for (int i = 0; i < P; i++)
         {
-            double s = a[tri(i, j)];
+            if (i == k)
+                continue;
+            const double cik = inv[tri(i, k)] * rd;
 #pragma unroll
-            for (int k = 0; k < j; k++)
-                s -= L[tri(i, k)] * L[tri(j, k)] * L[tri(k, k)];
-            L[tri(i, j)] = s * rd;
+            for (int j = 0; j <= i; j++)
+            {
+                if (j == k)
+                    continue;
+                inv[tri(i, j)] -= cik * inv[tri(j, k)];
+            }
         }
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if (i != k)
+                inv[tri(i, k)] *= rd;
+        inv[tri(k, k)] = -rd;
     }
-    // M = L^-1 (unit lower), overwriting the strictly lower part of L column by column
-    double M[P * (P + 1) / 2];
 #pragma unroll
-    for (int j = 0; j < P; j++)
-    {
-        M[tri(j, j)] = 1.0;
-#pragma unroll
-        for (int i = j + 1; i < P; i++)
-        {
-            double s = -L[tri(i, j)];
-#pragma unroll
-            for (int k = j + 1; k < i; k++)
-                s -= L[tri(i, k)] * M[tri(k, j)];
-            M[tri(i, j)] = s;
-        }
-    }
-    // inv = M^T D^-1 M
-#pragma unroll
-    for (int i = 0; i < P; i++)
-#pragma unroll
-        for (int j = 0; j <= i; j++)
-        {
-            double s = 0;
-#pragma unroll
-            for (int k = i; k < P; k++)
-                s += M[tri(k, i)] * M[tri(k, j)] * rD[k];
-            inv[tri(i, j)] = s;
-        }
+    for (int i = 0; i < P * (P + 1) / 2; i++)
+        inv[i] = -inv[i];
     return ok;
 }
 
