@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: voxels/s of the voxelwise VB hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1] [--voxels V]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c4] [--voxels V]
 
 A "step" is one complete pass of the hot path (every voxel of this rank's shard fitted to VB
 convergence: fabber_vb_run_device = Vb::DoCalculationsVoxelwise) over one batch of synthetic
@@ -13,9 +13,10 @@ collective is one tiny all-reduce of [sum F or noise checksum, sum iterations, b
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     - HBM roofline of the VB kernel: algorithmic bytes (4 T in + 4 rows out per voxel,
-                 SURVEY.md section 8d) / HIP-event kernel time, against 8 TB/s. The kernel is
-                 fp64-VALU bound, not HBM bound; the honest binding figure is reported beside it
-                 under roofline.fp64_valu.
+                 SURVEY.md section 8d) / HIP-event kernel time, against 8 TB/s; `traffic` = HBM bytes
+                 per launch from the PMC passes committed under profiles/ (tools/pmc_passes.sh). The
+                 kernel is bound by fp64 VALU issue, not by HBM: roofline.valu_issue gives the executed
+                 instruction count and issue utilisation from the same profile.
   cpu_baseline - the CPU oracle (port of the reference algorithm, single thread) timed on this
                  host on a bounded voxel sample, plus the max relative difference of the
                  posterior means between GPU and CPU on that sample.
@@ -40,18 +41,73 @@ WORKLOADS = {
                desc="BASELINE configs[2]: bi-exponential (examples biexp), white noise, 100 timepoints, max-iterations 50"),
     "c2": dict(num_exps=1, T=50, dt=0.04, voxels=128 * 128 * 64, its=10,
                desc="BASELINE configs[1]: exp single-exponential, white noise, 50 timepoints, 128x128x64 voxels, max-iterations 10"),
+    "c1": dict(kind="poly", degree=2, T=10, voxels=8 * 8 * 8, its=10,
+               desc="BASELINE configs[0]: poly degree 2, white noise, 10 timepoints, 8x8x8 volume, max-iterations 10"),
+    "c4": dict(kind="linear_ar", T=200, voxels=2_000_000, its=10,
+               desc="BASELINE configs[3] model: linear design (4 regressors), AR(1) noise, 200 timepoints, max-iterations 10; "
+                    "2e6 voxels per GPU by default (the 256^3 volume is --voxels 16777216: 13 GB of series)"),
 }
+
+
+def make_problem(w, V, seed, need_f):
+    import cases
+    from fabber_core_amd import vbabi
+    kind = w.get("kind", "exp")
+    if kind == "exp":
+        return cases.exp_problem(V, w["T"], w["num_exps"], w["dt"], seed=seed, max_iterations=w["its"], need_f=need_f)
+    if kind == "poly":
+        return cases.poly_problem(V, w["T"], w["degree"], seed=seed, max_iterations=w["its"], need_f=need_f)
+    return cases.linear_problem(V, w["T"], seed=seed, max_iterations=w["its"], need_f=need_f, noise=vbabi.NOISE_AR1)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the 157.3 TF fp32 vector peak)
 EXP_FLOP_EQ = 25.0             # flop-equivalents charged per fp64 exp()
+N_SIMDS = 256 * 4              # MI355X: 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4
 
 
-def flops_per_voxel_iteration(P, T, num_exps):
+def flops_per_voxel_iteration(P, T, w):
     """(2P+1) E_m + 2TP + P(P+1)T + 6TP + 6T + 2P^3 + 6P^2 with
-    E_m = 3 T N_e flops + T N_e exp() for the exponential model."""
-    e_m = 3 * T * num_exps + T * num_exps * EXP_FLOP_EQ
+    E_m = 3 T N_e flops + T N_e exp() for the exponential model, 2 T P for the polynomial and
+    the linear model (the algorithm's count: what the reference executes per voxel-iteration, not
+    what the kernel executes after sharing work between the 2P+1 evaluations)."""
+    if w.get("kind", "exp") == "exp":
+        e_m = 3 * T * w["num_exps"] + T * w["num_exps"] * EXP_FLOP_EQ
+    else:
+        e_m = 2 * T * P
     return (2 * P + 1) * e_m + 2 * T * P + P * (P + 1) * T + 6 * T * P + 6 * T + 2 * P ** 3 + 6 * P ** 2
+
+
+def pmc_traffic(workload, V, kernel, args):
+    """HBM bytes per launch of the VB kernel from the PMC passes committed under profiles/
+    (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes of this very
+    command, scaled by the bytes-per-count measured with tools/pmc_calib on the kernels' own access
+    widths). Counters cannot be read from inside the timed run, so the figure is attached only when
+    the committed profile is of the same workload, size, kernel and default engine settings."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_%s.json" % workload)
+    if not os.path.exists(path) or V != WORKLOADS[workload]["voxels"] or args.need_f or args.variant != "auto" \
+            or args.residual != "auto" or args.residual_tol is not None:
+        return {"traffic": None}
+    prof = json.load(open(path))
+    name = (prof.get("kernel_trace") or {}).get("name", "")
+    tag = kernel.replace("lane<", "").rstrip(">").split(",")  # e.g. lane<exp,4> -> ["exp", "4"]
+    if len(tag) < 2 or ("%sModel<%s>" % (tag[0].capitalize(), tag[1])) not in name:
+        return {"traffic": None}
+    cal, ctr = prof["calibration"], prof["counters"]
+    fetch = ctr["FETCH_SIZE"]["mean_per_launch"] * cal["read_rows<float> FETCH_SIZE"]["bytes_per_count"]
+    write = ctr["WRITE_SIZE"]["mean_per_launch"] * cal["write_rows<double> WRITE_SIZE"]["bytes_per_count"]
+    valu = ctr.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
+    issue = None
+    if valu:
+        # one VALU instruction of a 64-lane wave occupies its SIMD's 16-lane pipe for 4 cycles
+        issue = {"valu_wave_instructions": valu, "simds": N_SIMDS, "clock_ghz": CLOCK_GHZ,
+                 "utilisation": valu * 4 / (N_SIMDS * prof["kernel_trace"]["avg_ns"] * CLOCK_GHZ),
+                 "wait_any_over_wave_cycles": ctr["SQ_WAIT_ANY"]["mean_per_launch"] / ctr["SQ_WAVE_CYCLES"]["mean_per_launch"]}
+    return {"traffic": fetch + write, "valu_issue": issue,
+            "traffic_detail": {"fetch_bytes": fetch, "write_bytes": write, "source": os.path.relpath(path, ROOT),
+                               "profiled_kernel_ms": prof["kernel_trace"]["avg_ns"] / 1e6,
+                               "note": "includes the per-iteration re-read of the series (it does not stay in the "
+                                       "Infinity Cache at this size) and register spill traffic; see DESIGN.md"}}
 
 
 def main():
@@ -92,18 +148,18 @@ def main():
         hiplib.set_residual_tolerance(args.residual_tol)
     w = WORKLOADS[args.workload]
     V = args.voxels or w["voxels"]
-    T, P = w["T"], 2 * w["num_exps"]
+    T = w["T"]
     # every rank gets its own contiguous block of the (world x V)-voxel problem: distinct seed
-    holder, y = cases.exp_problem(V, T, w["num_exps"], w["dt"], seed=20260103 + rank, max_iterations=w["its"],
-                                  need_f=bool(args.need_f))
+    holder, y = make_problem(w, V, 20260103 + rank, bool(args.need_f))
+    P = holder.cfg.n_params
     prob = DeviceProblem(holder, y, device)
     summary = torch.zeros(3, dtype=torch.float64, device=device)
+    n_mvn = P + holder.n_noise_outputs
+    noise_row = n_mvn * (n_mvn + 1) // 2 + P  # mean of the first noise parameter
 
     def step():
         prob.run()
         # per-step global health/convergence summary: [sum F (or noise-mean checksum), sum iterations, bad voxels]
-        n = holder.cfg.n_params + 1
-        noise_row = n * (n + 1) // 2 + holder.cfg.n_params
         summary[0] = prob.free_energy.sum() if args.need_f else prob.mvn[noise_row].sum()
         summary[1] = prob.iterations.sum(dtype=torch.float64)
         summary[2] = (prob.status != 0).sum(dtype=torch.float64)
@@ -124,8 +180,6 @@ def main():
         ev[i][0].record()      # same stream the kernel is launched on (torch's current stream)
         prob.run()
         ev[i][1].record()
-        n = holder.cfg.n_params + 1
-        noise_row = n * (n + 1) // 2 + holder.cfg.n_params
         summary[0] = prob.free_energy.sum() if args.need_f else prob.mvn[noise_row].sum()
         summary[1] = prob.iterations.sum(dtype=torch.float64)
         summary[2] = (prob.status != 0).sum(dtype=torch.float64)
@@ -144,24 +198,26 @@ def main():
         rows = holder.n_mvn_rows
         alg_bytes = (4 * T + 4 * rows) * V
         mean_its = summ[1] / (V * world)
-        flops = flops_per_voxel_iteration(P, T, w["num_exps"]) * mean_its * V
+        flops = flops_per_voxel_iteration(P, T, w) * mean_its * V
         roofline = {
             "bound": "hbm", "kernel": prob.kernel,
             "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-            "note": "kernel is fp64-VALU/transcendental bound (arithmetic intensity ~6e3 flop/B), see fp64_valu",
-            "fp64_valu": {"achieved": flops / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP-eq/s",
-                          "frac": flops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          "flop_eq_per_voxel_iteration": flops_per_voxel_iteration(P, T, w["num_exps"]),
-                          "exp_flop_eq": EXP_FLOP_EQ},
+            "note": "the kernel is bound by fp64 VALU issue, not by HBM: see valu_issue (executed instructions, from "
+                    "the committed PMC profile) and fp64_algorithmic (the reference's operation count per second; it can "
+                    "exceed the vector peak because the kernel shares work between the 2P+1 model evaluations)",
+            "fp64_algorithmic": {"achieved": flops / (k_ms * 1e-3) / 1e12, "vector_peak": FP64_VALU_PEAK_TFLOPS,
+                                 "unit": "TFLOP-eq/s", "flop_eq_per_voxel_iteration": flops_per_voxel_iteration(P, T, w),
+                                 "exp_flop_eq": EXP_FLOP_EQ},
         }
+        roofline.update(pmc_traffic(args.workload, V, prob.kernel, args))
         cpu = None
         if args.cpu_sample > 0:
             import oracle
             import parity
             ns = min(args.cpu_sample, V)
-            hs, _ = cases.exp_problem(ns, T, w["num_exps"], w["dt"], seed=1, max_iterations=w["its"], need_f=bool(args.need_f))
+            hs, _ = make_problem(w, ns, 1, bool(args.need_f))
             ys = np.ascontiguousarray(y[:, :ns])
             oracle.run(hs, ys, v_end=min(64, ns))  # page the library in
             c0 = time.perf_counter()
@@ -172,7 +228,7 @@ def main():
             # Parity on the sample. The bi-exponential fit is chaotic: compare the
             # GPU-vs-CPU agreement with the agreement of two CPU builds of the same oracle source.
             nf = min(ns, 4096)
-            hf, _ = cases.exp_problem(nf, T, w["num_exps"], w["dt"], seed=1, max_iterations=w["its"], need_f=bool(args.need_f))
+            hf, _ = make_problem(w, nf, 1, bool(args.need_f))
             yf = np.ascontiguousarray(ys[:, :nf])
             ref_f = {k: (v[:, :nf] if v.ndim == 2 else v[:nf]) for k, v in ref.items() if isinstance(v, np.ndarray)}
             floor = parity.population_stats(hf, ref_f, oracle.run_fma(hf, yf))
