@@ -1132,3 +1132,10 @@ inline std::ostream &operator<<(std::ostream &os, const MatrixView &v)
 }
 
 } // namespace NEWMAT
+
+// FSL's NEWMAT headers bring namespace std into scope for everything that includes them, and
+// model sources written against them rely on it (e.g. examples/exp_models.cc:26 uses an
+// unqualified `string`). Define FABBER_NEWMAT_NO_USING_STD to opt out.
+#ifndef FABBER_NEWMAT_NO_USING_STD
+using namespace std;
+#endif

@@ -269,6 +269,24 @@ def test_output_only_from_mvn():
 
 
 @pytest.mark.gpu
+def test_spatialvb_restart_output_only():
+    """test_spatialvb.cc:585-670 (RestartOutputOnly)"""
+    n = np.arange(1, 11, dtype=np.float64)
+    data = volume((5, 5, 5), float(VAL) + 1.5 * float(VAL) * n * n)
+    first = fabber.run(data, {"model": "poly", "degree": 2, "noise": "white", "method": "spatialvb", "max-iterations": 50,
+                              "save-mvn": True})
+    out = fabber.run(data, {"model": "poly", "degree": 2, "noise": "white", "method": "spatialvb", "save-mean": True,
+                            "save-model-fit": True, "output-only": True, "continue-from-mvn": "mvns"},
+                     extra_data={"mvns": first["finalMVN"]})
+    assert "finalMVN" not in out
+    assert out["mean_c0"].shape == (5, 5, 5)
+    assert np.all(np.abs(out["mean_c0"] - VAL) < 1e-4)
+    assert np.all(np.abs(out["mean_c1"]) < 1e-4)
+    assert np.all(np.abs(out["mean_c2"] - 1.5 * VAL) < 1e-4)
+    assert out["modelfit"].shape == (5, 5, 5, 10)
+
+
+@pytest.mark.gpu
 def test_image_priors():
     """test_vb.cc:71-232"""
     series = [VAL if n % 2 == 0 else VAL * np.float32(3) for n in range(10)]

@@ -45,6 +45,87 @@ def test_neighbour_lists_on_a_full_grid():
     assert (nn2d[centre] > 0).sum() == 4
 
 
+def _cube(n, origin=0):
+    c = vbabi.grid_coords((n, n, n))
+    return (c + origin).astype(np.int32)
+
+
+def _first_neighbour_sets(coords, dims=3):
+    """Neighbour sets (1-based ids) from the oracle and from the driver's table; they must agree."""
+    nn, nn2, n2c = oracle.calc_neighbours(coords, dims)
+    ref = [set(row[row > 0].tolist()) for row in nn]
+    if hiplib.available():
+        drv = hiplib.neighbours(coords, dims)
+        assert [set((row[row >= 0] + 1).tolist()) for row in drv] == ref
+    return ref, nn2, n2c
+
+
+def test_reference_calc_neighbours_cases():
+    """test/test_spatialvb.cc:81-582, every CalcNeighbours case of the reference's own suite."""
+    # one voxel, at 1 and at 0 (:81-105)
+    for at in (1, 0):
+        ref, _, n2c = _first_neighbour_sets(np.full((3, 1), at, dtype=np.int32))
+        assert ref == [set()] and n2c[0] == 0
+    # five voxels along x, y, z (:107-187)
+    for axis in range(3):
+        c = np.ones((3, 5), dtype=np.int32)
+        c[axis] = np.arange(1, 6)
+        ref, _, _ = _first_neighbour_sets(c)
+        assert [len(s) for s in ref] == [1, 2, 2, 2, 1]
+    # 5x5x5 cube with co-ordinates from 0 (:189-247) and from 1 (:460-518)
+    n = 5
+    for origin in (0, 1):
+        ref, nn2, n2c = _first_neighbour_sets(_cube(n, origin))
+        v = 1
+        for z in range(n):
+            for y in range(n):
+                for x in range(n):
+                    want = set()
+                    if x != 0: want.add(v - 1)
+                    if x != n - 1: want.add(v + 1)
+                    if y != 0: want.add(v - n)
+                    if y != n - 1: want.add(v + n)
+                    if z != 0: want.add(v - n * n)
+                    if z != n - 1: want.add(v + n * n)
+                    assert ref[v - 1] == want
+                    if origin == 0:  # second neighbours, duplicates kept (:365-457)
+                        exp = []
+                        if x >= 2: exp.append(v - 2)
+                        if x <= n - 3: exp.append(v + 2)
+                        if y >= 2: exp.append(v - 2 * n)
+                        if y <= n - 3: exp.append(v + 2 * n)
+                        if z >= 2: exp.append(v - 2 * n * n)
+                        if z <= n - 3: exp.append(v + 2 * n * n)
+                        for _ in range(2):
+                            for (a, da), (b, db) in (((x, 1), (y, n)), ((x, 1), (z, n * n)), ((y, n), (z, n * n))):
+                                if a >= 1 and b >= 1: exp.append(v - da - db)
+                                if a >= 1 and b <= n - 2: exp.append(v - da + db)
+                                if a <= n - 2 and b >= 1: exp.append(v + da - db)
+                                if a <= n - 2 and b <= n - 2: exp.append(v + da + db)
+                        assert n2c[v - 1] == len(exp)
+                        assert sorted(nn2[v - 1][:n2c[v - 1]].tolist()) == sorted(exp)
+                    v += 1
+    # reduced spatial dimensions on the cube (:251-363)
+    for dims, per_axis in ((1, 1), (2, 2)):
+        ref, _, _ = _first_neighbour_sets(_cube(n), dims)
+        v = 1
+        for z in range(n):
+            for y in range(n):
+                for x in range(n):
+                    want = set()
+                    if x != 0: want.add(v - 1)
+                    if x != n - 1: want.add(v + 1)
+                    if dims >= 2 and y != 0: want.add(v - n)
+                    if dims >= 2 and y != n - 1: want.add(v + n)
+                    assert ref[v - 1] == want
+                    v += 1
+    # irregular five-voxel volume (:521-582)
+    c = np.array([[1, 2, 1, 2, 1], [1, 1, 2, 2, 1], [1, 1, 1, 1, 2]], dtype=np.int32)
+    ref, _, n2c = _first_neighbour_sets(c)
+    assert [len(s) for s in ref] == [3, 2, 2, 2, 1]
+    assert n2c.tolist() == [2, 3, 3, 2, 2]
+
+
 def test_no_wrap_around_between_rows():
     """The last voxel of a row and the first of the next have consecutive offsets but are not
     neighbours (wrap-around test, inference_vb.cc:906-925)."""
