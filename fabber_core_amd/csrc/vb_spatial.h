@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
         double trace_term = 0, term2 = 0;
         for (int v = blockIdx.x * 256 + threadIdx.x; v < (int)V; v += gridDim.x * 256)
         {
+            if (sa.status[v] != 0) // ignored voxels (priors.cc:237-240) ...
+                continue;
             const double sigmaK = sa.state[(size_t)(L::SIG + tri(k, k)) * V + v];
             const double wK = sa.state[(size_t)(L::M + k) * V + v];
             int nn = 0;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
             for (int i = 0; i < 6; i++)
             {
                 const int u = sa.nn[(size_t)v * 6 + i];
-                if (u >= 0)
+                if (u >= 0 && sa.status[u] == 0) // ... are also gone from every neighbour list (IgnoreVoxel)
                 {
                     nn++;
                     SwK += wK - sa.state[(size_t)(L::M + k) * V + u];
@@ -305,7 +307,7 @@ __global__ void vb_spatial_ak_final_kernel(const SpatialArgs sa)
 // ---- first sweep, one level: priors + UpdateTheta (inference_vb.cc:614-672) -------------------
 // There are hundreds of these launches per iteration, so the (large) argument block stays in
 // device memory and only the level range travels with the launch.
-template <int P>
+template <int P, bool NEEDF>
 __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs *__restrict__ sap, int level_begin,
     int level_count, int it)
 {
@@ -317,7 +319,10 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
         return;
     const int v = sa.order[level_begin + i];
     const size_t V = (size_t)ka.cfg.n_voxels;
-    if (sa.status[v] != 0)
+    // An ignored voxel still has its priors applied before the reference skips it
+    // (inference_vb.cc:626-641); only the last voxel's are observable (its F term is reused).
+    const bool ignored = sa.status[v] != 0;
+    if (ignored && v != ka.cfg.n_voxels - 1)
         return;
     VoxelState<P> st;
     Moments<P> mo;
@@ -334,18 +339,26 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             const double *mk = sa.state + (size_t)(L::M + k) * V;
             int nn = 0, nn2 = 0;
             double contrib_nn = 0, contrib_nn2 = 0;
+            // Vb::IgnoreVoxel (inference_vb.cc:266-297) deletes a failed voxel from the first-neighbour
+            // lists of its neighbours and from the second-neighbour lists of its second neighbours;
+            // the second-neighbour list itself was fixed when it was built, so it still reaches
+            // across a failed intermediate voxel. With fixed tables: test the status of every END
+            // point, never of the intermediate one.
             for (int a = 0; a < 6; a++)
             {
                 const int u = sa.nn[(size_t)v * 6 + a];
                 if (u < 0)
                     continue;
-                nn++;
-                contrib_nn += mk[u];
+                if (sa.status[u] == 0)
+                {
+                    nn++;
+                    contrib_nn += mk[u];
+                }
                 if (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p)
                     for (int b = 0; b < 6; b++)
                     {
                         const int w = sa.nn[(size_t)u * 6 + b];
-                        if (w >= 0 && w != v)
+                        if (w >= 0 && w != v && sa.status[w] == 0)
                         {
                             nn2++;
                             contrib_nn2 += -mk[w];
@@ -415,8 +428,38 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
     }
     if (v == ka.cfg.n_voxels - 1)
         *sa.fprior_last = Fprior;
+    if (ignored)
+        return;
+    // CalculateF "before" and "theta" (:643, :651). Their values are overwritten before anyone can
+    // read them, but their failures are observable: a non-finite F (e.g. a non-finite sample) stops
+    // the voxel HERE, before / straight after the update of its means, and makes it an ignored voxel
+    // for every voxel that follows in the sweep.
+    if (NEEDF)
+    {
+        double F;
+        bool finite = true;
+        // the means are still the linearisation centre: k = y - g, k'k = s
+        const bool ok = calc_free_energy<P>(ka, st, mo.s, trace_SA<P>(st, mo), Fprior, F, finite);
+        if (!ok || !finite)
+        {
+            sa.status[v] = ok ? FVB_BAD_FREE_ENERGY : FVB_BAD_RESULT;
+            return;
+        }
+    }
+    int status = FVB_OK;
     if (!update_theta<P>(st, mo, 0.0)) // LMalpha = 0 in the spatial loop (:649)
-        sa.status[v] = FVB_BAD_RESULT;
+        status = FVB_BAD_RESULT;
+    if (NEEDF && status == FVB_OK)
+    {
+        double kk, trSA, F;
+        bool lost, finite = true;
+        residual_terms<P>(st, mo, 0.0, kk, trSA, lost);
+        const bool ok = calc_free_energy<P>(ka, st, kk, trSA, Fprior, F, finite);
+        if (!ok || !finite)
+            status = ok ? FVB_BAD_FREE_ENERGY : FVB_BAD_RESULT;
+    }
+    if (status != FVB_OK)
+        sa.status[v] = status;
     sp_store_theta<P>(sa, v, st);
 }
 
@@ -517,7 +560,9 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
 #define FVB_SPATIAL_CASE(MODEL, TAG, PP)                                                                     \
     case PP:                                                                                                 \
         return SpatialKernels{ vb_spatial_setup_kernel<MODEL<PP>, PP>, vb_spatial_ak_partial_kernel<PP>,     \
-            vb_spatial_ak_final_kernel<PP>, vb_spatial_theta_kernel<PP>,                                     \
+            vb_spatial_ak_final_kernel<PP>,                                                                  \
+            need_f ? (SpatialThetaFn)vb_spatial_theta_kernel<PP, true>                                       \
+                   : (SpatialThetaFn)vb_spatial_theta_kernel<PP, false>,                                     \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true>                           \
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false>,                         \
             vb_spatial_pack_kernel<PP>, SpLayout<PP>::ROWS, "spatial<" TAG "," #PP ">" };

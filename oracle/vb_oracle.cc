@@ -10,6 +10,7 @@
  */
 #include "vb_oracle.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>

@@ -241,6 +241,51 @@ def test_spatial_options_dims_speed_first_iteration_and_free_energy():
     spatial_check(h, vbabi.SpatialHolder(coords, spatial_speed=1.5, q1=5.0, q2=2.0), y, "speed+q1q2, two spatial params")
 
 
+def failing_voxel_problem(typ, need_f=True):
+    mask, coords = masked_volume((9, 8, 6), seed=11, keep=0.9)
+    V = coords.shape[1]
+    _, y = smooth_exp_data(coords, 50, 0.04, seed=12)
+    bad = [V // 2, V // 2 + 1, V - 1]  # two adjacent interior voxels and the LAST voxel
+    for v in bad:
+        y[7, v] = np.nan  # non-finite means after the first UpdateTheta -> ReCentre throws -> IgnoreVoxel
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=6, need_f=need_f,
+                           param_overrides={"amp1": dict(type=typ)})
+    return h, vbabi.SpatialHolder(coords), y, bad
+
+
+@pytest.mark.parametrize("typ", ["M", "P"])
+def test_oracle_ignores_failed_voxels_and_their_neighbours_carry_on(typ):
+    """Vb::IgnoreVoxel (inference_vb.cc:266-297): a voxel that fails is dropped from its
+    neighbours' lists and from the a_K sums; everything else finishes."""
+    h, sp, y, bad = failing_voxel_problem(typ)
+    r = oracle.run_spatial(h, sp, y)
+    assert sorted(np.flatnonzero(r["status"]).tolist()) == sorted(bad)
+    ok = r["status"] == 0
+    assert np.isfinite(r["mvn"][:, ok]).all() and np.isfinite(r["free_energy"][ok]).all()
+
+
+@gpu
+@pytest.mark.parametrize("typ", ["M", "m", "P", "p"])
+def test_failed_voxels_are_ignored_as_in_the_reference(typ):
+    """With F evaluated, the non-finite sample is caught by the first CalculateF of the sweep,
+    before the voxel's means change: exactly the three voxels fail."""
+    h, sp, y, bad = failing_voxel_problem(typ)
+    spatial_check(h, sp, y, "IgnoreVoxel " + typ, check_f=True)
+    got = hiplib.run_spatial_host(h, sp, y)
+    assert sorted(np.flatnonzero(got["status"]).tolist()) == sorted(bad)
+
+
+@gpu
+def test_without_f_a_failure_spreads_along_the_sweep_as_in_the_reference():
+    """Without F nothing looks at the voxel between UpdateTheta (non-finite means) and ReCentre in
+    the second sweep: every later neighbour reads those means in the meantime. The level-ordered
+    sweep reproduces the reference's index-ordered cascade voxel for voxel."""
+    h, sp, y, bad = failing_voxel_problem("M", need_f=False)
+    cpu = oracle.run_spatial(h, sp, y)
+    assert set(bad) < set(np.flatnonzero(cpu["status"]).tolist())
+    spatial_check(h, sp, y, "IgnoreVoxel cascade")
+
+
 @gpu
 def test_spatialvb_method_with_nonspatial_priors_reproduces_reference_output():
     ref = gu.load_reference_outdata()
