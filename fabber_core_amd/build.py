@@ -18,6 +18,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
+BINDIR = os.path.join(HERE, "bin")
 OBJDIR = os.path.join(HERE, "build", "obj")
 ARCH = "gfx950"
 
@@ -140,7 +141,7 @@ def build_host(force=False, jobs=None, verbose=True):
     lib = os.path.join(LIBDIR, "libfabbercore_amd.so")
     engine = os.path.join(LIBDIR, "libfabber_vb_hip.so")
     if rebuilt or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(engine):
-        cmd = ["g++", "-shared", "-fPIC", "-o", lib] + objs + ["-L", LIBDIR, "-lfabber_vb_hip", "-ldl", "-Wl,-rpath,$ORIGIN",
+        cmd = ["g++", "-shared", "-fPIC", "-o", lib] + objs + ["-L", LIBDIR, "-lfabber_vb_hip", "-ldl", "-lz", "-Wl,-rpath,$ORIGIN",
                                                                 "-Wl,--no-undefined"]
         p = subprocess.run(cmd, capture_output=True, text=True)
         if p.returncode != 0:
@@ -150,9 +151,27 @@ def build_host(force=False, jobs=None, verbose=True):
     return lib
 
 
+def build_cli(force=False, verbose=True):
+    """bin/fabber: the command line tool (fabber_main.cc), linked against libfabbercore_amd.so."""
+    os.makedirs(BINDIR, exist_ok=True)
+    exe = os.path.join(BINDIR, "fabber")
+    src = os.path.join(HOST_DIR, "cli", "fabber_main.cc")
+    lib = os.path.join(LIBDIR, "libfabbercore_amd.so")
+    if force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(lib), os.path.getmtime(src)):
+        cmd = ["g++"] + HOST_FLAGS + ["-I", HOST_DIR, src, "-o", exe, "-L", LIBDIR, "-lfabbercore_amd", "-lfabber_vb_hip",
+                                      "-Wl,-rpath,$ORIGIN/../lib"]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s\n%s" % (" ".join(cmd), p.stdout, p.stderr))
+        if verbose:
+            print("[build] linked", exe, file=sys.stderr)
+    return exe
+
+
 def build_all(force=False, jobs=None, verbose=True):
     libs = [build_hip(force=force, jobs=jobs, verbose=verbose)]
     libs.append(build_host(force=force, jobs=jobs, verbose=verbose))
+    libs.append(build_cli(force=force, verbose=verbose))
     return libs
 
 

@@ -747,6 +747,10 @@ public:
         Matrix::operator=(v);
         return *this;
     }
+    ColumnVector &operator=(const MatrixView &v)
+    {
+        return *this = v.AsMatrix();
+    }
     using Matrix::operator<<;
     using Matrix::ReSize;
     void ReSize(int n)
