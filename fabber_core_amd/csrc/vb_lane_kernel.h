@@ -205,6 +205,12 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(precise);
     mo.precise = precise;
+    // ReCentre's non-finite tests (fwdmodel_linear.cc:134-140,174-181). With every timepoint in
+    // the sums they are read off the sums after the pass - g through its running total, J(.,i)
+    // through A_ii = sum_t J_ti^2 (a non-finite term makes the sum non-finite; a finite J whose
+    // square overflows, |J| > 1e154, would be reported too) - instead of 3 instructions per value
+    // and timepoint. With masked timepoints, whose J does not enter A, they stay per timepoint.
+    double g_total = 0;
     auto step = [&](int t, double y_cur) {
         double g, f2[P], f3[P], J[P];
         sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
@@ -213,9 +219,13 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
         {
             FVB_NO_CONTRACT
             J[i] = (f2[i] - f3[i]) * rden[i];
-            bad_jac |= !is_finite(J[i]);
+            if (phi_index)
+                bad_jac |= !is_finite(J[i]);
         }
-        bad_offset |= !is_finite(g);
+        if (phi_index)
+            bad_offset |= !is_finite(g);
+        else
+            g_total += g;
         const bool unmasked = phi_index ? (phi_index[t] != 255) : true; // wave-uniform
         if (unmasked)
         {
@@ -232,6 +242,13 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
         }
     };
     FVB_FOR_EACH_TIMEPOINT(pipe, ka, v, V, T, step)
+    if (!phi_index)
+    {
+        bad_offset = !is_finite(g_total);
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            bad_jac |= !is_finite(mo.A[tri(i, i)]);
+    }
     return bad_offset ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
 }
 

@@ -209,17 +209,22 @@ struct ExpModel
 #pragma unroll
             for (int j = 0; j < N; j++)
                 val[j] = tp[2 * j] * e0[j];
-            double res = 0;
+            // (eval() starts from res = 0: 0 + x is x, bit for bit, except that a -0 term would
+            // become +0 - the sums here start from their first term and save the additions)
+            double res = val[0];
 #pragma unroll
-            for (int j = 0; j < N; j++)
+            for (int j = 1; j < N; j++)
                 res += val[j];
             g = res;
 #pragma unroll
             for (int i = 0; i < N; i++)
             {
-                double a2 = 0, a3 = 0, r2 = 0, r3 = 0;
+                double a2 = (i == 0) ? tp2[0] * e0[0] : val[0];
+                double a3 = (i == 0) ? tp3[0] * e0[0] : val[0];
+                double r2 = (i == 0) ? tp[0] * e2[0] : val[0];
+                double r3 = (i == 0) ? tp[0] * e3[0] : val[0];
 #pragma unroll
-                for (int j = 0; j < N; j++)
+                for (int j = 1; j < N; j++)
                 {
                     a2 += (j == i) ? tp2[2 * i] * e0[i] : val[j];
                     a3 += (j == i) ? tp3[2 * i] * e0[i] : val[j];
