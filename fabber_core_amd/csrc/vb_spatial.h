@@ -57,6 +57,12 @@ struct SpatialArgs
     int32_t it;
     int32_t level_begin, level_count;
     int32_t n_blocks;
+    // Multi-GPU slabs: this process updates voxels [owned_begin, owned_end) of its local list; the
+    // rest are ghost copies of neighbouring slabs' boundary planes (read as neighbours, never
+    // updated here, refreshed by the halo exchange). One process: the whole list.
+    int32_t owned_begin, owned_end;
+    int32_t n_voxels_global; // the V of h_K = V/2 + q2 (priors.cc:321)
+    double *ak_sums;         // [P][2] (trace_term, term2): this slab's, then the all-reduced ones
 };
 
 #if defined(__HIPCC__)
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
         if (!is_spatial_type(type))
             continue;
         double trace_term = 0, term2 = 0;
-        for (int v = blockIdx.x * 256 + threadIdx.x; v < (int)V; v += gridDim.x * 256)
+        for (int v = sa.owned_begin + blockIdx.x * 256 + threadIdx.x; v < sa.owned_end; v += gridDim.x * 256)
         {
             if (sa.status[v] != 0) // ignored voxels (priors.cc:237-240) ...
                 continue;
@@ -278,6 +284,24 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
     }
 }
 
+// this slab's sums: the per-block partials added in block order (deterministic)
+template <int P>
+__global__ void vb_spatial_ak_reduce_kernel(const SpatialArgs sa)
+{
+    const int k = threadIdx.x;
+    if (k >= P)
+        return;
+    double trace_term = 0, term2 = 0;
+    if (is_spatial_type(sa.ka.cfg.prior_type[k]))
+        for (int b = 0; b < sa.n_blocks; b++)
+        {
+            trace_term += sa.partials[((size_t)b * P + k) * 2 + 0];
+            term2 += sa.partials[((size_t)b * P + k) * 2 + 1];
+        }
+    sa.ak_sums[2 * k + 0] = trace_term;
+    sa.ak_sums[2 * k + 1] = term2;
+}
+
 template <int P>
 __global__ void vb_spatial_ak_final_kernel(const SpatialArgs sa)
 {
@@ -285,14 +309,10 @@ __global__ void vb_spatial_ak_final_kernel(const SpatialArgs sa)
     const int k = threadIdx.x;
     if (k >= P || !is_spatial_type(ka.cfg.prior_type[k]))
         return;
-    double trace_term = 0, term2 = 0;
-    for (int b = 0; b < sa.n_blocks; b++) // fixed order: deterministic
-    {
-        trace_term += sa.partials[((size_t)b * P + k) * 2 + 0];
-        term2 += sa.partials[((size_t)b * P + k) * 2 + 1];
-    }
+    // with several slabs ak_sums holds the all-reduced sums by now (set by the host in between)
+    const double trace_term = sa.ak_sums[2 * k + 0], term2 = sa.ak_sums[2 * k + 1];
     const double gk = 1 / (0.5 * trace_term + 0.5 * term2 + 1 / sa.q1);
-    const double hK = ka.cfg.n_voxels * 0.5 + sa.q2;
+    const double hK = sa.n_voxels_global * 0.5 + sa.q2;
     double aK = gk * hK;
     if (aK < 1e-50)
         aK = 1e-50;
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
     // An ignored voxel still has its priors applied before the reference skips it
     // (inference_vb.cc:626-641); only the last voxel's are observable (its F term is reused).
     const bool ignored = sa.status[v] != 0;
-    if (ignored && v != ka.cfg.n_voxels - 1)
+    if (ignored && v != sa.owned_end - 1)
         return;
     VoxelState<P> st;
     Moments<P> mo;
@@ -426,7 +446,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             st.pprec[k] = ka.cfg.prior_prec[k];
         }
     }
-    if (v == ka.cfg.n_voxels - 1)
+    if (v == sa.owned_end - 1) // (with several slabs: the last voxel of THIS slab)
         *sa.fprior_last = Fprior;
     if (ignored)
         return;
@@ -468,8 +488,8 @@ template <class Model, int P, bool NEEDF>
 __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_spatial_noise_kernel(const SpatialArgs sa)
 {
     const KernelArgs &ka = sa.ka;
-    const int v = blockIdx.x * 64 + threadIdx.x;
-    if (v >= ka.cfg.n_voxels)
+    const int v = sa.owned_begin + blockIdx.x * 64 + threadIdx.x;
+    if (v >= sa.owned_end)
         return;
     if (sa.status[v] != 0)
         return;
@@ -547,7 +567,7 @@ typedef void (*SpatialKernelFn)(const SpatialArgs);
 typedef void (*SpatialThetaFn)(const SpatialArgs *, int, int, int);
 struct SpatialKernels
 {
-    SpatialKernelFn setup, ak_partial, ak_final;
+    SpatialKernelFn setup, ak_partial, ak_reduce, ak_final;
     SpatialThetaFn theta;
     SpatialKernelFn noise, pack;
     int state_rows;
@@ -560,7 +580,7 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
 #define FVB_SPATIAL_CASE(MODEL, TAG, PP)                                                                     \
     case PP:                                                                                                 \
         return SpatialKernels{ vb_spatial_setup_kernel<MODEL<PP>, PP>, vb_spatial_ak_partial_kernel<PP>,     \
-            vb_spatial_ak_final_kernel<PP>,                                                                  \
+            vb_spatial_ak_reduce_kernel<PP>, vb_spatial_ak_final_kernel<PP>,                                 \
             need_f ? (SpatialThetaFn)vb_spatial_theta_kernel<PP, true>                                       \
                    : (SpatialThetaFn)vb_spatial_theta_kernel<PP, false>,                                     \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true>                           \

@@ -174,13 +174,51 @@ struct DevMem
     }
 };
 
-int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data, const fvb_outputs *d_out,
-    hipStream_t stream, void (*progress_cb)(int, int))
+} // namespace
+
+// One spatial VB run on one device: geometry, work buffers and the per-iteration steps. A single
+// process drives it from run_spatial() below; with several slabs the caller interleaves the steps
+// with its collectives (all-reduce of the a_K sums, halo exchange of the boundary planes).
+struct fvb_spatial_run
 {
-    const int V = cfg->n_voxels, P = cfg->n_params;
-    const bool need_f = cfg->need_f != 0;
+    fvb_config cfg;
+    fvb_spatial sp;
     SpatialKernels k;
-    switch (cfg->model)
+    SpatialArgs sa;
+    hipStream_t stream = nullptr;
+    int V = 0, P = 0, owned_begin = 0, owned_end = 0;
+    bool has_spatial = false;
+    std::vector<int32_t> level_begin;
+    DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums;
+    double t_geometry_ms = 0;
+
+    int open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out, hipStream_t stream_);
+    int ak_sums(double *host_sums);
+    int set_ak_sums(const double *host_sums);
+    int sweep(int it);
+    int copy_means(int v_begin, int v_count, double *host_means, int32_t *host_status, bool to_device);
+    int finish();
+};
+
+int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out,
+    hipStream_t stream_)
+{
+    cfg = *cfg_;
+    sp = *sp_;
+    stream = stream_;
+    V = cfg.n_voxels;
+    P = cfg.n_params;
+    owned_begin = 0;
+    owned_end = V;
+    if (sp.owned_end > sp.owned_begin)
+    {
+        owned_begin = sp.owned_begin;
+        owned_end = sp.owned_end;
+    }
+    if (owned_begin < 0 || owned_end > V)
+        return api_fail(-45, "owned voxel range outside the local voxel list");
+    const bool need_f = cfg.need_f != 0;
+    switch (cfg.model)
     {
     case FVB_MODEL_POLY:
         k = get_spatial_kernels_poly(P, need_f);
@@ -192,164 +230,253 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
         k = get_spatial_kernels_exp(P, need_f);
         break;
     default:
-        k = SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+        k = SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
     }
     if (!k.setup)
         return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
 
     // ---- host-side geometry ----
-    const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
-    const auto t_start = now();
+    const auto t_start = std::chrono::steady_clock::now();
     std::vector<int32_t> nn;
-    std::string err = build_neighbours(sp->coords, V, sp->spatial_dims, nn);
+    std::string err = build_neighbours(sp.coords, V, sp.spatial_dims, nn);
     if (!err.empty())
         return api_fail(-41, err);
-    const int32_t *X = sp->coords, *Y = sp->coords + V, *Z = sp->coords + 2 * (size_t)V;
+    const int32_t *X = sp.coords, *Y = sp.coords + V, *Z = sp.coords + 2 * (size_t)V;
     // Level function a x + b y + c z: a stencil offset that leads to a smaller voxel index must
     // lower the level, one that leads to a larger index must raise it. First neighbours only
     // (types M, m): (1,1,1). Second neighbours too (types P, p read neighbours of neighbours, e.g.
     // (x+1, y-1) which has a smaller index): b > a and c > b, so (1,2,3).
     bool second_neighbours = false;
     for (int kk = 0; kk < P; kk++)
-        second_neighbours |= (cfg->prior_type[kk] == FVB_PRIOR_SPATIAL_P || cfg->prior_type[kk] == FVB_PRIOR_SPATIAL_p);
-    const long long cy = second_neighbours ? 2 : 1, cz = second_neighbours ? 3 : 1;
-    std::vector<long long> level(V);
-    long long lmin = 0, lmax = 0;
-    for (int v = 0; v < V; v++)
     {
-        level[v] = (long long)X[v] + cy * Y[v] + cz * Z[v];
-        lmin = (v == 0 || level[v] < lmin) ? level[v] : lmin;
-        lmax = (v == 0 || level[v] > lmax) ? level[v] : lmax;
+        second_neighbours |= (cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_P || cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_p);
+        has_spatial |= cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M;
     }
-    std::vector<int32_t> order(V), level_begin;
+    const long long cy = second_neighbours ? 2 : 1, cz = second_neighbours ? 3 : 1;
+    const int n_owned = owned_end - owned_begin;
+    std::vector<long long> level(n_owned);
+    long long lmin = 0, lmax = 0;
+    for (int i = 0; i < n_owned; i++)
+    {
+        const int v = owned_begin + i;
+        level[i] = (long long)X[v] + cy * Y[v] + cz * Z[v];
+        lmin = (i == 0 || level[i] < lmin) ? level[i] : lmin;
+        lmax = (i == 0 || level[i] > lmax) ? level[i] : lmax;
+    }
+    std::vector<int32_t> order(std::max(n_owned, 1));
+    level_begin.clear();
     if (lmax - lmin < (1LL << 24))
     {
         // counting sort (stable: voxels of a level stay in index order)
         const size_t nl = (size_t)(lmax - lmin + 1);
         std::vector<int32_t> start(nl + 1, 0);
-        for (int v = 0; v < V; v++)
-            start[(size_t)(level[v] - lmin) + 1]++;
+        for (int i = 0; i < n_owned; i++)
+            start[(size_t)(level[i] - lmin) + 1]++;
         for (size_t l = 0; l < nl; l++)
             start[l + 1] += start[l];
         for (size_t l = 0; l < nl; l++)
             if (start[l + 1] > start[l])
                 level_begin.push_back(start[l]);
-        level_begin.push_back(V);
-        for (int v = 0; v < V; v++)
-            order[start[(size_t)(level[v] - lmin)]++] = v;
+        level_begin.push_back(n_owned);
+        for (int i = 0; i < n_owned; i++)
+            order[start[(size_t)(level[i] - lmin)]++] = owned_begin + i;
     }
     else
     {
-        for (int v = 0; v < V; v++)
-            order[v] = v;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
-        for (int i = 0; i < V; i++)
-            if (i == 0 || level[order[i]] != level[order[i - 1]])
+        std::vector<int32_t> idx(n_owned);
+        for (int i = 0; i < n_owned; i++)
+            idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level[a] < level[b]; });
+        for (int i = 0; i < n_owned; i++)
+        {
+            if (i == 0 || level[idx[i]] != level[idx[i - 1]])
                 level_begin.push_back(i);
-        level_begin.push_back(V);
+            order[i] = owned_begin + idx[i];
+        }
+        level_begin.push_back(n_owned);
     }
-
-    const auto t_geom = now();
+    t_geometry_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 
     // ---- device memory ----
-    const int n_blocks = std::max(1, std::min(1024, (V + 255) / 256));
-    DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status;
+    const int n_blocks = std::max(1, std::min(1024, (n_owned + 255) / 256));
     FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V));
     FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6));
-    FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * (size_t)V));
+    FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * order.size()));
     FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS));
+    FVB_HIP_CHECK(d_sums.alloc(sizeof(double) * FVB_MAX_PARAMS * 2));
     FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)n_blocks * P * 2));
     FVB_HIP_CHECK(d_fprior.alloc(sizeof(double)));
     FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V));
     FVB_HIP_CHECK(hipMemcpyAsync(d_nn.p, nn.data(), sizeof(int32_t) * (size_t)V * 6, hipMemcpyHostToDevice, stream));
-    FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
+    FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, stream));
     double aK0[FVB_MAX_PARAMS];
     for (int i = 0; i < FVB_MAX_PARAMS; i++)
         aK0[i] = 1e-8; // priors.cc:185
     FVB_HIP_CHECK(hipMemcpyAsync(d_aK.p, aK0, sizeof(aK0), hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(hipMemsetAsync(d_fprior.p, 0, sizeof(double), stream));
+    FVB_HIP_CHECK(hipMemsetAsync(d_sums.p, 0, sizeof(double) * FVB_MAX_PARAMS * 2, stream));
     FVB_HIP_CHECK(hipMemsetAsync(d_partials.p, 0, sizeof(double) * (size_t)n_blocks * P * 2, stream));
 
-    SpatialArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.ka.cfg = *cfg;
+    sa.ka.cfg = cfg;
     sa.ka.out = *d_out;
     sa.ka.data = d_data;
     sa.ka.save = nullptr;
-    sa.ka.n_unmasked = 0; // filled by the caller below
     sa.ka.residual_mode = api_residual_mode();
     sa.ka.residual_tol = api_residual_tol();
     sa.state = (double *)d_state.p;
     sa.nn = (const int32_t *)d_nn.p;
     sa.order = (const int32_t *)d_order.p;
     sa.aK = (double *)d_aK.p;
+    sa.ak_sums = (double *)d_sums.p;
     sa.partials = (double *)d_partials.p;
     sa.fprior_last = (double *)d_fprior.p;
     sa.status = (int32_t *)d_status.p;
-    sa.spatial_dims = sp->spatial_dims;
-    sa.update_first_iter = sp->update_first_iter;
-    sa.spatial_speed = sp->spatial_speed;
-    sa.q1 = sp->q1;
-    sa.q2 = sp->q2;
+    sa.spatial_dims = sp.spatial_dims;
+    sa.update_first_iter = sp.update_first_iter;
+    sa.spatial_speed = sp.spatial_speed;
+    sa.q1 = sp.q1;
+    sa.q2 = sp.q2;
     sa.n_blocks = n_blocks;
+    sa.owned_begin = owned_begin;
+    sa.owned_end = owned_end;
+    sa.n_voxels_global = sp.n_voxels_global > 0 ? sp.n_voxels_global : V;
+    // number of unmasked timepoints: phi_index is a device pointer here, read it back once
+    int n_unmasked = cfg.n_times;
+    if (cfg.phi_index)
     {
-        // number of unmasked timepoints: phi_index is a device pointer here, read it back once
-        int n_unmasked = cfg->n_times;
-        if (cfg->phi_index)
-        {
-            std::vector<uint8_t> h(cfg->n_times);
-            FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg->phi_index, h.size(), hipMemcpyDeviceToHost, stream));
-            FVB_HIP_CHECK(hipStreamSynchronize(stream));
-            n_unmasked = 0;
-            for (int t = 0; t < cfg->n_times; t++)
-                n_unmasked += (h[t] != 255);
-        }
-        sa.ka.n_unmasked = n_unmasked;
-
-        DevMem d_sa; // the argument block the per-level launches read (nothing in it changes per launch)
-        FVB_HIP_CHECK(d_sa.alloc(sizeof(SpatialArgs)));
-        FVB_HIP_CHECK(hipMemcpyAsync(d_sa.p, &sa, sizeof(SpatialArgs), hipMemcpyHostToDevice, stream));
-        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // `sa` is pageable host memory and is modified below
-        const SpatialArgs *sap = (const SpatialArgs *)d_sa.p;
-
-        const auto t_alloc = now();
-        const unsigned grid64 = (unsigned)((V + 63) / 64), grid256 = (unsigned)((V + 255) / 256);
-        hipLaunchKernelGGL(k.setup, dim3(grid64), dim3(64), 0, stream, sa);
-        FVB_HIP_CHECK(hipGetLastError());
-        bool has_spatial = false;
-        for (int kk = 0; kk < P; kk++)
-            has_spatial |= cfg->prior_type[kk] >= FVB_PRIOR_SPATIAL_M;
-        for (int it = 0; it < cfg->max_iterations; it++)
-        {
-            if (progress_cb)
-                progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
-            sa.it = it;
-            if (has_spatial && (it > 0 || sp->update_first_iter))
-            {
-                hipLaunchKernelGGL(k.ak_partial, dim3(n_blocks), dim3(256), 0, stream, sa);
-                hipLaunchKernelGGL(k.ak_final, dim3(1), dim3(64), 0, stream, sa);
-            }
-            for (size_t l = 0; l + 1 < level_begin.size(); l++)
-            {
-                const int begin = level_begin[l], count = level_begin[l + 1] - level_begin[l];
-                hipLaunchKernelGGL(k.theta, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, sap, begin, count, it);
-            }
-            hipLaunchKernelGGL(k.noise, dim3(grid64), dim3(64), 0, stream, sa);
-            FVB_HIP_CHECK(hipGetLastError());
-        }
-        sa.it = cfg->max_iterations;
-        hipLaunchKernelGGL(k.pack, dim3(grid256), dim3(256), 0, stream, sa);
-        FVB_HIP_CHECK(hipGetLastError());
-        const auto t_enq = now();
-        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // the DevMem buffers are freed on return
-        if (timing)
-            fprintf(stderr, "[fvb spatial] V=%d levels=%zu: geometry %.1f ms, alloc+upload %.1f ms, enqueue %.1f ms, drain %.1f ms\n", V,
-                level_begin.size() - 1, ms(t_start, t_geom), ms(t_geom, t_alloc), ms(t_alloc, t_enq), ms(t_enq, now()));
+        std::vector<uint8_t> h(cfg.n_times);
+        FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg.phi_index, h.size(), hipMemcpyDeviceToHost, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream));
+        n_unmasked = 0;
+        for (int t = 0; t < cfg.n_times; t++)
+            n_unmasked += (h[t] != 255);
     }
+    sa.ka.n_unmasked = n_unmasked;
+    // the argument block the per-level launches read (nothing in it changes per launch)
+    FVB_HIP_CHECK(d_sa.alloc(sizeof(SpatialArgs)));
+    FVB_HIP_CHECK(hipMemcpyAsync(d_sa.p, &sa, sizeof(SpatialArgs), hipMemcpyHostToDevice, stream));
+    FVB_HIP_CHECK(hipStreamSynchronize(stream)); // `sa`, nn, order are pageable host memory
+
+    // Vb::SetupPerVoxelDists for every local voxel, ghosts included (their initial means are what
+    // the neighbouring slab starts from too)
+    hipLaunchKernelGGL(k.setup, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fvb_spatial_run::ak_sums(double *host_sums)
+{
+    hipLaunchKernelGGL(k.ak_partial, dim3(sa.n_blocks), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL(k.ak_reduce, dim3(1), dim3(64), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    if (host_sums)
+    {
+        FVB_HIP_CHECK(hipMemcpyAsync(host_sums, d_sums.p, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+int fvb_spatial_run::set_ak_sums(const double *host_sums)
+{
+    if (host_sums)
+        FVB_HIP_CHECK(hipMemcpyAsync(d_sums.p, host_sums, sizeof(double) * 2 * P, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k.ak_final, dim3(1), dim3(64), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    if (host_sums)
+        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // the caller's buffer is pageable
+    return 0;
+}
+
+int fvb_spatial_run::sweep(int it)
+{
+    sa.it = it;
+    const SpatialArgs *sap = (const SpatialArgs *)d_sa.p;
+    for (size_t l = 0; l + 1 < level_begin.size(); l++)
+    {
+        const int begin = level_begin[l], count = level_begin[l + 1] - level_begin[l];
+        hipLaunchKernelGGL(k.theta, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, sap, begin, count, it);
+    }
+    const int n_owned = owned_end - owned_begin;
+    if (n_owned > 0)
+        hipLaunchKernelGGL(k.noise, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fvb_spatial_run::copy_means(int v_begin, int v_count, double *host_means, int32_t *host_status, bool to_device)
+{
+    if (v_begin < 0 || v_count < 0 || v_begin + v_count > V)
+        return api_fail(-46, "voxel range outside the local voxel list");
+    if (v_count == 0)
+        return 0;
+    // rows 0..P-1 of the state image are the posterior means (SpLayout::M)
+    double *dev = (double *)d_state.p + v_begin;
+    const size_t width = sizeof(double) * (size_t)v_count;
+    if (host_means)
+    {
+        if (to_device)
+            FVB_HIP_CHECK(hipMemcpy2DAsync(dev, sizeof(double) * (size_t)V, host_means, width, width, P, hipMemcpyHostToDevice, stream));
+        else
+            FVB_HIP_CHECK(hipMemcpy2DAsync(host_means, width, dev, sizeof(double) * (size_t)V, width, P, hipMemcpyDeviceToHost, stream));
+    }
+    if (host_status)
+    {
+        int32_t *ds = (int32_t *)d_status.p + v_begin;
+        if (to_device)
+            FVB_HIP_CHECK(hipMemcpyAsync(ds, host_status, sizeof(int32_t) * (size_t)v_count, hipMemcpyHostToDevice, stream));
+        else
+            FVB_HIP_CHECK(hipMemcpyAsync(host_status, ds, sizeof(int32_t) * (size_t)v_count, hipMemcpyDeviceToHost, stream));
+    }
+    FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int fvb_spatial_run::finish()
+{
+    sa.it = cfg.max_iterations;
+    hipLaunchKernelGGL(k.pack, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    FVB_HIP_CHECK(hipStreamSynchronize(stream)); // the work buffers are freed with the object
+    return 0;
+}
+
+namespace
+{
+int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data, const fvb_outputs *d_out,
+    hipStream_t stream, void (*progress_cb)(int, int))
+{
+    const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_start = now();
+    fvb_spatial_run run;
+    int rc = run.open(cfg, sp, d_data, d_out, stream);
+    if (rc)
+        return rc;
+    const auto t_open = now();
+    for (int it = 0; it < cfg->max_iterations; it++)
+    {
+        if (progress_cb)
+            progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
+        if (run.has_spatial && (it > 0 || sp->update_first_iter))
+        {
+            if ((rc = run.ak_sums(nullptr)) != 0 || (rc = run.set_ak_sums(nullptr)) != 0)
+                return rc;
+        }
+        if ((rc = run.sweep(it)) != 0)
+            return rc;
+    }
+    const auto t_enq = now();
+    if ((rc = run.finish()) != 0)
+        return rc;
+    if (timing)
+        fprintf(stderr, "[fvb spatial] V=%d levels=%zu: geometry %.1f ms, alloc+upload+setup %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
+            run.V, run.level_begin.size() - 1, run.t_geometry_ms, ms(t_start, t_open) - run.t_geometry_ms, ms(t_open, t_enq),
+            ms(t_enq, now()));
     return 0;
 }
 } // namespace
@@ -375,6 +502,66 @@ int32_t fabber_vb_run_spatial_device(const fvb_config *cfg, const fvb_spatial *s
     if (!data)
         return api_fail(-21, "data is NULL");
     return run_spatial(cfg, sp, data, out, (hipStream_t)stream, progress_cb);
+}
+
+int32_t fabber_vb_spatial_open(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    void *stream, fvb_spatial_run **run)
+{
+    if (!run)
+        return api_fail(-47, "run handle pointer is NULL");
+    *run = nullptr;
+    int rc = api_validate(cfg, true);
+    if (rc)
+        return rc;
+    if (!sp || !sp->coords)
+        return api_fail(-42, "spatial description / coordinates missing");
+    if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
+        return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
+    if (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis != 1)
+        return api_fail(-44, "spatial VB is built for white noise with one noise parameter");
+    if (!out || !out->mvn)
+        return api_fail(-20, "outputs.mvn is required");
+    if (cfg->n_voxels == 0 || !data)
+        return api_fail(-21, "no voxels / data is NULL");
+    fvb_spatial_run *r = new fvb_spatial_run();
+    rc = r->open(cfg, sp, data, out, (hipStream_t)stream);
+    if (rc)
+    {
+        delete r;
+        return rc;
+    }
+    *run = r;
+    return 0;
+}
+
+int32_t fabber_vb_spatial_ak_sums(fvb_spatial_run *run, double *sums)
+{
+    return run ? run->ak_sums(sums) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_set_ak_sums(fvb_spatial_run *run, const double *sums)
+{
+    return run ? run->set_ak_sums(sums) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_sweep(fvb_spatial_run *run, int32_t iteration)
+{
+    return run ? run->sweep(iteration) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_copy_means(fvb_spatial_run *run, int32_t v_begin, int32_t v_count, double *means, int32_t *status,
+    int32_t to_device)
+{
+    return run ? run->copy_means(v_begin, v_count, means, status, to_device != 0) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_close(fvb_spatial_run *run)
+{
+    if (!run)
+        return api_fail(-47, "run handle is NULL");
+    const int rc = run->finish();
+    delete run;
+    return rc;
 }
 
 int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data,

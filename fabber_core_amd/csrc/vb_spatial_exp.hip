@@ -10,7 +10,7 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f)
         FVB_SPATIAL_CASE(ExpModel, "exp", 2)
         FVB_SPATIAL_CASE(ExpModel, "exp", 4)
     default:
-        return SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+        return SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
     }
 }
 } // namespace fvb

@@ -14,7 +14,7 @@ import numpy as np
 
 FVB_MAX_PARAMS = 16
 FVB_MAX_PHIS = 8
-FVB_ABI_VERSION = 3
+FVB_ABI_VERSION = 4
 
 MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
 TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)
@@ -291,6 +291,9 @@ class FvbSpatial(C.Structure):
         ("spatial_speed", C.c_double),
         ("q1", C.c_double),
         ("q2", C.c_double),
+        ("owned_begin", C.c_int32),
+        ("owned_end", C.c_int32),
+        ("n_voxels_global", C.c_int32),
     ]
 
 
@@ -304,7 +307,8 @@ def grid_coords(shape, mask=None):
 
 
 class SpatialHolder:
-    def __init__(self, coords, spatial_dims=3, spatial_speed=-1.0, q1=10.0, q2=1.0, update_first_iter=False):
+    def __init__(self, coords, spatial_dims=3, spatial_speed=-1.0, q1=10.0, q2=1.0, update_first_iter=False,
+                 owned=None, n_voxels_global=0):
         self.coords = np.ascontiguousarray(coords, dtype=np.int32)
         assert self.coords.ndim == 2 and self.coords.shape[0] == 3
         self.sp = FvbSpatial()
@@ -314,3 +318,5 @@ class SpatialHolder:
         self.sp.spatial_speed = spatial_speed
         self.sp.q1 = q1
         self.sp.q2 = q2
+        self.sp.owned_begin, self.sp.owned_end = owned if owned is not None else (0, 0)
+        self.sp.n_voxels_global = n_voxels_global

@@ -44,7 +44,7 @@ extern "C" {
 
 #define FVB_MAX_PARAMS 16
 #define FVB_MAX_PHIS 8
-#define FVB_ABI_VERSION 3
+#define FVB_ABI_VERSION 4
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
@@ -234,6 +234,11 @@ typedef struct fvb_spatial
     int32_t update_first_iter; /* option update-spatial-prior-on-first-iteration */
     double spatial_speed;    /* option spatial-speed (default -1 = unlimited) */
     double q1, q2;           /* options spatial-q1 (10), spatial-q2 (1) */
+    /* Several GPUs (z-slabs, see the stepwise functions below): this process updates local voxels
+     * [owned_begin, owned_end) only; the others are ghost copies of the neighbouring slabs'
+     * boundary planes. owned_end <= owned_begin (e.g. both 0) = every voxel is owned. */
+    int32_t owned_begin, owned_end;
+    int32_t n_voxels_global; /* voxel count of the whole volume (0 = n_voxels): the V of h_K, priors.cc:321 */
 } fvb_spatial;
 
 /* Same conventions as fabber_vb_run_device / fabber_vb_run_host. The iteration count is
@@ -244,6 +249,37 @@ int32_t fabber_vb_run_spatial_device(const fvb_config *cfg, const fvb_spatial *s
     const fvb_outputs *out, void *stream, void (*progress_cb)(int, int));
 int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
     const fvb_outputs *out, int32_t device, void (*progress_cb)(int, int));
+
+/*
+ * The same run step by step, for callers that put collectives between the steps (one process per
+ * GPU, the volume cut into z-slabs):
+ *
+ *   fabber_vb_spatial_open(cfg, sp, data, out, stream, &run)   geometry, buffers, SetupPerVoxelDists
+ *   for it in 0 .. max_iterations-1:
+ *       if (any spatial prior) and (it > 0 or update_first_iter):
+ *           fabber_vb_spatial_ak_sums(run, sums)        this slab's (trace term, quadratic term) per parameter
+ *           ... all-reduce(SUM) of sums[n_params][2] over the slabs ...
+ *           fabber_vb_spatial_set_ak_sums(run, sums)    a_K from the global sums (priors.cc:314-343)
+ *       fabber_vb_spatial_sweep(run, it)                first sweep level by level, second sweep
+ *       ... halo exchange: fabber_vb_spatial_copy_means() of the owned boundary planes to the
+ *           neighbours, of their planes into the ghost voxels ...
+ *   fabber_vb_spatial_close(run)                        result images of every local voxel, free
+ *
+ * Ghost voxels keep the values of the last exchange during a sweep (block-Jacobi across slab
+ * boundaries, Gauss-Seidel inside a slab). With one process and no ghosts the sequence above is
+ * exactly fabber_vb_run_spatial_device. All pointers except `data`, `out` are host pointers.
+ */
+typedef struct fvb_spatial_run fvb_spatial_run;
+int32_t fabber_vb_spatial_open(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    void *stream, fvb_spatial_run **run);
+int32_t fabber_vb_spatial_ak_sums(fvb_spatial_run *run, double *sums /* [n_params][2] */);
+int32_t fabber_vb_spatial_set_ak_sums(fvb_spatial_run *run, const double *sums /* [n_params][2] */);
+int32_t fabber_vb_spatial_sweep(fvb_spatial_run *run, int32_t iteration);
+/* posterior means [n_params][v_count] and status [v_count] of local voxels [v_begin, v_begin+v_count):
+ * device -> host (to_device = 0) or host -> device (1). Either buffer may be NULL. */
+int32_t fabber_vb_spatial_copy_means(fvb_spatial_run *run, int32_t v_begin, int32_t v_count, double *means, int32_t *status,
+    int32_t to_device);
+int32_t fabber_vb_spatial_close(fvb_spatial_run *run);
 
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);
