@@ -27,6 +27,10 @@ protected:
     bool IsSpatial(FabberRunData &rundata) const;
     /** Resolve model / priors / noise / convergence options into the engine's problem block */
     void BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg);
+    /** Models evaluated on the host: initial posterior of every voxel as an MVN image, and the
+     *  re-centre callback the engine calls (fvb_linearise_fn) */
+    void BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg);
+    static int32_t LineariseCallback(void *user, int32_t n_active, const int32_t *ids, const double *means, double *lin);
 
     NoiseModel *m_noise;
     int m_noise_params;

@@ -104,6 +104,7 @@ struct Vb::EngineStorage
 
 static OptionSpec VB_OPTIONS[] = {
     { "noise", OPT_STR, "Noise model to use (white or ar1)", OPT_REQ, "" },
+    { "host-model", OPT_BOOL, "Evaluate the forward model on the host even if it has a device body (always the case for models from a model library)", OPT_NONREQ, "" },
     { "convergence", OPT_STR, "Name of method for detecting convergence", OPT_NONREQ, "maxits" },
     { "max-iterations", OPT_STR, "number of iterations of VB to use with the maxits convergence detector", OPT_NONREQ, "10" },
     { "min-fchange", OPT_STR, "When using the fchange convergence detector, the change in F to stop at", OPT_NONREQ, "10" },
@@ -220,10 +221,15 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
         throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters are not supported by the MI355X engine");
     cfg.n_params = P;
     DeviceModelSpec spec;
-    st.has_device_model = m_model->GetDeviceModel(spec);
+    // A model without a device body (any model library written for the reference), or any model
+    // when host-model is set, is evaluated on the host: 2P+1 Evaluate calls per voxel and
+    // re-centre, everything else on the GPU (fabber_vb_run_hostmodel_host).
+    st.has_device_model = m_model->GetDeviceModel(spec) && !rundata.GetBool("host-model");
     if (!st.has_device_model)
-        throw FabberInternalError("Model '" + rundata.GetString("model")
-            + "' has no device body (FwdModel::GetDeviceModel) and the host-Jacobian path is not part of this build");
+    {
+        spec = DeviceModelSpec();
+        spec.model = FVB_MODEL_HOSTJAC;
+    }
     cfg.model = spec.model;
     for (int i = 0; i < 4; i++)
     {
@@ -307,6 +313,112 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
                 throw FabberRunDataError("MVNDist::Load - Voxel data does not contain a valid MVN - last value != 1");
         cfg.init_mvn = st.init_mvn.Store();
         rundata.GetStringDefault("continue-from-params", "");
+    }
+}
+
+// ---- host-evaluated models ----------------------------------------------------------------------
+struct HostModelContext
+{
+    Vb *self;
+    FwdModel *model;
+    FabberRunData *rundata;
+    const Matrix *data, *coords, *suppdata;
+    int T, P;
+    string error;
+};
+
+// The initial posterior of every voxel as an MVN image (FwdModel::GetInitialPosterior needs the
+// voxel's data, fwdmodel.cc:284-313; noise from the noise model's initial posterior)
+void Vb::BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg)
+{
+    if (cfg.init_mvn)
+        return; // continue-from-mvn
+    const int P = cfg.n_params, N = cfg.n_phis, n = P + N, V = cfg.n_voxels;
+    const int rows = fabber_vb_mvn_rows(n), nCov = n * (n + 1) / 2;
+    const Matrix &data = rundata.GetMainVoxelData();
+    const Matrix &coords = rundata.GetVoxelCoords();
+    const Matrix &supp = rundata.GetVoxelSuppData();
+    Matrix &img = m_store->init_mvn;
+    img.ReSize(rows, V);
+    for (int r = 0; r < rows; r++)
+        for (int v = 0; v < V; v++)
+            img.at0(r, v) = 0;
+    for (int v = 0; v < V; v++)
+    {
+        if (supp.Ncols() == V)
+            m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)), ColumnVector(supp.Column(v + 1)));
+        else
+            m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)));
+        MVNDist post(P);
+        m_model->GetInitialPosterior(post, rundata);
+        const NEWMAT::SymmetricMatrix &cov = post.GetCovariance();
+        for (int i = 0; i < P; i++)
+        {
+            for (int j = 0; j <= i; j++)
+                img.at0(i * (i + 1) / 2 + j, v) = cov(i + 1, j + 1);
+            img.at0(nCov + i, v) = post.means(i + 1);
+        }
+        for (int k = 0; k < N; k++)
+        {
+            const double b = cfg.noise_post_b[k], c = cfg.noise_post_c[k];
+            const int q = P + k;
+            img.at0(q * (q + 1) / 2 + q, v) = b * b * c; // GammaDist variance / mean, as OutputAsMVN
+            img.at0(nCov + q, v) = b * c;
+        }
+        img.at0(rows - 1, v) = 1;
+    }
+    cfg.init_mvn = img.Store();
+}
+
+// fvb_linearise_fn: LinearizedFwdModel::ReCentre (fwdmodel_linear.cc:126-182) for the active voxels
+int32_t Vb::LineariseCallback(void *user, int32_t n_active, const int32_t *ids, const double *means, double *lin)
+{
+    HostModelContext &cx = *static_cast<HostModelContext *>(user);
+    try
+    {
+        const int T = cx.T, P = cx.P;
+        const bool have_supp = cx.suppdata->Ncols() == cx.data->Ncols();
+        ColumnVector centre(P), pert(P), g, f2, f3;
+        for (int a = 0; a < n_active; a++)
+        {
+            const int v = ids[a];
+            if (have_supp)
+                cx.model->PassData(v + 1, ColumnVector(cx.data->Column(v + 1)), ColumnVector(cx.coords->Column(v + 1)),
+                    ColumnVector(cx.suppdata->Column(v + 1)));
+            else
+                cx.model->PassData(v + 1, ColumnVector(cx.data->Column(v + 1)), ColumnVector(cx.coords->Column(v + 1)));
+            for (int i = 0; i < P; i++)
+                centre(i + 1) = means[(size_t)a * P + i];
+            double *out = lin + (size_t)a * T * (P + 1);
+            cx.model->EvaluateFabber(centre, g, "");
+            if (g.Nrows() != T)
+                throw FabberInternalError("Model returned " + stringify(g.Nrows()) + " timepoints, data has " + stringify(T));
+            for (int t = 0; t < T; t++)
+                out[t] = g(t + 1);
+            for (int i = 0; i < P; i++)
+            {
+                double delta = centre(i + 1) * 1e-5; // :157-161
+                if (delta < 0)
+                    delta = -delta;
+                if (delta < 1e-10)
+                    delta = 1e-10;
+                pert = centre;
+                pert(i + 1) = centre(i + 1) + delta;
+                const double c2 = pert(i + 1);
+                cx.model->EvaluateFabber(pert, f2, "");
+                pert(i + 1) = centre(i + 1) - delta;
+                const double c3 = pert(i + 1);
+                cx.model->EvaluateFabber(pert, f3, "");
+                for (int t = 0; t < T; t++)
+                    out[T + (size_t)t * P + i] = (f2(t + 1) - f3(t + 1)) / (c2 - c3);
+            }
+        }
+        return 0;
+    }
+    catch (std::exception &e)
+    {
+        cx.error = e.what();
+        return 1;
     }
 }
 
@@ -395,6 +507,18 @@ void Vb::DoCalculations(FabberRunData &rundata)
         s_progress_rundata = &rundata;
         rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
         s_progress_rundata = NULL;
+    }
+    else if (!m_store->has_device_model)
+    {
+        if (IsSpatial(rundata))
+            throw FabberInternalError("Spatial VB needs a model with a device body (FwdModel::GetDeviceModel)");
+        LOG << "Vb::Voxelwise calculations on the MI355X engine with the model evaluated on the host, " << m_nvoxels
+            << " voxels x " << cfg.n_times << " timepoints" << endl;
+        BuildInitialMvn(rundata, cfg);
+        HostModelContext ctx = { this, m_model, &rundata, &data, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "" };
+        rc = fabber_vb_run_hostmodel_host(&cfg, data.Store(), &out, device, &Vb::LineariseCallback, &ctx);
+        if (rc == -54 && ctx.error != "")
+            throw FabberInternalError(ctx.error);
     }
     else
     {
@@ -491,9 +615,32 @@ void Vb::SaveResults(FabberRunData &rundata) const
     if (V > 0)
     {
         const Matrix &data = rundata.GetMainVoxelData();
+        const bool host_model = !m_store->has_device_model;
+        if (host_model) // the model prediction can only come from the model's own host code
+            pp.modelfit = pp.residuals = NULL;
         int rc = fabber_vb_postproc_host(&cfg, data.Store(), m_result_image.Store(), &pp, rundata.GetIntDefault("device", 0, 0));
         if (rc != 0)
             throw FabberInternalError(string("MI355X engine failed in post-processing: ") + fabber_vb_last_error());
+        if (host_model && (want_fit || want_resid)) // inference.cc:181-243
+        {
+            const Matrix &coords = rundata.GetVoxelCoords();
+            const int nCov = (P + N) * (P + N + 1) / 2;
+            ColumnVector tmp, means(P);
+            for (int v = 0; v < V; v++)
+            {
+                m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)));
+                for (int k = 0; k < P; k++)
+                    means(k + 1) = m_result_image.at0(nCov + k, v);
+                m_model->EvaluateFabber(means, tmp, "");
+                for (int t = 0; t < T; t++)
+                {
+                    if (want_fit)
+                        fit[(size_t)t * V + v] = tmp(t + 1);
+                    if (want_resid)
+                        resid[(size_t)t * V + v] = data.at0(t, v) - tmp(t + 1);
+                }
+            }
+        }
     }
     for (int k = 0; k < P; k++)
     {

@@ -107,6 +107,9 @@ struct WaveCtx
     bool precValid, covValid;
     double logdetLam;
     bool sv_prec;
+    // Host-evaluated models (vb_hostmodel.h): the linearisation about the current means as the
+    // host computed it - g [T] followed by J [T][P] - instead of the device model bodies.
+    const double *lin;
 };
 
 #define FVB_WAVE_FOR(idx, n) for (int idx = cx.lane; idx < (n); idx += 64)
@@ -204,6 +207,27 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
     const WaveLayout &L = cx.L;
     const int T = L.T, P = L.P, N = L.N, Ps = L.Ps, PT = L.PT;
     double *sh = cx.sh;
+    bool bad_offset = false, bad_jac = false;
+    if (cx.lin)
+    {
+        FVB_WAVE_FOR(i, P)
+        sh[L.ml + i] = sh[L.m + i];
+        FVB_WAVE_FOR(t, T)
+        {
+            const double g = cx.lin[t];
+            sh[L.gl + t] = g;
+            bad_offset |= !is_finite(g);
+            for (int i = 0; i < P; i++)
+            {
+                const double Jti = cx.lin[T + t * P + i];
+                sh[L.J + t * Ps + i] = Jti;
+                bad_jac |= !is_finite(Jti);
+            }
+            sh[L.r + t] = sh[L.y + t] - g;
+        }
+    }
+    else
+    {
     FVB_WAVE_FOR(i, P)
     {
         const int tr = ka.cfg.transform[i];
@@ -228,7 +252,6 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
         }
     }
     wave_sync();
-    bool bad_offset = false, bad_jac = false;
     FVB_WAVE_FOR(t, T)
     {
         const double g = eval_model_runtime(ka.cfg.model, ma, P, t, sh + L.pv);
@@ -244,6 +267,7 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
             bad_jac |= !is_finite(Jti);
         }
         sh[L.r + t] = sh[L.y + t] - g;
+    }
     }
     wave_sync();
     // One output entry per lane; with fewer than 33 entries the spare lanes split each entry's
@@ -597,6 +621,7 @@ __global__ __launch_bounds__(64) void vb_wave_kernel(const KernelArgs ka, const 
     cx.lane = threadIdx.x;
     cx.v = blockIdx.x;
     cx.V = (size_t)ka.cfg.n_voxels;
+    cx.lin = nullptr;
     const int v = cx.v, T = L.T, P = L.P, N = L.N, PP = L.PP;
     const size_t V = cx.V;
     double *sh = cx.sh;

@@ -48,7 +48,7 @@ extern "C" {
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
- * its offset/Jacobian are supplied per iteration by the host (see fabber_vb_hostjac_*). */
+ * its offset / Jacobian are supplied per re-centre by the host (fabber_vb_run_hostmodel_host). */
 enum fvb_model
 {
     FVB_MODEL_POLY = 0,
@@ -280,6 +280,22 @@ int32_t fabber_vb_spatial_sweep(fvb_spatial_run *run, int32_t iteration);
 int32_t fabber_vb_spatial_copy_means(fvb_spatial_run *run, int32_t v_begin, int32_t v_count, double *means, int32_t *status,
     int32_t to_device);
 int32_t fabber_vb_spatial_close(fvb_spatial_run *run);
+
+/*
+ * Voxelwise VB with a forward model that exists only as host code (cfg->model =
+ * FVB_MODEL_HOSTJAC): a FwdModel subclass from a model library written for the reference. The
+ * model is evaluated where it lives - `linearise` is called once per re-centre with the voxels
+ * still running and must fill, for active voxel a (global index voxel_ids[a], Fabber-space means
+ * means[a * n_params + i]), lin[a * n_times * (n_params + 1) ...] with g [n_times] followed by
+ * J [n_times][n_params]: the model prediction and its Jacobian about those means as
+ * LinearizedFwdModel::ReCentre computes them (fwdmodel_linear.cc:126-182). Everything else of the
+ * loop runs on the device. cfg->init_mvn (host pointer) must hold the initial posterior
+ * (FwdModel::GetInitialPosterior + the initial noise posterior), white noise only. Host pointers
+ * throughout; returns 0 or a negative code (-54: the callback returned non-zero).
+ */
+typedef int32_t (*fvb_linearise_fn)(void *user, int32_t n_active, const int32_t *voxel_ids, const double *means, double *lin);
+int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device,
+    fvb_linearise_fn linearise, void *user);
 
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);

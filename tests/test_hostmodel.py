@@ -1,0 +1,116 @@
+"""Forward models that exist only as host code (model libraries written for the reference): the
+model is evaluated on the host, the rest of the VB loop on the GPU (vb_hostmodel.h,
+fabber_vb_run_hostmodel_host). A small third-party-style library (tests/plugins/fwdmodel_bump.cc)
+is compiled against the public headers and loaded with fabber_load_models."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from fabber_core_amd import fabber
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "fabber_core_amd", "csrc", "host")
+LIBDIR = os.path.join(ROOT, "fabber_core_amd", "lib")
+SRC = os.path.join(ROOT, "tests", "plugins", "fwdmodel_bump.cc")
+
+pytestmark = [
+    pytest.mark.skipif(shutil.which("g++") is None, reason="no g++"),
+    pytest.mark.skipif(not os.path.exists(os.path.join(LIBDIR, "libfabbercore_amd.so")), reason="host library not built"),
+]
+
+
+@pytest.fixture(scope="module")
+def plugin(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("plugin") / "libfabber_models_bump.so")
+    cmd = ["g++", "-std=c++17", "-shared", "-fPIC", "-I", HOST, SRC, "-o", out, "-L", LIBDIR, "-lfabbercore_amd",
+           "-Wl,-rpath," + LIBDIR, "-Wl,--no-undefined"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return out
+
+
+def volume(shape, series):
+    return np.broadcast_to(np.asarray(series, dtype=np.float32), tuple(shape) + (len(series),)).copy()
+
+
+def test_plugin_loads_and_describes_itself(plugin):
+    f = fabber.Fabber(model_libs=[plugin])
+    assert {"bump", "mypoly"} <= set(f.get_models())
+    f.set_options({"model": "bump", "noise": "white", "method": "vb"})
+    assert f.get_model_params() == ["amp", "mu", "width"]
+    y = np.asarray(f.model_evaluate([2.0, 5.0, 2.0], 9))
+    assert np.allclose(y, 2.0 * np.exp(-(np.arange(1, 10) - 5.0) ** 2 / 8.0), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_host_evaluated_copy_of_a_builtin_model_matches_the_device_run(plugin):
+    """The library's 'mypoly' is the built-in polynomial model without a device body: same
+    problem, model evaluated on the host vs in the kernel."""
+    rng = np.random.default_rng(1)
+    shape, T = (6, 5, 4), 12
+    t = np.arange(1, T + 1)
+    c = rng.uniform(-3, 3, shape + (3,))
+    data = (c[..., 0:1] + c[..., 1:2] * t + c[..., 2:3] * t * t + rng.normal(0, 0.1, shape + (T,))).astype(np.float32)
+    opts = {"degree": 2, "noise": "white", "method": "vb", "max-iterations": 8, "save-mean": True, "save-mvn": True,
+            "save-free-energy": True, "save-model-fit": True, "save-residuals": True, "save-noise-mean": True}
+    dev = fabber.run(data, dict(opts, model="poly"))
+    host = fabber.run(data, dict(opts, model="mypoly"), model_libs=[plugin])
+    assert "evaluated on the host" in host["log"]
+    for k in ("mean_c0", "mean_c1", "mean_c2", "noise_means", "modelfit", "residuals"):
+        assert np.allclose(host[k], dev[k], rtol=2e-5, atol=1e-5), k
+    assert np.allclose(host["finalMVN"], dev["finalMVN"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(host["freeEnergy"], dev["freeEnergy"], rtol=1e-5)
+    # the same for a built-in model forced onto the host route
+    forced = fabber.run(data, dict(opts, model="poly", **{"host-model": True}))
+    assert np.allclose(forced["finalMVN"], dev["finalMVN"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv", ["pointzeroone", "freduce", "trialmode", "lm"])
+def test_every_convergence_detector_on_the_host_route(conv):
+    """Save / revert / trial iterations survive the cut of the loop at its re-centres: same
+    per-voxel results as the device route of the same (nonlinear) model."""
+    rng = np.random.default_rng(2)
+    shape, T = (8, 8, 4), 50
+    t = np.arange(T) * 0.04
+    amp = np.where(rng.random(shape) < 0.5, 1.0, 0.5)
+    data = (amp[..., None] * np.exp(-t) + rng.normal(0, 0.1, shape + (T,))).astype(np.float32)
+    opts = {"model": "exp", "num-exps": 1, "dt": 0.04, "noise": "white", "method": "vb", "convergence": conv, "max-iterations": 30,
+            "min-fchange": 0.01, "save-mean": True, "save-mvn": True, "save-free-energy": True, "save-free-energy-history": True}
+    dev = fabber.run(data, opts)
+    host = fabber.run(data, dict(opts, **{"host-model": True}))
+    assert host["freeEnergyHistory"].shape == dev["freeEnergyHistory"].shape
+    close = np.isclose(host["freeEnergy"], dev["freeEnergy"], rtol=1e-4, atol=1e-3)
+    assert close.mean() > 0.99      # a voxel whose |dF| sits on the threshold may stop one iteration apart
+    sel = close
+    assert np.allclose(host["mean_amp1"][sel], dev["mean_amp1"][sel], rtol=1e-3)
+    assert np.allclose(host["mean_r1"][sel], dev["mean_r1"][sel], rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_third_party_model_fits_its_data(plugin):
+    rng = np.random.default_rng(3)
+    shape, T = (5, 5, 3), 24
+    t = np.arange(1, T + 1)
+    amp = rng.uniform(2, 4, shape)
+    mu = rng.uniform(8, 16, shape)
+    width = rng.uniform(2.5, 4, shape)
+    clean = amp[..., None] * np.exp(-(t - mu[..., None]) ** 2 / (2 * width[..., None] ** 2))
+    data = (clean + rng.normal(0, 0.02, shape + (T,))).astype(np.float32)
+    out = fabber.run(data, {"model": "bump", "noise": "white", "method": "vb", "max-iterations": 20, "save-mean": True,
+                            "save-model-fit": True, "save-mvn": True}, model_libs=[plugin])
+    assert np.allclose(out["mean_amp"], amp, rtol=0.03)
+    assert np.allclose(out["mean_mu"], mu, atol=0.1)
+    assert np.allclose(np.abs(out["mean_width"]), width, rtol=0.05)
+    assert np.sqrt(np.mean((out["modelfit"] - clean) ** 2)) < 0.02
+    # bad voxels: a series of zeros (log amplitude prior: the model still evaluates) stays finite,
+    # a NaN sample stops that voxel only when allow-bad-voxels is set
+    data[1, 1, 1, 5] = np.nan
+    with pytest.raises(fabber.FabberError):
+        fabber.run(data, {"model": "bump", "noise": "white", "method": "vb", "save-mean": True}, model_libs=[plugin])
+    out = fabber.run(data, {"model": "bump", "noise": "white", "method": "vb", "save-mean": True, "allow-bad-voxels": True},
+                     model_libs=[plugin])
+    assert np.isfinite(out["mean_amp"][0, 0, 0])

@@ -45,12 +45,14 @@ def test_reference_example_model_builds_loads_and_evaluates(plugin):
     assert np.allclose(y, np.exp(-t) + 0.5 * np.exp(-6 * t), rtol=1e-6)
 
 
-def test_model_without_a_device_body_is_refused_loudly(plugin):
-    """The plugin's class knows nothing about FwdModel::GetDeviceModel: the engine must say so
-    rather than fall back to anything."""
+@pytest.mark.skipif(hiplib.available() and hiplib.device_count() > 0, reason="a GPU is present")
+def test_host_evaluated_model_still_needs_the_gpu(plugin):
+    """The plugin's class knows nothing about FwdModel::GetDeviceModel, so its Evaluate runs on the
+    host - but only that: the rest of the loop is the GPU engine, and without a device the run fails
+    with a message instead of falling back to a CPU implementation."""
     f = fabber.Fabber(model_libs=[plugin])
     f.set_options({"model": "exp", "num-exps": 1, "dt": 0.04, "noise": "white", "method": "vb"})
     f.set_extent((2, 2, 1))
     f.set_data("data", np.ones((2, 2, 1, 10), dtype=np.float32))
-    with pytest.raises(fabber.FabberError, match="no device body"):
+    with pytest.raises(fabber.FabberError, match="no HIP device"):
         f.run()
