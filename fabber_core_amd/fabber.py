@@ -40,6 +40,8 @@ def load_library(path=None):
     path = path or DEFAULT_LIB
     if not os.path.exists(path):
         raise RuntimeError("%s not found: run `python -m fabber_core_amd.build`" % path)
+    from . import single_hip_runtime
+    single_hip_runtime()
     L = C.CDLL(path)
     cp, vp = C.c_char_p, C.c_void_p
     L.fabber_new.restype = vp

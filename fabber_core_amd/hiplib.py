@@ -29,6 +29,8 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise HipEngineError("%s not built: run `python -m fabber_core_amd.build` (no CPU fallback exists)" % LIB_PATH)
+        from . import single_hip_runtime
+        single_hip_runtime()
         L = C.CDLL(LIB_PATH)
         cfgp, outp, ppp = C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbOutputs), C.POINTER(vbabi.FvbPostproc)
         L.fabber_vb_mvn_rows.restype = C.c_int32
