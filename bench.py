@@ -225,7 +225,7 @@ def main():
         }
         roofline.update(pmc_traffic(args.workload, V, prob.kernel, args))
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             import oracle
             import parity
             ns = min(args.cpu_sample, V)
