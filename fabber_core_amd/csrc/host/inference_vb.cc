@@ -17,7 +17,9 @@
 
 #include <cstring>
 #include <math.h>
+#include <algorithm>
 #include <memory>
+#include <thread>
 
 using namespace std;
 using NEWMAT::ColumnVector;
@@ -104,6 +106,7 @@ struct Vb::EngineStorage
 
 static OptionSpec VB_OPTIONS[] = {
     { "noise", OPT_STR, "Noise model to use (white or ar1)", OPT_REQ, "" },
+    { "host-model-threads", OPT_INT, "Host threads evaluating a host-side model (0 = as many as the hardware has, at most 16)", OPT_NONREQ, "0" },
     { "host-model", OPT_BOOL, "Evaluate the forward model on the host even if it has a device body (always the case for models from a model library)", OPT_NONREQ, "" },
     { "convergence", OPT_STR, "Name of method for detecting convergence", OPT_NONREQ, "maxits" },
     { "max-iterations", OPT_STR, "number of iterations of VB to use with the maxits convergence detector", OPT_NONREQ, "10" },
@@ -325,6 +328,7 @@ struct HostModelContext
     const Matrix *data, *coords, *suppdata;
     int T, P;
     string error;
+    std::vector<FwdModel *> models; // [0] = the technique's own instance, the rest are per-thread copies
 };
 
 // The initial posterior of every voxel as an MVN image (FwdModel::GetInitialPosterior needs the
@@ -370,56 +374,83 @@ void Vb::BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg)
     cfg.init_mvn = img.Store();
 }
 
-// fvb_linearise_fn: LinearizedFwdModel::ReCentre (fwdmodel_linear.cc:126-182) for the active voxels
+// LinearizedFwdModel::ReCentre (fwdmodel_linear.cc:126-182) for active voxels [a0, a1) with one model instance
+static void linearise_range(HostModelContext &cx, FwdModel *model, int a0, int a1, const int32_t *ids, const double *means, double *lin)
+{
+    const int T = cx.T, P = cx.P;
+    const bool have_supp = cx.suppdata->Ncols() == cx.data->Ncols();
+    ColumnVector centre(P), pert(P), g, f2, f3;
+    for (int a = a0; a < a1; a++)
+    {
+        const int v = ids[a];
+        if (have_supp)
+            model->PassData(v + 1, ColumnVector(cx.data->Column(v + 1)), ColumnVector(cx.coords->Column(v + 1)),
+                ColumnVector(cx.suppdata->Column(v + 1)));
+        else
+            model->PassData(v + 1, ColumnVector(cx.data->Column(v + 1)), ColumnVector(cx.coords->Column(v + 1)));
+        for (int i = 0; i < P; i++)
+            centre(i + 1) = means[(size_t)a * P + i];
+        double *out = lin + (size_t)a * T * (P + 1);
+        model->EvaluateFabber(centre, g, "");
+        if (g.Nrows() != T)
+            throw FabberInternalError("Model returned " + stringify(g.Nrows()) + " timepoints, data has " + stringify(T));
+        for (int t = 0; t < T; t++)
+            out[t] = g(t + 1);
+        for (int i = 0; i < P; i++)
+        {
+            double delta = centre(i + 1) * 1e-5; // :157-161
+            if (delta < 0)
+                delta = -delta;
+            if (delta < 1e-10)
+                delta = 1e-10;
+            pert = centre;
+            pert(i + 1) = centre(i + 1) + delta;
+            const double c2 = pert(i + 1);
+            model->EvaluateFabber(pert, f2, "");
+            pert(i + 1) = centre(i + 1) - delta;
+            const double c3 = pert(i + 1);
+            model->EvaluateFabber(pert, f3, "");
+            for (int t = 0; t < T; t++)
+                out[T + (size_t)t * P + i] = (f2(t + 1) - f3(t + 1)) / (c2 - c3);
+        }
+    }
+}
+
+// fvb_linearise_fn: the active voxels shared out over the host threads, one model instance each
+// (a FwdModel holds the current voxel's data, so instances cannot be shared)
 int32_t Vb::LineariseCallback(void *user, int32_t n_active, const int32_t *ids, const double *means, double *lin)
 {
     HostModelContext &cx = *static_cast<HostModelContext *>(user);
-    try
-    {
-        const int T = cx.T, P = cx.P;
-        const bool have_supp = cx.suppdata->Ncols() == cx.data->Ncols();
-        ColumnVector centre(P), pert(P), g, f2, f3;
-        for (int a = 0; a < n_active; a++)
+    const int nthreads = std::max(1, std::min((int)cx.models.size(), n_active / 64 + 1));
+    std::vector<std::string> errors(nthreads);
+    auto work = [&](int k) {
+        try
         {
-            const int v = ids[a];
-            if (have_supp)
-                cx.model->PassData(v + 1, ColumnVector(cx.data->Column(v + 1)), ColumnVector(cx.coords->Column(v + 1)),
-                    ColumnVector(cx.suppdata->Column(v + 1)));
-            else
-                cx.model->PassData(v + 1, ColumnVector(cx.data->Column(v + 1)), ColumnVector(cx.coords->Column(v + 1)));
-            for (int i = 0; i < P; i++)
-                centre(i + 1) = means[(size_t)a * P + i];
-            double *out = lin + (size_t)a * T * (P + 1);
-            cx.model->EvaluateFabber(centre, g, "");
-            if (g.Nrows() != T)
-                throw FabberInternalError("Model returned " + stringify(g.Nrows()) + " timepoints, data has " + stringify(T));
-            for (int t = 0; t < T; t++)
-                out[t] = g(t + 1);
-            for (int i = 0; i < P; i++)
-            {
-                double delta = centre(i + 1) * 1e-5; // :157-161
-                if (delta < 0)
-                    delta = -delta;
-                if (delta < 1e-10)
-                    delta = 1e-10;
-                pert = centre;
-                pert(i + 1) = centre(i + 1) + delta;
-                const double c2 = pert(i + 1);
-                cx.model->EvaluateFabber(pert, f2, "");
-                pert(i + 1) = centre(i + 1) - delta;
-                const double c3 = pert(i + 1);
-                cx.model->EvaluateFabber(pert, f3, "");
-                for (int t = 0; t < T; t++)
-                    out[T + (size_t)t * P + i] = (f2(t + 1) - f3(t + 1)) / (c2 - c3);
-            }
+            const int a0 = (int)((long long)n_active * k / nthreads), a1 = (int)((long long)n_active * (k + 1) / nthreads);
+            linearise_range(cx, cx.models[k], a0, a1, ids, means, lin);
         }
-        return 0;
-    }
-    catch (std::exception &e)
-    {
-        cx.error = e.what();
-        return 1;
-    }
+        catch (std::exception &e)
+        {
+            errors[k] = e.what();
+        }
+        catch (...)
+        {
+            errors[k] = "unknown exception in the model";
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < nthreads; k++)
+        pool.emplace_back(work, k);
+    work(0);
+    for (size_t k = 0; k < pool.size(); k++)
+        pool[k].join();
+    for (int k = 0; k < nthreads; k++)
+        if (errors[k] != "")
+        {
+            cx.error = errors[k];
+            return 1;
+        }
+    return 0;
 }
 
 // The engine's per-iteration callback carries no context pointer: the run data whose
@@ -515,7 +546,23 @@ void Vb::DoCalculations(FabberRunData &rundata)
         LOG << "Vb::Voxelwise calculations on the MI355X engine with the model evaluated on the host, " << m_nvoxels
             << " voxels x " << cfg.n_times << " timepoints" << endl;
         BuildInitialMvn(rundata, cfg);
-        HostModelContext ctx = { this, m_model, &rundata, &data, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "" };
+        HostModelContext ctx = { this, m_model, &rundata, &data, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
+        // one model instance per host thread (host-model-threads, default: the hardware's, at most 16)
+        int nthreads = rundata.GetIntDefault("host-model-threads", 0, 0, 256);
+        if (nthreads == 0)
+            nthreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+        std::vector<std::unique_ptr<FwdModel> > copies;
+        ctx.models.push_back(m_model);
+        for (int k = 1; k < nthreads; k++)
+        {
+            copies.emplace_back(FwdModel::NewFromName(rundata.GetString("model")));
+            copies.back()->SetLogger(m_log);
+            copies.back()->Initialize(rundata);
+            vector<Parameter> tmp;
+            copies.back()->GetParameters(rundata, tmp); // resolves the transforms EvaluateFabber applies
+            ctx.models.push_back(copies.back().get());
+        }
+        LOG << "Vb::Model evaluations on " << nthreads << " host thread(s)" << endl;
         rc = fabber_vb_run_hostmodel_host(&cfg, data.Store(), &out, device, &Vb::LineariseCallback, &ctx);
         if (rc == -54 && ctx.error != "")
             throw FabberInternalError(ctx.error);
