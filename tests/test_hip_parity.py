@@ -274,3 +274,43 @@ def test_properties_at_full_size():
     gpu = {k: (v[:, idx] if v.ndim == 2 else v[idx]) for k, v in res.items() if isinstance(v, np.ndarray) and k != "f_history"}
     floor = parity.population_stats(ho, cpu, cpu2)
     parity.population(ho, cpu, gpu, floor, what="1e6 sample")
+
+
+def _full_size_properties(h, y, make_small, what, sample=4096):
+    """replicated voxels and a sub-block run on its own are bit-identical; a random sample agrees
+    per voxel with the CPU oracle (well-conditioned models)"""
+    V = h.cfg.n_voxels
+    y[:, V - 1] = y[:, 0]
+    y[:, V // 3 + 5] = y[:, 0]
+    res = hipengine.run(h, y)
+    assert np.all(res["status"] == 0)
+    assert np.array_equal(res["mvn"][:, 0], res["mvn"][:, V - 1])
+    assert np.array_equal(res["mvn"][:, 0], res["mvn"][:, V // 3 + 5])
+    lo, hi = V // 2 - 31, V // 2 + 8200
+    sub = hipengine.run(make_small(hi - lo), np.ascontiguousarray(y[:, lo:hi]))
+    assert np.array_equal(sub["mvn"], res["mvn"][:, lo:hi])
+    idx = np.sort(np.random.default_rng(0).choice(V, sample, replace=False))
+    hs = make_small(len(idx))
+    ys = np.ascontiguousarray(y[:, idx])
+    gpu = {k: (v[:, idx] if v.ndim == 2 else v[idx]) for k, v in res.items() if isinstance(v, np.ndarray) and k != "f_history"}
+    # (strict() bounds |d mean| by 1e-6 max(|mean|, sd), or 10x the CPU-vs-CPU floor; a purely relative
+    # figure is meaningless for the Fabber-space means that sit at ~0, e.g. log r of a rate of 1)
+    return parity.strict(hs, oracle.run(hs, ys), gpu, what=what, cpu2=oracle.run_fma(hs, ys))
+
+
+def test_c2_properties_at_full_size():
+    """BASELINE config 2 at its size: 128 x 128 x 64 voxels, single exponential, T = 50."""
+    V = 128 * 128 * 64
+    h, y = cases.exp_problem(V, 50, 1, 0.04, seed=20260102, max_iterations=10)
+    assert hiplib.kernel_name(h) == "lane<exp,2>"
+    _full_size_properties(h, y, lambda n: cases.exp_problem(n, 50, 1, 0.04, seed=1, max_iterations=10)[0], "C2 full size")
+
+
+def test_c4_model_properties_at_two_million_voxels():
+    """BASELINE config 4 model (linear design, AR(1) noise, T = 200) at 2e6 voxels (the 256^3 volume
+    itself is run by bench.py --workload c4 --voxels 16777216)."""
+    V = 2_000_000
+    h, y = cases.linear_problem(V, 200, seed=20260104, max_iterations=10, noise=vbabi.NOISE_AR1)
+    assert hiplib.kernel_name(h) == "lane_ar1<linear,4>"
+    _full_size_properties(h, y, lambda n: cases.linear_problem(n, 200, seed=1, max_iterations=10, noise=vbabi.NOISE_AR1)[0],
+                          "C4 model 2e6", sample=2048)
