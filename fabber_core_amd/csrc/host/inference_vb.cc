@@ -506,6 +506,16 @@ void Vb::DoCalculations(FabberRunData &rundata)
     const int device = rundata.GetIntDefault("device", 0, 0);
     const Matrix &coords = rundata.GetVoxelCoords();
     int rc;
+    if (m_locked_linear)
+    {
+        // In the voxelwise loop the locked centres only serve the set-up re-centre, which the loop
+        // repeats about the posterior means before anything uses it (inference_vb.cc:227-235, :443,
+        // :490): no effect on the results. The spatial loop really keeps them (:695).
+        if (spatial)
+            throw InvalidOptionValue("locked-linear-from-mvn", rundata.GetString("locked-linear-from-mvn"),
+                "Fixed linearisation centres are not supported with spatial VB by the MI355X engine");
+        LOG << "Vb::locked-linear-from-mvn has no effect on voxelwise VB (the loop re-centres about the posterior means)" << endl;
+    }
     if (spatial)
     {
         // Vb::DoCalculationsSpatial (inference_vb.cc:578-767): whole-volume sweeps with the counting
