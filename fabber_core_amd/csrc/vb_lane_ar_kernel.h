@@ -114,7 +114,7 @@ __device__ __forceinline__ void ar_forms(const VoxelState<P> &st, const ArMoment
 // The streaming pass: model + finite-difference Jacobian about `centre`, AR moments
 template <class Model, int P>
 __device__ __forceinline__ int recentre_ar(
-    const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P], ArMoments<P> &mo)
+    const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P], ArMoments<P> &mo, bool precise = false)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int T = ka.cfg.n_times;
@@ -153,26 +153,21 @@ __device__ __forceinline__ int recentre_ar(
     for (int i = 0; i < P; i++)
         Jp[i] = 0;
     double y_next = load_data(ka, (size_t)v);
+    typename Model::Sweep sweep;
+    sweep.init(ma, tp, tp2, tp3);
+    sweep.set_precise(precise);
     for (int t = 0; t < T; t++)
     {
         const double y_cur = y_next;
         if (t + 1 < T)
             y_next = load_data(ka, (size_t)(t + 1) * V + v);
-        const double g = Model::eval(ma, t, tp);
-        double J[P];
+        double g, f2[P], f3[P], J[P];
+        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
             FVB_NO_CONTRACT
-            double q[P];
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                q[j] = tp[j];
-            q[i] = tp2[i];
-            const double f2 = Model::eval(ma, t, q);
-            q[i] = tp3[i];
-            const double f3 = Model::eval(ma, t, q);
-            J[i] = (f2 - f3) * rden[i];
+            J[i] = (f2[i] - f3[i]) * rden[i];
             bad_jac |= !is_finite(J[i]);
         }
         bad_offset |= !is_finite(g);
@@ -237,26 +232,21 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
     }
     double sum_all = 0, cross = 0, k_first = 0, k_prev = 0;
     double y_next = load_data(ka, (size_t)v);
+    typename Model::Sweep sweep;
+    sweep.init(ma, tp, tp2, tp3);
     for (int t = 0; t < T; t++)
     {
         const double y_cur = y_next;
         if (t + 1 < T)
             y_next = load_data(ka, (size_t)(t + 1) * V + v);
-        const double g = Model::eval(ma, t, tp);
+        double g, f2[P], f3[P];
+        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
         double Jd = 0;
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
             FVB_NO_CONTRACT
-            double q[P];
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                q[j] = tp[j];
-            q[i] = tp2[i];
-            const double f2 = Model::eval(ma, t, q);
-            q[i] = tp3[i];
-            const double f3 = Model::eval(ma, t, q);
-            Jd += ((f2 - f3) * rden[i]) * nd[i];
+            Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
         }
         const double k = y_cur - g + Jd;
         sum_all += k * k;
@@ -560,7 +550,7 @@ __global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_ar_kernel
     int hist_len = 0;
     bool setup_failed = false;
 
-    status = recentre_ar<Model, P>(ka, ma, v, st.m, mo);
+    status = recentre_ar<Model, P>(ka, ma, v, st.m, mo, true);
     if (status != FVB_OK)
         setup_failed = true;
 

@@ -69,12 +69,66 @@ struct PointwiseSweep
     }
 };
 
+// Sweep for a model that is linear in each of its parameters, f = sum_n basis_n(t) p_n (the
+// polynomial and the design-matrix model): the perturbed predictions are f(tp) plus the basis
+// function times the perturbation, one multiply-add each instead of a full evaluation -
+// f2_i = g + b_i (tp2_i - tp_i). In exact arithmetic that IS f(tp with tp2_i); in floating point
+// it differs from the full sum by its rounding, ~1e-16 |g|, i.e. by as much as two evaluations of
+// the reference's own sum differ under re-association. Pointwise when set_precise(true).
+template <class Model, int P>
+struct LinearInParameterSweep
+{
+    double d2[P], d3[P];
+    bool precise;
+    FVB_HD void init(const ModelArgs &, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P])
+    {
+        precise = false;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            d2[i] = tp2[i] - tp[i];
+            d3[i] = tp3[i] - tp[i];
+        }
+    }
+    FVB_HD void set_precise(bool p)
+    {
+        precise = p;
+    }
+    FVB_HD void eval(const ModelArgs &ma, int t, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P],
+        double &g, double (&f2)[P], double (&f3)[P])
+    {
+        FVB_NO_CONTRACT
+        if (precise) // wave-uniform
+        {
+            PointwiseSweep<Model, P> pw;
+            pw.eval(ma, t, tp, tp2, tp3, g, f2, f3);
+            return;
+        }
+        g = Model::eval(ma, t, tp);
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            const double b = Model::basis(ma, t, i);
+            f2[i] = g + b * d2[i];
+            f3[i] = g + b * d3[i];
+        }
+    }
+};
+
 // fwdmodel_poly.cc:62-80. The reference accumulates i^n in an int.
 template <int P>
 struct PolyModel
 {
     static constexpr int model_id = FVB_MODEL_POLY;
-    typedef PointwiseSweep<PolyModel<P>, P> Sweep;
+    typedef LinearInParameterSweep<PolyModel<P>, P> Sweep;
+    // d f / d p_n at timepoint t (the model is linear in every parameter)
+    static FVB_HD double basis(const ModelArgs &, int t, int n)
+    {
+        int pw = 1;
+        for (int k = 0; k < n; k++)
+            pw *= t + 1;
+        return (double)pw;
+    }
     static FVB_HD double eval(const ModelArgs &, int t, const double (&p)[P])
     {
         FVB_NO_CONTRACT
@@ -100,7 +154,11 @@ template <int P>
 struct LinearModel
 {
     static constexpr int model_id = FVB_MODEL_LINEAR;
-    typedef PointwiseSweep<LinearModel<P>, P> Sweep;
+    typedef LinearInParameterSweep<LinearModel<P>, P> Sweep;
+    static FVB_HD double basis(const ModelArgs &a, int t, int n)
+    {
+        return a.design[(size_t)t * P + n];
+    }
     static FVB_HD double eval(const ModelArgs &a, int t, const double (&p)[P])
     {
         FVB_NO_CONTRACT
