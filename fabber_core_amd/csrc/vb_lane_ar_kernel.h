@@ -152,15 +152,10 @@ __device__ __forceinline__ int recentre_ar(
 #pragma unroll
     for (int i = 0; i < P; i++)
         Jp[i] = 0;
-    double y_next = load_data(ka, (size_t)v);
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(precise);
-    for (int t = 0; t < T; t++)
-    {
-        const double y_cur = y_next;
-        if (t + 1 < T)
-            y_next = load_data(ka, (size_t)(t + 1) * V + v);
+    auto step = [&](int t, double y_cur) {
         double g, f2[P], f3[P], J[P];
         sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
 #pragma unroll
@@ -197,7 +192,8 @@ __device__ __forceinline__ int recentre_ar(
         for (int i = 0; i < P; i++)
             Jp[i] = J[i];
         rp = r;
-    }
+    };
+    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
 #pragma unroll
     for (int i = 0; i < P; i++)
         mo.JT[i] = Jp[i];
@@ -231,14 +227,9 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
         nd[i] = mo.ml[i] - m[i];
     }
     double sum_all = 0, cross = 0, k_first = 0, k_prev = 0;
-    double y_next = load_data(ka, (size_t)v);
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
-    for (int t = 0; t < T; t++)
-    {
-        const double y_cur = y_next;
-        if (t + 1 < T)
-            y_next = load_data(ka, (size_t)(t + 1) * V + v);
+    auto step = [&](int t, double y_cur) {
         double g, f2[P], f3[P];
         sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
         double Jd = 0;
@@ -254,7 +245,8 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
         if (t == 0)
             k_first = k;
         k_prev = k;
-    }
+    };
+    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
     kk00 = sum_all - k_first * k_first;
     kk20 = sum_all - k_prev * k_prev;
     kk10 = -2 * cross;

@@ -82,52 +82,71 @@ __device__ __forceinline__ double load_data(const KernelArgs &ka, size_t idx)
 }
 
 // Software pipeline over a voxel's time series. At a million voxels the image (400 MB) does not
-// stay in the Infinity Cache between iterations, so every pass re-reads it from HBM (~2 us under
-// load) while one timepoint is only ~0.3 us of arithmetic: the sample for t + DEPTH is requested
-// while t is processed and travels through a shift register (DEPTH register moves per step, no
-// unrolling). Loads return in order, so the wait before using the oldest leaves DEPTH - 1 in
-// flight.
+// stay in L2 between iterations, so every pass re-reads it from the Infinity Cache / HBM while one
+// timepoint is only ~0.2 us of arithmetic: the sample for t + DEPTH is requested while t is
+// processed. The loop body is instantiated DEPTH times so that slot j of the pipe is a fixed
+// register in copy j (a register that a load is still writing cannot be moved), and the loop is
+// instantiated per element type with the loads of its main part unconditional, so that the
+// compiler's wait before using the oldest sample leaves the younger loads in flight.
 #ifndef FVB_PREFETCH_DEPTH
 #define FVB_PREFETCH_DEPTH 2
 #endif
+template <typename RAW>
 struct DataPipe
 {
     static constexpr int D = FVB_PREFETCH_DEPTH;
-    // raw bits as loaded (float -> double conversion would have to wait for the load)
-    unsigned long long q[D];
-    static __device__ __forceinline__ unsigned long long load_raw(const KernelArgs &ka, size_t idx)
-    {
-        return ka.cfg.data_f64 ? ((const unsigned long long *)ka.data)[idx]
-                               : (unsigned long long)((const unsigned int *)ka.data)[idx];
-    }
+    RAW q[D]; // as loaded (the float -> double conversion would have to wait for the load)
+    const RAW *p;
     __device__ __forceinline__ void start(const KernelArgs &ka, int v, size_t V, int T)
     {
+        p = (const RAW *)ka.data + v;
 #pragma unroll
         for (int j = 0; j < D; j++)
-            q[j] = (j < T) ? load_raw(ka, (size_t)j * V + v) : 0ull;
+            q[j] = (j < T) ? p[(size_t)j * V] : RAW(0);
     }
     // sample t (which sits in slot j = t % D); the slot is refilled with sample t + D at once
-    __device__ __forceinline__ double take(const KernelArgs &ka, int v, size_t V, int T, int t, int j)
+    __device__ __forceinline__ double take_and_refill(size_t V, int t, int j)
     {
-        const unsigned long long raw = q[j];
+        const RAW raw = q[j];
+        q[j] = p[(size_t)(t + D) * V];
+        return (double)raw;
+    }
+    __device__ __forceinline__ double take(size_t V, int T, int t, int j)
+    {
+        const RAW raw = q[j];
         if (t + D < T)
-            q[j] = load_raw(ka, (size_t)(t + D) * V + v);
-        return ka.cfg.data_f64 ? __longlong_as_double((long long)raw) : (double)__uint_as_float((unsigned int)raw);
+            q[j] = p[(size_t)(t + D) * V];
+        return (double)raw;
     }
 };
 
-// for (t = 0; t < T; t++) BODY(t, y_t) with the data pipeline: D copies of the body, slot j of the
-// pipe being a fixed register in copy j (a register that a load is still writing cannot be moved)
-#define FVB_FOR_EACH_TIMEPOINT(PIPE, KA, VOX, NV, NT, BODY)                                                  \
-    for (int t0_ = 0; t0_ < (NT); t0_ += DataPipe::D)                                                        \
+// for (t = 0; t < T; t++) BODY(t, y_t)
+#define FVB_STREAM_TIMEPOINTS_AS(RAW, KA, VOX, NV, NT, BODY)                                                 \
     {                                                                                                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < DataPipe::D; j_++)                                           \
+        DataPipe<RAW> pipe_;                                                                                 \
+        pipe_.start((KA), (VOX), (NV), (NT));                                                                \
+        constexpr int D_ = DataPipe<RAW>::D;                                                                 \
+        const int n_main_ = ((NT) > D_) ? (((NT)-D_) / D_) * D_ : 0; /* t + D < T for every t below */       \
+        for (int t0_ = 0; t0_ < n_main_; t0_ += D_)                                                          \
         {                                                                                                    \
-            const int t_ = t0_ + j_;                                                                         \
-            if (t_ < (NT))                                                                                   \
-                BODY(t_, (PIPE).take((KA), (VOX), (NV), (NT), t_, j_));                                      \
+            _Pragma("unroll") for (int j_ = 0; j_ < D_; j_++)                                                \
+                BODY(t0_ + j_, pipe_.take_and_refill((NV), t0_ + j_, j_));                                   \
+        }                                                                                                    \
+        for (int t0_ = n_main_; t0_ < (NT); t0_ += D_)                                                       \
+        {                                                                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < D_; j_++)                                                \
+            {                                                                                                \
+                const int t_ = t0_ + j_;                                                                     \
+                if (t_ < (NT))                                                                               \
+                    BODY(t_, pipe_.take((NV), (NT), t_, j_));                                                \
+            }                                                                                                \
         }                                                                                                    \
     }
+#define FVB_FOR_EACH_TIMEPOINT(KA, VOX, NV, NT, BODY)                                                        \
+    if ((KA).cfg.data_f64)                                                                                   \
+        FVB_STREAM_TIMEPOINTS_AS(double, KA, VOX, NV, NT, BODY)                                              \
+    else                                                                                                     \
+        FVB_STREAM_TIMEPOINTS_AS(float, KA, VOX, NV, NT, BODY)
 
 // MVNDist::GetCovariance (dist_mvn.cc:232-265)
 template <int P>
@@ -199,8 +218,6 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
     bool bad_offset = false, bad_jac = false;
     // (one phi here, so the index only marks masked timepoints: not read at all when there are none)
     const uint8_t *phi_index = (ka.n_unmasked == T) ? nullptr : ka.cfg.phi_index;
-    DataPipe pipe;
-    pipe.start(ka, v, V, T);
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(precise);
@@ -241,7 +258,7 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
             mo.s += r * r;
         }
     };
-    FVB_FOR_EACH_TIMEPOINT(pipe, ka, v, V, T, step)
+    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
     if (!phi_index)
     {
         bad_offset = !is_finite(g_total);
@@ -447,8 +464,6 @@ __device__ __forceinline__ double exact_residual(
     double kk = 0;
     // (one phi here, so the index only marks masked timepoints: not read at all when there are none)
     const uint8_t *phi_index = (ka.n_unmasked == T) ? nullptr : ka.cfg.phi_index;
-    DataPipe pipe;
-    pipe.start(ka, v, V, T);
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(mo.precise); // the Jacobian as the re-centre about ml computed it
@@ -469,7 +484,7 @@ __device__ __forceinline__ double exact_residual(
             kk += k * k;
         }
     };
-    FVB_FOR_EACH_TIMEPOINT(pipe, ka, v, V, T, step)
+    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
     return kk;
 }
 
