@@ -193,7 +193,7 @@ __device__ __forceinline__ int recentre_ar(
             Jp[i] = J[i];
         rp = r;
     };
-    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
+    FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
 #pragma unroll
     for (int i = 0; i < P; i++)
         mo.JT[i] = Jp[i];
@@ -246,7 +246,7 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
             k_first = k;
         k_prev = k;
     };
-    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
+    FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
     kk00 = sum_all - k_first * k_first;
     kk20 = sum_all - k_prev * k_prev;
     kk10 = -2 * cross;
@@ -445,7 +445,7 @@ __device__ __forceinline__ void restore_alpha(const KernelArgs &ka, int v, ArAlp
 }
 
 template <class Model, int P, bool NEEDF>
-__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_ar_kernel(const KernelArgs ka)
+__global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int v = blockIdx.x * 64 + threadIdx.x;

@@ -24,12 +24,34 @@
 #include "vb_math.h"
 #include "vb_models.h"
 
-// Minimum waves per SIMD the register allocator must leave room for (2nd argument of
-// __launch_bounds__ = waves per SIMD/EU on gfx950). One wave alone cannot keep a SIMD's fp64
-// pipe busy; see DESIGN.md section 4 for the measured effect.
-#ifndef FVB_LANE_WAVES_PER_SIMD
-#define FVB_LANE_WAVES_PER_SIMD 3
+// Waves per SIMD the register allocator must leave room for (2nd argument of __launch_bounds__ =
+// waves per SIMD/EU on gfx950) and depth of the data pipeline, per parameter count. Measured on
+// MI355X: with P <= 2 the streaming loop fits 170 VGPRs, so three waves
+// and a short pipeline win (C2: 1.42 ms vs 1.58 ms); from P = 3 the loop alone needs ~130 VGPRs,
+// three waves spill ~20 GB per launch and two waves with a deeper pipeline are both faster and
+// quieter on HBM (C3: 21.0 ms / 6 GB of spills vs 22.2 ms / 20 GB; C4 model 17.3 vs 18.6 ms).
+// FVB_LANE_WAVES_PER_SIMD / FVB_PREFETCH_DEPTH override both for experiments.
+namespace fvb
+{
+template <int P>
+constexpr int lane_waves()
+{
+#ifdef FVB_LANE_WAVES_PER_SIMD
+    return FVB_LANE_WAVES_PER_SIMD;
+#else
+    return P <= 2 ? 3 : 2;
 #endif
+}
+template <int P>
+constexpr int lane_prefetch_depth()
+{
+#ifdef FVB_PREFETCH_DEPTH
+    return FVB_PREFETCH_DEPTH;
+#else
+    return P <= 2 ? 2 : 4;
+#endif
+}
+} // namespace fvb
 
 namespace fvb
 {
@@ -88,13 +110,10 @@ __device__ __forceinline__ double load_data(const KernelArgs &ka, size_t idx)
 // register in copy j (a register that a load is still writing cannot be moved), and the loop is
 // instantiated per element type with the loads of its main part unconditional, so that the
 // compiler's wait before using the oldest sample leaves the younger loads in flight.
-#ifndef FVB_PREFETCH_DEPTH
-#define FVB_PREFETCH_DEPTH 2
-#endif
-template <typename RAW>
+template <typename RAW, int DEPTH>
 struct DataPipe
 {
-    static constexpr int D = FVB_PREFETCH_DEPTH;
+    static constexpr int D = DEPTH;
     RAW q[D]; // as loaded (the float -> double conversion would have to wait for the load)
     const RAW *p;
     __device__ __forceinline__ void start(const KernelArgs &ka, int v, size_t V, int T)
@@ -121,11 +140,11 @@ struct DataPipe
 };
 
 // for (t = 0; t < T; t++) BODY(t, y_t)
-#define FVB_STREAM_TIMEPOINTS_AS(RAW, KA, VOX, NV, NT, BODY)                                                 \
+#define FVB_STREAM_TIMEPOINTS_AS(RAW, DEPTH, KA, VOX, NV, NT, BODY)                                                 \
     {                                                                                                        \
-        DataPipe<RAW> pipe_;                                                                                 \
+        DataPipe<RAW, DEPTH> pipe_;                                                                               \
         pipe_.start((KA), (VOX), (NV), (NT));                                                                \
-        constexpr int D_ = DataPipe<RAW>::D;                                                                 \
+        constexpr int D_ = DEPTH;                                                                           \
         const int n_main_ = ((NT) > D_) ? (((NT)-D_) / D_) * D_ : 0; /* t + D < T for every t below */       \
         for (int t0_ = 0; t0_ < n_main_; t0_ += D_)                                                          \
         {                                                                                                    \
@@ -142,11 +161,11 @@ struct DataPipe
             }                                                                                                \
         }                                                                                                    \
     }
-#define FVB_FOR_EACH_TIMEPOINT(KA, VOX, NV, NT, BODY)                                                        \
+#define FVB_FOR_EACH_TIMEPOINT(DEPTH, KA, VOX, NV, NT, BODY)                                                 \
     if ((KA).cfg.data_f64)                                                                                   \
-        FVB_STREAM_TIMEPOINTS_AS(double, KA, VOX, NV, NT, BODY)                                              \
+        FVB_STREAM_TIMEPOINTS_AS(double, DEPTH, KA, VOX, NV, NT, BODY)                                       \
     else                                                                                                     \
-        FVB_STREAM_TIMEPOINTS_AS(float, KA, VOX, NV, NT, BODY)
+        FVB_STREAM_TIMEPOINTS_AS(float, DEPTH, KA, VOX, NV, NT, BODY)
 
 // MVNDist::GetCovariance (dist_mvn.cc:232-265)
 template <int P>
@@ -258,7 +277,7 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
             mo.s += r * r;
         }
     };
-    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
+    FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
     if (!phi_index)
     {
         bad_offset = !is_finite(g_total);
@@ -484,7 +503,7 @@ __device__ __forceinline__ double exact_residual(
             kk += k * k;
         }
     };
-    FVB_FOR_EACH_TIMEPOINT(ka, v, V, T, step)
+    FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
     return kk;
 }
 
@@ -589,7 +608,8 @@ template <int P, bool NEEDF>
 struct ParkPlan
 {
     static constexpr int PT = P * (P + 1) / 2;
-    static constexpr int BUDGET = 26;
+    // rows of 512 B that fit a wave's share of the CU's 160 KB of LDS at lane_waves<P>() waves per SIMD
+    static constexpr int BUDGET = lane_waves<P>() >= 3 ? 26 : 38;
     static constexpr int SIG = 0;
     static constexpr bool HAS_LAM = NEEDF && (2 * PT <= BUDGET);
     static constexpr int LAM = PT;
@@ -812,7 +832,7 @@ __device__ __forceinline__ void restore_state(const KernelArgs &ka, int v, Voxel
 }
 
 template <class Model, int P, bool NEEDF>
-__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_lane_kernel(const KernelArgs ka)
+__global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int v = blockIdx.x * 64 + threadIdx.x;

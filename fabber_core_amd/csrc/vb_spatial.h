@@ -143,7 +143,7 @@ __device__ __forceinline__ bool is_spatial_type(int t)
 
 // ---- setup: Vb::SetupPerVoxelDists (inference_vb.cc:207-247), one lane per voxel --------------
 template <class Model, int P>
-__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_spatial_setup_kernel(const SpatialArgs sa)
+__global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(const SpatialArgs sa)
 {
     const KernelArgs &ka = sa.ka;
     constexpr int PT = P * (P + 1) / 2;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
 
 // ---- second sweep: UpdateNoise, ReCentre, F (inference_vb.cc:674-722), all voxels -------------
 template <class Model, int P, bool NEEDF>
-__global__ __launch_bounds__(64, FVB_LANE_WAVES_PER_SIMD) void vb_spatial_noise_kernel(const SpatialArgs sa)
+__global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(const SpatialArgs sa)
 {
     const KernelArgs &ka = sa.ka;
     const int v = sa.owned_begin + blockIdx.x * 64 + threadIdx.x;
