@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+struct fvb_config;
+
 class InferenceTechnique : public Loggable
 {
 public:
@@ -28,6 +30,12 @@ public:
     virtual void SaveResults(FabberRunData &rundata) const;
 
 protected:
+    /** finalMVN, mean_/std_/zstat_/var_<param>, modelfit, residuals, noise images and model extras
+     *  from m_result_image (inference.cc:112-281), computed by the engine's post-processing kernel.
+     *  n_noise = noise entries in the MVN, n_noise_saved = how many go to noise_means/_stdevs. */
+    void SaveEngineResults(FabberRunData &rundata, const fvb_config &cfg, const std::vector<Parameter> &params,
+        int n_noise, int n_noise_saved, bool host_model) const;
+
     FwdModel *m_model;
     int m_num_params;
     bool m_halt_bad_voxel;

@@ -1,0 +1,199 @@
+// inference_nlls.cc - the "nlls" technique: host driver of the engine's non-linear least squares
+// kernel (csrc/vb_nlls_kernel.h). Replaces NLLSInferenceTechnique::Initialize / DoCalculations of
+// the reference (inference_nlls.cc:62-214); the per-voxel minimisation, the NLLS precision and
+// the result images are computed on the GPU (fabber_nlls_run_host, fabber_vb_postproc_host).
+// There is no CPU path.
+#include "inference_nlls.h"
+
+#include "version.h"
+
+#include "../../../include/fabber_vb.h"
+
+#include <cstring>
+
+using namespace std;
+using NEWMAT::Matrix;
+
+struct NLLSInferenceTechnique::EngineStorage
+{
+    fvb_config cfg;
+    Matrix design;
+    vector<unsigned char> phi_index;
+    vector<Parameter> params;
+};
+
+static OptionSpec NLLS_OPTIONS[] = {
+    { "vb-init", OPT_BOOL, "Whether NLLS is being run in isolation or as a pre-step for VB", OPT_NONREQ, "" },
+    { "lm", OPT_BOOL, "Whether to use LM convergence (default is L)", OPT_NONREQ, "" },
+    { "" },
+};
+
+InferenceTechnique *NLLSInferenceTechnique::NewInstance()
+{
+    return new NLLSInferenceTechnique();
+}
+
+NLLSInferenceTechnique::NLLSInferenceTechnique()
+    : initialFwdPosterior(NULL)
+    , m_vbinit(false)
+    , m_lm(false)
+    , m_store(new EngineStorage())
+{
+}
+
+NLLSInferenceTechnique::~NLLSInferenceTechnique()
+{
+    delete initialFwdPosterior;
+    delete m_store;
+}
+
+void NLLSInferenceTechnique::GetOptions(vector<OptionSpec> &opts) const
+{
+    for (int i = 0; NLLS_OPTIONS[i].name != ""; i++)
+        opts.push_back(NLLS_OPTIONS[i]);
+}
+
+string NLLSInferenceTechnique::GetDescription() const
+{
+    return "Non-linear least squares inference technique, running on the MI355X engine.";
+}
+
+string NLLSInferenceTechnique::GetVersion() const
+{
+    return fabber_version();
+}
+
+void NLLSInferenceTechnique::Initialize(FwdModel *fwd_model, FabberRunData &rundata)
+{
+    InferenceTechnique::Initialize(fwd_model, rundata);
+    LOG << "NLLSInferenceTechnique::Initialising" << endl;
+    m_vbinit = rundata.GetBool("vb-init");
+
+    // inference_nlls.cc:68-82. NumParams() is the deprecated count the reference uses here; models
+    // that describe themselves through GetParameterDefaults only have m_num_params.
+    const int n = m_num_params;
+    MVNDist *post = new MVNDist(n);
+    MVNDist junk(n);
+    m_model->HardcodedInitialDists(junk, *post);
+    const string file = rundata.GetStringDefault("fwd-inital-posterior", "modeldefault");
+    if (file != "modeldefault")
+    {
+        LOG << "NLLSInferenceTechnique::File posterior" << endl;
+        post->LoadFromMatrix(file);
+    }
+    delete initialFwdPosterior;
+    initialFwdPosterior = post;
+    if (initialFwdPosterior->GetSize() != n)
+        throw FabberInternalError("NLLSInferenceTechnique: starting estimate has " + stringify(initialFwdPosterior->GetSize())
+            + " entries, the model has " + stringify(n) + " parameters");
+    m_lm = rundata.GetBool("lm");
+    LOG << "NLLSInferenceTechnique::Done initialising" << endl;
+}
+
+void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
+{
+    EngineStorage &st = *m_store;
+    fvb_config &cfg = st.cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.abi_version = FVB_ABI_VERSION;
+    const Matrix &data = rundata.GetMainVoxelData();
+    const Matrix &coords = rundata.GetVoxelCoords();
+    cfg.n_voxels = data.Ncols();
+    cfg.n_times = data.Nrows();
+    cfg.data_f64 = 1;
+    // the post-processing kernel reads these as for a VB result without noise entries
+    cfg.noise = FVB_NOISE_WHITE;
+    cfg.n_phis = 0;
+    cfg.convergence = FVB_CONV_MAXITS;
+    cfg.max_iterations = 1;
+
+    st.params.clear();
+    m_model->GetParameters(rundata, st.params);
+    const int P = (int)st.params.size();
+    if (P > FVB_MAX_PARAMS)
+        throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters are not supported by the MI355X engine");
+    cfg.n_params = P;
+    DeviceModelSpec spec;
+    if (!m_model->GetDeviceModel(spec))
+        throw FabberInternalError("method=nlls needs a forward model with a device body (FwdModel::GetDeviceModel); "
+                                  "models from a model library run with method=vb");
+    cfg.model = spec.model;
+    for (int i = 0; i < 4; i++)
+    {
+        cfg.model_iopt[i] = spec.iopt[i];
+        cfg.model_dopt[i] = spec.dopt[i];
+    }
+    if (spec.model == FVB_MODEL_LINEAR)
+    {
+        if (spec.design.Nrows() != cfg.n_times && cfg.n_voxels > 0)
+            throw InvalidOptionValue("basis", stringify(spec.design.Nrows()) + " rows",
+                "Design matrix length does not match the data (" + stringify(cfg.n_times) + " timepoints)");
+        st.design = spec.design;
+        cfg.design = st.design.Store();
+    }
+    for (int k = 0; k < P; k++)
+    {
+        cfg.transform[k] = st.params[k].transform->DeviceCode();
+        cfg.post_mean[k] = initialFwdPosterior->means(k + 1); // Fabber space, as it is (inference_nlls.cc:131)
+    }
+    st.phi_index.clear();
+    if (!m_masked_tpoints.empty()) // MaskRows (inference_nlls.cc:110,152,216-234)
+    {
+        st.phi_index.assign(cfg.n_times, 0);
+        for (size_t i = 0; i < m_masked_tpoints.size(); i++)
+        {
+            const int t = m_masked_tpoints[i];
+            if (t < 1 || t > cfg.n_times)
+                throw InvalidOptionValue("mt" + stringify(i + 1), stringify(t), "Masked timepoint is outside the time series");
+            st.phi_index[t - 1] = 255;
+        }
+        cfg.phi_index = st.phi_index.data();
+    }
+
+    const int V = cfg.n_voxels;
+    m_result_image.ReSize(fabber_vb_mvn_rows(P), V);
+    m_status.assign(V, 0);
+    if (V == 0)
+        return;
+
+    fvb_nlls nl;
+    fabber_nlls_defaults(&nl);
+    nl.lm = m_lm ? 1 : 0; // Levenberg by default, Levenberg-Marquardt with --lm (inference_nlls.cc:124-128)
+    fvb_outputs out;
+    memset(&out, 0, sizeof(out));
+    out.mvn = m_result_image.Store();
+    out.status = m_status.data();
+    vector<int> iterations(V, 0);
+    out.iterations = iterations.data();
+    LOG << "NLLSInferenceTechnique::Calculations on the MI355X engine, " << V << " voxels x " << cfg.n_times << " timepoints, "
+        << (m_lm ? "Levenberg-Marquardt" : "Levenberg") << " damping" << endl;
+    const int rc = fabber_nlls_run_host(&cfg, &nl, data.Store(), &out, rundata.GetIntDefault("device", 0, 0));
+    if (rc != 0)
+        throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
+    rundata.Progress(V, V);
+
+    // per-voxel failures: what the reference's catch block does (inference_nlls.cc:186-207)
+    static const char *reasons[] = { "", "LinearizedFwdModel::ReCentre: Non-finite values found in offset",
+        "LinearizedFwdModel::ReCentre: Non-finite values found in jacobian", "", "NEWMAT exception: matrix is singular" };
+    int n_bad = 0;
+    for (int v = 0; v < V; v++)
+    {
+        const int code = m_status[v] & 0xff;
+        if (code == 0)
+            continue;
+        const string msg = reasons[code < 5 ? code : 4];
+        if (n_bad < 20)
+            LOG << "NLLSInferenceTechnique::NEWMAT Exception in this voxel (" << v + 1 << " at " << coords.at0(0, v) << " "
+                << coords.at0(1, v) << " " << coords.at0(2, v) << "):\n" << msg << endl;
+        n_bad++;
+        if (m_halt_bad_voxel)
+            throw FabberInternalError(msg);
+    }
+    if (n_bad)
+        LOG << "NLLSInferenceTechnique::Estimates in " << n_bad << " voxels may be unreliable (precision matrix set manually)" << endl;
+}
+
+void NLLSInferenceTechnique::SaveResults(FabberRunData &rundata) const
+{
+    SaveEngineResults(rundata, m_store->cfg, m_store->params, 0, 0, false);
+}

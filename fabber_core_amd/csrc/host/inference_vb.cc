@@ -636,13 +636,16 @@ static void save_rows(FabberRunData &rundata, const string &name, const vector<d
     rundata.SaveVoxelData(name, m);
 }
 
-void Vb::SaveResults(FabberRunData &rundata) const
+// InferenceTechnique::SaveResults of the reference (inference.cc:112-281) plus the noise images
+// of Vb::SaveResults (inference_vb.cc:981-994), from the packed result image by the engine's
+// post-processing kernel. N = noise entries in the MVN (0 for NLLS), n_noise_saved = how many of
+// them go into noise_means / noise_stdevs.
+void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_config &cfg, const vector<Parameter> &params,
+    int N, int n_noise_saved, bool host_model) const
 {
-    LOG << "Vb::Preparing to save results..." << endl;
     InferenceTechnique::SaveResults(rundata); // finalMVN
 
-    const fvb_config &cfg = m_store->cfg;
-    const int V = m_nvoxels, P = cfg.n_params, T = cfg.n_times, N = m_noise_params;
+    const int V = cfg.n_voxels, P = cfg.n_params, T = cfg.n_times;
     const bool want_mean = rundata.GetBool("save-mean"), want_std = rundata.GetBool("save-std");
     const bool want_zstat = rundata.GetBool("save-zstat"), want_var = rundata.GetBool("save-var");
     const bool want_nmean = rundata.GetBool("save-noise-mean"), want_nstd = rundata.GetBool("save-noise-std");
@@ -672,7 +675,6 @@ void Vb::SaveResults(FabberRunData &rundata) const
     if (V > 0)
     {
         const Matrix &data = rundata.GetMainVoxelData();
-        const bool host_model = !m_store->has_device_model;
         if (host_model) // the model prediction can only come from the model's own host code
             pp.modelfit = pp.residuals = NULL;
         int rc = fabber_vb_postproc_host(&cfg, data.Store(), m_result_image.Store(), &pp, rundata.GetIntDefault("device", 0, 0));
@@ -701,7 +703,7 @@ void Vb::SaveResults(FabberRunData &rundata) const
     }
     for (int k = 0; k < P; k++)
     {
-        const string &name = m_store->params[k].name;
+        const string &name = params[k].name;
         if (want_mean)
             save_rows(rundata, "mean_" + name, mean, P, k, 1, V);
         if (want_zstat)
@@ -716,9 +718,9 @@ void Vb::SaveResults(FabberRunData &rundata) const
     if (want_fit)
         save_rows(rundata, "modelfit", fit, T, 0, T, V);
     if (want_nmean && N > 0)
-        save_rows(rundata, "noise_means", nmean, N, 0, m_noise->NumParams(), V); // first NumParams() noise entries (inference_vb.cc:981-989)
+        save_rows(rundata, "noise_means", nmean, N, 0, n_noise_saved, V); // first NumParams() noise entries (inference_vb.cc:981-989)
     if (want_nstd && N > 0)
-        save_rows(rundata, "noise_stdevs", nstd, N, 0, m_noise->NumParams(), V);
+        save_rows(rundata, "noise_stdevs", nstd, N, 0, n_noise_saved, V);
 
     // model-specific extra outputs are defined by host code only (FwdModel::EvaluateModel with
     // a key): evaluate them on the host, like inference.cc:181-252
@@ -756,6 +758,13 @@ void Vb::SaveResults(FabberRunData &rundata) const
         }
     }
 
+}
+
+void Vb::SaveResults(FabberRunData &rundata) const
+{
+    LOG << "Vb::Preparing to save results..." << endl;
+    SaveEngineResults(rundata, m_store->cfg, m_store->params, m_noise_params, m_noise->NumParams(), !m_store->has_device_model);
+    const int V = m_nvoxels;
     if (m_saveF && m_needF && !m_free_energy.empty())
     {
         Matrix F(1, V);

@@ -7,6 +7,7 @@
 #include "fwdmodel_linear.h"
 #include "fwdmodel_poly.h"
 #include "inference.h"
+#include "inference_nlls.h"
 #include "inference_vb.h"
 #include "noisemodel.h"
 #include "noisemodel_white.h"
@@ -17,6 +18,7 @@ void FabberSetup::SetupDefaultInferenceTechniques()
     InferenceTechniqueFactory *f = InferenceTechniqueFactory::GetInstance();
     f->Add("vb", &Vb::NewInstance);
     f->Add("spatialvb", &Vb::NewInstance);
+    f->Add("nlls", &NLLSInferenceTechnique::NewInstance);
 }
 void FabberSetup::SetupDefaultNoiseModels()
 {

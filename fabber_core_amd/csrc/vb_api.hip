@@ -43,7 +43,7 @@ int noise_outputs(const fvb_config *cfg)
     return cfg->noise == FVB_NOISE_WHITE ? cfg->n_phis : 3;
 }
 
-int validate(const fvb_config *cfg, bool allow_spatial = false)
+int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_noise = false)
 {
     if (!cfg)
         return fail(-1, "config is NULL");
@@ -53,7 +53,8 @@ int validate(const fvb_config *cfg, bool allow_spatial = false)
         return fail(-3, "bad n_voxels / n_times");
     if (cfg->n_params <= 0 || cfg->n_params > FVB_MAX_PARAMS)
         return fail(-4, "n_params out of range");
-    if (cfg->n_phis <= 0 || cfg->n_phis > FVB_MAX_PHIS)
+    // (a result image without noise entries - method=nlls - can only be post-processed)
+    if ((cfg->n_phis <= 0 && !(allow_no_noise && cfg->n_phis == 0)) || cfg->n_phis > FVB_MAX_PHIS)
         return fail(-5, "n_phis out of range");
     if (cfg->noise != FVB_NOISE_WHITE && cfg->noise != FVB_NOISE_AR1)
         return fail(-6, "noise model not supported by this build");
@@ -439,7 +440,7 @@ int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_ou
 int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp,
     void *stream)
 {
-    int rc = validate(cfg, true); // the output images do not depend on the prior types
+    int rc = validate(cfg, true, true); // the output images do not depend on the prior types
     if (rc)
         return rc;
     if (!mvn || !pp)
@@ -458,7 +459,7 @@ int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const
 int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp,
     int32_t device)
 {
-    int rc = validate(cfg, true);
+    int rc = validate(cfg, true, true);
     if (rc)
         return rc;
     if (fabber_vb_device_count() <= 0)

@@ -1,0 +1,202 @@
+/*
+ * vb_nlls_kernel.h - non-linear least squares (method=nlls), one lane per voxel.
+ *
+ * NLLSInferenceTechnique::DoCalculations (inference_nlls.cc:94-214) minimises, per voxel,
+ * cf(p) = |y - f(p)|^2 (NLLSCF::cf, :223-235) with gradient -2 J'(y - f) (:237-256) and the
+ * Gauss-Newton Hessian 2 J'J (:258-290), J from LinearizedFwdModel::ReCentre, masked timepoints
+ * dropped from y, f and J. The minimiser itself is FSL MISCMATHS `nonlin` (NL_LM), which is not
+ * part of the reference's tree; it is restated here from its published algorithm:
+ *
+ *   cf = cf(p); lambda = 0.1
+ *   up to 200 times:
+ *       H = 2 J'J with the diagonal damped - Levenberg (default): H_ii + lambda;
+ *                                            Levenberg-Marquardt (option lm): H_ii (1 + lambda)
+ *       step = -H^-1 grad ; ncf = cf(p + step)
+ *       if the solve worked and ncf < cf: p += step, lambda /= 10,
+ *            stop if 2 |cf - ncf| <= 1e-8 (|cf| + |ncf| + eps); cf = ncf; new grad / H
+ *       else: lambda *= 10, stop if lambda > 1e20 (grad / H kept)
+ *
+ * The moments pass of the VB lane kernel (recentre(), vb_lane_kernel.h) delivers everything one
+ * iteration needs in ONE sweep over the series: at the trial point p + step it returns
+ * s = |y - f|^2 = ncf together with J'J and J'r, which become the next iteration's H and grad
+ * when the step is accepted (the reference evaluates the model once for cf and 2P + 1 times more
+ * for grad/hess: the same 2P + 1 evaluations, so no work is wasted on accepted steps).
+ *
+ * Result (inference_nlls.cc:150-207): means = p, precisions = J'J / (cf / (N_samples - P)) with
+ * diagonal entries below 1e-6 raised to 1e-6, covariance = inverse; where the model or the
+ * inverse fails: precisions 1e-12 I.
+ */
+#pragma once
+
+#include "vb_lane_kernel.h"
+
+#include <cfloat>
+
+namespace fvb
+{
+struct NllsArgs
+{
+    KernelArgs ka;
+    fvb_nlls nl;
+};
+
+#if defined(__HIPCC__)
+
+template <class Model, int P>
+__global__ __launch_bounds__(64, 2) void nlls_lane_kernel(const NllsArgs na)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const KernelArgs &ka = na.ka;
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    if (v >= ka.cfg.n_voxels)
+        return;
+
+    ModelArgs ma;
+    ma.iopt0 = ka.cfg.model_iopt[0];
+    ma.dopt0 = ka.cfg.model_dopt[0];
+    ma.design = ka.cfg.design;
+
+    // starting estimate, Fabber space (inference_nlls.cc:131-132: the means of the 'posterior'
+    // from HardcodedInitialDists or fwd-inital-posterior are used as they are)
+    double par[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        par[i] = ka.cfg.post_mean[i];
+
+    Moments<P> cur;
+    int status = recentre<Model, P>(ka, ma, v, par, cur, true);
+    double cf = cur.s;
+    double lambda = na.nl.lambda0;
+    int niter = 0;
+    bool running = (status == FVB_OK);
+    while (running && niter < na.nl.max_iterations)
+    {
+        niter++;
+        double H[PT], Hinv[PT];
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            H[i] = 2.0 * cur.A[i];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            if (na.nl.lm)
+                H[tri(i, i)] *= (1.0 + lambda);
+            else
+                H[tri(i, i)] += lambda;
+        }
+        double logabs;
+        int sign;
+        bool solved = ldl_inverse<P>(H, Hinv, logabs, sign);
+        double trial[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            double step = 0;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                step += Hinv[tri(i, j)] * (2.0 * cur.u[j]); // -H^-1 grad, grad = -2 J'r
+            solved = solved && is_finite(step);
+            trial[i] = par[i] + step;
+        }
+        if (!solved) // keep the model evaluation below away from non-finite parameters
+        {
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                trial[i] = par[i];
+        }
+        Moments<P> tr;
+        const int st = recentre<Model, P>(ka, ma, v, trial, tr, true);
+        const double ncf = tr.s;
+        if (solved && ncf < cf) // (a non-finite ncf compares false, as in the reference)
+        {
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                par[i] = trial[i];
+            cur = tr;
+            lambda *= 0.1;
+            const bool converged = 2.0 * fabs(cf - ncf) <= na.nl.cf_tolerance * (fabs(cf) + fabs(ncf) + DBL_EPSILON);
+            cf = ncf;
+            if (st != FVB_OK) // the next gradient's ReCentre throws (fwdmodel_linear.cc:134-181)
+            {
+                status = st;
+                running = false;
+            }
+            if (converged)
+                running = false;
+        }
+        else
+        {
+            lambda *= 10.0;
+            if (lambda > na.nl.lambda_max)
+                running = false;
+        }
+    }
+
+    // ---- the NLLS precision (inference_nlls.cc:160-184) ----
+    double cov[PT];
+    bool fallback = (status != FVB_OK);
+    if (!fallback)
+    {
+        const double mse = cf / (double)(ka.n_unmasked - P);
+        double prec[PT];
+        bool finite = true;
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+        {
+            prec[i] = cur.A[i] / mse;
+            finite = finite && is_finite(prec[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if (prec[tri(i, i)] < 1e-6)
+                prec[tri(i, i)] = 1e-6;
+        double logabs;
+        int sign;
+        bool ok = finite && mvn_invert<P>(prec, cov, logabs, sign);
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            ok = ok && is_finite(cov[i]);
+        if (!ok)
+        {
+            fallback = true;
+            // a perfect fit (mse = 0) or T = P leaves no finite precision: that is not a failure
+            // of the voxel, it just gets the uninformative precision of the catch branch
+            if (finite)
+                status = FVB_BAD_RESULT;
+        }
+    }
+    if (fallback) // inference_nlls.cc:186-207: precisions 1e-12 I
+    {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++)
+                cov[tri(i, j)] = (i == j) ? 1e12 : 0.0;
+    }
+    double *dst = ka.out.mvn + v;
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        dst[(size_t)i * V] = cov[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        dst[(size_t)(PT + i) * V] = par[i];
+    dst[(size_t)(PT + P) * V] = 1.0;
+    if (ka.out.status)
+        ka.out.status[v] = status;
+    if (ka.out.iterations)
+        ka.out.iterations[v] = niter;
+    if (ka.out.free_energy) // no free energy in NLLS: the final sum of squares is reported here
+        ka.out.free_energy[v] = cf;
+}
+
+#endif // __HIPCC__
+
+typedef void (*NllsKernelFn)(const NllsArgs);
+struct NllsKernelInfo
+{
+    NllsKernelFn fn;
+    const char *name;
+};
+NllsKernelInfo get_nlls_kernel(int model, int P);
+} // namespace fvb

@@ -208,3 +208,79 @@ def run(data, options, mask=None, extra_data=None, outputs=None, lib_path=None, 
             if fab.data_size(name) >= 0:
                 result[name] = fab.get_data(name)
         return result
+
+
+# ---- model validation workflow (py/fabber.py:41-176, doc/models.rst "testing your model") ----
+
+def _value_list(values):
+    return [float(v) for v in values] if np.ndim(values) else [float(values)]
+
+
+def generate_test_data(options, param_testvalues, nt=10, patchsize=10, noise=None, seed=None, lib_path=None, model_libs=()):
+    """Synthetic volume made of cubic patches, one per combination of the parameters that were
+    given several test values (at most three such parameters: one per axis); every voxel of a
+    patch holds the model's prediction for that combination (py/fabber.py:105-176).
+
+    -> dict(data, clean, patch_rois, param_rois): `data` = clean + N(0, noise²) when `noise` is
+    given, `patch_rois` labels the patches 1.., `param_rois[p]` holds 1 + the index of p's value."""
+    with Fabber(lib_path, model_libs) as fab:
+        fab.set_options(options)
+        names = fab.get_model_params()
+        unknown = set(param_testvalues) - set(names)
+        if unknown:
+            raise ValueError("not parameters of model %s: %s" % (options.get("model"), sorted(unknown)))
+        values = {p: _value_list(param_testvalues.get(p, 0.0)) for p in names}
+        axes = [p for p in param_testvalues if len(values[p]) > 1]
+        if len(axes) > 3:
+            raise ValueError("at most 3 parameters may vary, got %d" % len(axes))
+        counts = [len(values[p]) for p in axes] + [1] * (3 - len(axes))
+        shape = tuple(c * patchsize for c in counts)
+        clean = np.zeros(shape + (nt,), dtype=np.float64)
+        patch_rois = np.zeros(shape, dtype=np.int32)
+        param_rois = {p: np.zeros(shape, dtype=np.int32) for p in axes}
+        label = 0
+        for pos in np.ndindex(*counts):
+            block = tuple(slice(i * patchsize, (i + 1) * patchsize) for i in pos)
+            theta = [values[p][pos[axes.index(p)]] if p in axes else values[p][0] for p in names]
+            clean[block] = fab.model_evaluate(theta, nt)
+            label += 1
+            patch_rois[block] = label
+            for a, p in enumerate(axes):
+                param_rois[p][block] = pos[a] + 1
+    data = clean
+    if noise is not None:
+        data = clean + np.random.default_rng(seed).normal(0.0, noise, clean.shape)
+    return {"data": data, "clean": clean, "patch_rois": patch_rois, "param_rois": param_rois}
+
+
+def self_test(model, options, param_testvalues, invert=True, disp=False, lib_path=None, model_libs=(), **kwargs):
+    """Generate test data from the model, fit it and report, per varied parameter, the mean
+    estimate over the voxels generated with each test value (py/fabber.py:41-103).
+
+    -> (report, log): report[param][test value] = mean output; report["noise"][input sd] =
+    1/sqrt(mean noise precision)."""
+    options = dict(options, model=model)
+    test = generate_test_data(options, param_testvalues, lib_path=lib_path, model_libs=model_libs, **kwargs)
+    report, log = {}, None
+    if not invert:
+        return report, log
+    options.setdefault("method", "vb")
+    options.setdefault("noise", "white")
+    options.update({"save-mean": True, "save-noise-mean": True, "save-noise-std": True, "save-model-fit": True,
+                    "allow-bad-voxels": True})
+    out = run(test["data"], options, lib_path=lib_path, model_libs=model_libs)
+    log = out["log"]
+    for param, values in param_testvalues.items():
+        values = _value_list(values)
+        if len(values) < 2:
+            continue
+        roi = test["param_rois"][param]
+        report[param] = {v: float(np.mean(out["mean_" + param][roi == i + 1])) for i, v in enumerate(values)}
+        if disp:
+            for v, got in report[param].items():
+                print("%s: input %g -> %g output" % (param, v, got))
+    noise_in = kwargs.get("noise") or 0.0
+    report["noise"] = {noise_in: float(1.0 / np.sqrt(np.mean(out["noise_means"])))}
+    if disp:
+        print("noise: input %g -> %g output" % (noise_in, report["noise"][noise_in]))
+    return report, log

@@ -63,6 +63,12 @@ def lib():
         L.fabber_vb_transform.argtypes = [C.c_int32, C.c_int32, C.c_double]
         L.fabber_vb_ldl_inverse.restype = C.c_int32
         L.fabber_vb_ldl_inverse.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fabber_nlls_run_host.restype = C.c_int32
+        L.fabber_nlls_run_host.argtypes = [cfgp, C.POINTER(vbabi.FvbNlls), C.c_void_p, outp, C.c_int32]
+        L.fabber_nlls_run_device.restype = C.c_int32
+        L.fabber_nlls_run_device.argtypes = [cfgp, C.POINTER(vbabi.FvbNlls), C.c_void_p, outp, C.c_void_p, C.c_int32]
+        L.fabber_nlls_defaults.restype = None
+        L.fabber_nlls_defaults.argtypes = [C.POINTER(vbabi.FvbNlls)]
         if L.fabber_vb_abi_version() != vbabi.FVB_ABI_VERSION:
             raise HipEngineError("libfabber_vb_hip.so ABI version mismatch: rebuild")
         _LIB = L
@@ -133,6 +139,26 @@ def run_host(holder, data, device=0):
     _check(lib().fabber_vb_run_host(C.byref(cfg), data.ctypes.data, C.byref(out), device))
     arrs["setup_failed"] = (arrs["status"] & 0x100) != 0
     arrs["status"] = arrs["status"] & 0xFF
+    return arrs
+
+
+def nlls_run_host(holder, data, lm=False, start=None, settings=None, device=0):
+    """method=nlls on the GPU from host arrays. `start` = Fabber-space starting estimate
+    (default zeros, what the built-in models' HardcodedInitialDists leaves). Returns mvn
+    [mvn_rows(P)][V] (parameters only), status, iterations, cost (final sum of squares)."""
+    cfg = holder.cfg
+    data = _prepare_data(holder, data)
+    V, P = cfg.n_voxels, cfg.n_params
+    for p in range(P):
+        cfg.post_mean[p] = 0.0 if start is None else float(start[p])
+    nl = settings or vbabi.FvbNlls.defaults(lm)
+    arrs = dict(mvn=np.full((vbabi.mvn_rows(P), V), np.nan), status=np.full(V, -1, dtype=np.int32),
+                iterations=np.full(V, -1, dtype=np.int32), free_energy=np.full(V, np.nan))
+    out = vbabi.FvbOutputs()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    _check(lib().fabber_nlls_run_host(C.byref(cfg), C.byref(nl), data.ctypes.data, C.byref(out), device))
+    arrs["cost"] = arrs.pop("free_energy")
     return arrs
 
 

@@ -90,6 +90,21 @@ class FvbPostproc(C.Structure):
     ]
 
 
+class FvbNlls(C.Structure):
+    """fvb_nlls (include/fabber_vb.h): settings of the method=nlls minimiser."""
+    _fields_ = [
+        ("lm", C.c_int32),
+        ("max_iterations", C.c_int32),
+        ("cf_tolerance", C.c_double),
+        ("lambda0", C.c_double),
+        ("lambda_max", C.c_double),
+    ]
+
+    @classmethod
+    def defaults(cls, lm=False):
+        return cls(int(lm), 200, 1e-8, 0.1, 1e20)
+
+
 def mvn_rows(n):
     """Rows of the packed MVN image for an n-dimensional MVN (dist_mvn.cc:408)."""
     return n * (n + 1) // 2 + n + 1

@@ -297,6 +297,33 @@ typedef int32_t (*fvb_linearise_fn)(void *user, int32_t n_active, const int32_t 
 int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device,
     fvb_linearise_fn linearise, void *user);
 
+/*
+ * Non-linear least squares, method=nlls (NLLSInferenceTechnique::DoCalculations,
+ * inference_nlls.cc:94-214; cost function / gradient / Gauss-Newton Hessian NLLSCF :223-290). The
+ * minimiser is FSL MISCMATHS nonlin (NL_LM), restated in csrc/vb_nlls_kernel.h. Of fvb_config the
+ * call reads: n_voxels, n_times, n_params, model*, design, transform[], phi_index (255 = masked
+ * timepoint, inference_nlls.cc:110,152), data_f64 and post_mean[] = the starting estimate IN FABBER
+ * SPACE (inference_nlls.cc:131: the means of HardcodedInitialDists' posterior as they are).
+ * Outputs: mvn [fabber_vb_mvn_rows(n_params)][n_voxels] (parameters only, no noise entries),
+ * status, iterations (minimiser iterations), free_energy (if not NULL: the final sum of squares).
+ */
+typedef struct fvb_nlls
+{
+    int32_t lm;             /* option lm: 1 = Levenberg-Marquardt (diagonal scaled by 1 + lambda), 0 = Levenberg
+                               (lambda added to the diagonal; inference_nlls.cc:124-128) */
+    int32_t max_iterations; /* nonlin default 200 */
+    double cf_tolerance;    /* fractional change of the cost that counts as converged, 1e-8 */
+    double lambda0;         /* initial damping, 0.1 */
+    double lambda_max;      /* give up above this damping, 1e20 */
+} fvb_nlls;
+/* nonlin's defaults */
+void fabber_nlls_defaults(fvb_nlls *nl);
+/* Pointer conventions as fabber_vb_run_device / fabber_vb_run_host. */
+int32_t fabber_nlls_run_device(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
+    void *stream, int32_t n_unmasked);
+int32_t fabber_nlls_run_host(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
+    int32_t device);
+
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);
 

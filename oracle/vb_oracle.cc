@@ -1196,6 +1196,7 @@ static inline double load_data(const fvb_config *cfg, const void *data, size_t i
 
 #include "vb_oracle_ar.inc"
 #include "vb_oracle_spatial.inc"
+#include "vb_oracle_nlls.inc"
 
 } // namespace
 
@@ -1463,6 +1464,14 @@ int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, cons
         return -10;
     }
 }
+int32_t oracle_nlls_run(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
+    int32_t v_begin, int32_t v_end, int32_t halt_bad_voxel)
+{
+    if (cfg->abi_version != FVB_ABI_VERSION)
+        return -1;
+    return run_nlls(cfg, nl, data, out, v_begin, v_end, halt_bad_voxel);
+}
+
 const char *oracle_last_error(void)
 {
     return g_oracle_error.c_str();

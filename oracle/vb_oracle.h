@@ -47,6 +47,10 @@ int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double
 /* Vb::DoCalculationsSpatial (inference_vb.cc:578-767), white noise; host pointers. */
 int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out);
 const char *oracle_last_error(void);
+
+/* method=nlls (inference_nlls.cc:94-214), see vb_oracle_nlls.inc; conventions as oracle_vb_run. */
+int32_t oracle_nlls_run(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
+    int32_t v_begin, int32_t v_end, int32_t halt_bad_voxel);
 /* Vb::CalcNeighbours (inference_vb.cc:830-964): nn [n_voxels][6], nn2 [n_voxels][30] 1-based ids
  * (0 = none), n2count [n_voxels]. */
 int32_t oracle_calc_neighbours(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t *nn,

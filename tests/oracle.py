@@ -126,6 +126,31 @@ def run(holder, data, v_begin=0, v_end=None, halt_bad_voxel=False, trace_rows=0,
     return arrs
 
 
+def run_nlls(holder, data, lm=False, start=None, settings=None, halt_bad_voxel=False, _lib=None):
+    """method=nlls on the CPU (oracle/vb_oracle_nlls.inc); same result dict as hiplib.nlls_run_host."""
+    cfg = holder.cfg
+    data = prepare_data(holder, data)
+    V, P = cfg.n_voxels, cfg.n_params
+    for p in range(P):
+        cfg.post_mean[p] = 0.0 if start is None else float(start[p])
+    nl = settings or vbabi.FvbNlls.defaults(lm)
+    arrs = dict(mvn=np.full((vbabi.mvn_rows(P), V), np.nan), status=np.full(V, -1, dtype=np.int32),
+                iterations=np.full(V, -1, dtype=np.int32), free_energy=np.full(V, np.nan))
+    out = vbabi.FvbOutputs()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    L = _lib or lib()
+    L.oracle_nlls_run.restype = C.c_int32
+    L.oracle_nlls_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbNlls), C.c_void_p,
+                                  C.POINTER(vbabi.FvbOutputs), C.c_int32, C.c_int32, C.c_int32]
+    rc = L.oracle_nlls_run(C.byref(cfg), C.byref(nl), data.ctypes.data, C.byref(out), 0, V, int(halt_bad_voxel))
+    if rc < 0:
+        raise RuntimeError("oracle_nlls_run failed: %d" % rc)
+    arrs["first_bad_voxel"] = rc
+    arrs["cost"] = arrs.pop("free_energy")
+    return arrs
+
+
 def postproc(holder, data, mvn, want=("mean", "var", "std", "zstat", "modelfit", "residuals", "noise_mean", "noise_std")):
     cfg = holder.cfg
     V, T, P, N = cfg.n_voxels, cfg.n_times, cfg.n_params, cfg.n_phis

@@ -91,7 +91,7 @@ def test_cli_information_queries(tmp_path):
     r = run_cli("--version")
     assert r.returncode == 0 and r.stdout.startswith("Fabber ")
     assert run_cli("--listmodels").stdout.split() == ["exp", "linear", "poly"]
-    assert run_cli("--listmethods").stdout.split() == ["spatialvb", "vb"]
+    assert run_cli("--listmethods").stdout.split() == ["nlls", "spatialvb", "vb"]
     assert run_cli("--listparams", "--model=poly", "--degree=2").stdout.split() == ["c0", "c1", "c2"]
     assert run_cli("--listparams", "--model=exp", "--num-exps=2", "--dt=0.1").stdout.split() == ["amp1", "r1", "amp2", "r2"]
     r = run_cli()
