@@ -156,15 +156,11 @@ __device__ __forceinline__ int recentre_ar(
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(precise);
     auto step = [&](int t, double y_cur) {
-        double g, f2[P], f3[P], J[P];
-        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
+        double g, J[P];
+        sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
 #pragma unroll
         for (int i = 0; i < P; i++)
-        {
-            FVB_NO_CONTRACT
-            J[i] = (f2[i] - f3[i]) * rden[i];
             bad_jac |= !is_finite(J[i]);
-        }
         bad_offset |= !is_finite(g);
         const double r = y_cur - g;
 #pragma unroll
@@ -230,14 +226,14 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
     typename Model::Sweep sweep;
     sweep.init(ma, tp, tp2, tp3);
     auto step = [&](int t, double y_cur) {
-        double g, f2[P], f3[P];
-        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
+        double g, J[P];
+        sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
         double Jd = 0;
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
             FVB_NO_CONTRACT
-            Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
+            Jd += J[i] * nd[i];
         }
         const double k = y_cur - g + Jd;
         sum_all += k * k;

@@ -248,14 +248,12 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
     // and timepoint. With masked timepoints, whose J does not enter A, they stay per timepoint.
     double g_total = 0;
     auto step = [&](int t, double y_cur) {
-        double g, f2[P], f3[P], J[P];
-        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
-#pragma unroll
-        for (int i = 0; i < P; i++)
+        double g, J[P];
+        sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
+        if (phi_index)
         {
-            FVB_NO_CONTRACT
-            J[i] = (f2[i] - f3[i]) * rden[i];
-            if (phi_index)
+#pragma unroll
+            for (int i = 0; i < P; i++)
                 bad_jac |= !is_finite(J[i]);
         }
         if (phi_index)
@@ -487,14 +485,14 @@ __device__ __forceinline__ double exact_residual(
     sweep.init(ma, tp, tp2, tp3);
     sweep.set_precise(mo.precise); // the Jacobian as the re-centre about ml computed it
     auto step = [&](int t, double y_cur) {
-        double g, f2[P], f3[P];
-        sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
+        double g, J[P];
+        sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
         double Jd = 0;
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
             FVB_NO_CONTRACT
-            Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
+            Jd += J[i] * nd[i];
         }
         const bool unmasked = phi_index ? (phi_index[t] != 255) : true;
         if (unmasked)

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -512,6 +513,35 @@ struct Linearized
             const double denom = centre2[i] - centre3[i];
             for (int t = 0; t < T; t++)
                 J[(size_t)t * P + i] = (offset2[t] - offset3[t]) / denom; // :170
+        }
+        // Experiment switch (tools/measure/structured_j.py): the same difference quotient for the
+        // exponential model without the cancellation of the unperturbed terms. Never set in tests.
+        static const bool structured = getenv("ORACLE_STRUCTURED_J") != nullptr;
+        if (structured && model->cfg->model == FVB_MODEL_EXP)
+        {
+            const double dt = model->cfg->model_dopt[0];
+            for (int i = 0; i < P; i++)
+            {
+                double delta = centre[i] * 1e-5;
+                if (delta < 0)
+                    delta = -delta;
+                if (delta < 1e-10)
+                    delta = 1e-10;
+                const double c2 = centre[i] + delta, c3 = centre[i] - delta;
+                const int tr = model->cfg->transform[i];
+                const double p2 = to_model(tr, c2), p3 = to_model(tr, c3);
+                const int e = i / 2;
+                const double amp = to_model(model->cfg->transform[2 * e], centre[2 * e]);
+                const double rate = to_model(model->cfg->transform[2 * e + 1], centre[2 * e + 1]);
+                for (int t = 0; t < T; t++)
+                {
+                    const double tt = double(t) * dt;
+                    if (i % 2 == 0)
+                        J[(size_t)t * P + i] = ((p2 - p3) / (c2 - c3)) * std::exp(-rate * tt);
+                    else
+                        J[(size_t)t * P + i] = (std::exp(-p2 * tt) - std::exp(-p3 * tt)) * (amp / (c2 - c3));
+                }
+            }
         }
         for (size_t k = 0; k < J.size(); k++)
             if (!(0 * J[k] == 0 * J[k])) // :174
