@@ -114,6 +114,44 @@ static bool lu_decompose(Mat &lu, std::vector<int> &piv, int &sign)
 static Mat inverse(const Mat &m)
 {
     const int n = m.n;
+    // Experiment switch (tools/measure/structured_j.py): symmetric sweep inverse without pivoting,
+    // the algorithm of the kernels (vb_math.h). Never set in tests.
+    static const bool use_sweep = getenv("ORACLE_SWEEP_INVERSE") != nullptr;
+    if (use_sweep)
+    {
+        Mat w = m;
+        for (int k = 0; k < n; k++)
+        {
+            const double d = w(k, k);
+            if (d == 0.0)
+                throw SingularError();
+            const double rd = 1.0 / d;
+            for (int i = 0; i < n; i++)
+            {
+                if (i == k)
+                    continue;
+                const double cik = w(i, k) * rd;
+                for (int j = 0; j <= i; j++)
+                {
+                    if (j == k)
+                        continue;
+                    w(i, j) -= cik * w(std::max(j, k), std::min(j, k));
+                    w(j, i) = w(i, j);
+                }
+            }
+            for (int i = 0; i < n; i++)
+                if (i != k)
+                {
+                    w(std::max(i, k), std::min(i, k)) *= rd;
+                    w(std::min(i, k), std::max(i, k)) = w(std::max(i, k), std::min(i, k));
+                }
+            w(k, k) = -rd;
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++)
+                w(i, j) = -w(i, j);
+        return w;
+    }
     Mat lu = m;
     std::vector<int> piv;
     int sign;

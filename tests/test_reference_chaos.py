@@ -42,3 +42,32 @@ def test_well_conditioned_models_are_reproducible():
                  cases.linear_problem(300, 200, seed=20260104)):
         e_mean, e_cov, _ = parity.voxel_errors(h, oracle.run(h, y), oracle.run_fma(h, y))
         assert e_mean.max() < 1e-6 and e_cov.max() < 2e-4, (e_mean.max(), e_cov.max())
+
+
+def _bad_fraction(env):
+    """Fraction of voxels of the bi-exponential problem whose run ends with a non-finite
+    prediction, in a fresh process (the oracle reads its experiment switches once)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, cases, oracle\n"
+            "h, y = cases.exp_problem(6000, 100, 2, 0.02, seed=20260103, max_iterations=50)\n"
+            "print(json.dumps(float(np.mean(oracle.run(h, y)['status'] != 0))))\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, check=True)
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_failing_voxels_follow_the_inversion_algorithm():
+    """A few voxels of the bi-exponential fit reach a posterior precision whose condition number
+    exceeds 1e16; what the "inverse" of such a matrix is depends on the algorithm. With the LU
+    inverse (the oracle's restatement of NEWMAT .i()) some of them jump to a non-finite
+    prediction and stop; with the symmetric sweep the kernels use (vb_math.h) none does. This is
+    the documented difference between oracle and HIP path in the count of failed voxels
+     - the GPU tests bound the kernels' count by the oracle's."""
+    lu = _bad_fraction({})
+    sweep = _bad_fraction({"ORACLE_SWEEP_INVERSE": "1"})
+    assert 2e-4 < lu < 5e-3, lu
+    assert sweep < lu / 4, (sweep, lu)
