@@ -1,6 +1,6 @@
 /* noisemodel_ar.h - AR(1) noise model, host description (reference: noisemodel_ar.h).
- * Supported configuration: num-echoes = 1 with ar1-cross-terms = none (the reference's defaults,
- * BASELINE config 4); the updates themselves run in the HIP kernels (../../vb_lane_ar_kernel.h). */
+ * num-echoes = 1 or 2, ar1-cross-terms = none / same / dual; the updates themselves run in the HIP
+ * kernels (../../vb_lane_ar_kernel.h for one echo, ../../vb_wave_ar_kernel.h for every case). */
 #pragma once
 
 #include "dist_gamma.h"

@@ -127,6 +127,7 @@ static OptionSpec VB_OPTIONS[] = {
     { "PSP_byname<n>_transform", OPT_STR, "Transform to apply to parameter <n>", OPT_NONREQ, "" },
     { "allow-bad-voxels", OPT_BOOL, "Continue if numerical error found in a voxel, rather than stopping", OPT_NONREQ, "" },
     { "ar1-cross-terms", OPT_STR, "For AR1 noise, type of cross-linking (dual, same or none)", OPT_NONREQ, "dual" },
+    { "num-echoes", OPT_INT, "For AR1 noise, number of interleaved echoes (1 or 2)", OPT_NONREQ, "1" },
     { "spatial-dims", OPT_INT, "Number of spatial dimensions", OPT_NONREQ, "3" },
     { "spatial-speed", OPT_STR, "Restrict speed of spatial smoothing", OPT_NONREQ, "-1" },
     { "param-spatial-priors", OPT_STR, "Type of spatial priors for each parameter, as a sequence of characters. N=nonspatial, M=Markov random field, P=Penny, A=ARD", OPT_NONREQ, "N+" },

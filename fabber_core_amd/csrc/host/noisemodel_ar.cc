@@ -93,11 +93,7 @@ void Ar1cNoiseModel::Initialize(FabberRunData &args)
         if (ar1Type != "none")
             throw InvalidOptionValue("ar1-cross-terms", ar1Type, "You must use ar1-cross-terms=none with num-echoes=1");
     }
-    else if (nPhis == 2)
-    {
-        throw InvalidOptionValue("num-echoes", stringify(nPhis), "Dual-echo AR noise is not part of the MI355X engine yet");
-    }
-    else
+    else if (nPhis != 2)
     {
         throw InvalidOptionValue("num-echoes", stringify(nPhis), "Must be 1 or 2");
     }
@@ -150,13 +146,20 @@ void Ar1cNoiseModel::HardcodedInitialDists(NoiseParams &priorIn, NoiseParams &po
 void Ar1cNoiseModel::ConfigureEngine(fvb_config &cfg, int n_times, std::vector<unsigned char> &phi_index) const
 {
     cfg.noise = FVB_NOISE_AR1;
-    cfg.n_phis = 1;
+    cfg.n_phis = nPhis;
+    cfg.ar_cross_terms = NumAlphas() - 2; // none / same / dual
+    if (n_times % nPhis != 0)
+        throw InvalidOptionValue("num-echoes", stringify(nPhis), "The number of timepoints (" + stringify(n_times)
+            + ") is not a multiple of the number of echoes");
     Ar1cParams prior(NumAlphas(), nPhis), post(NumAlphas(), nPhis);
     HardcodedInitialDists(prior, post);
-    cfg.noise_prior_b[0] = prior.phis[0].b;
-    cfg.noise_prior_c[0] = prior.phis[0].c;
-    cfg.noise_post_b[0] = post.phis[0].b;
-    cfg.noise_post_c[0] = post.phis[0].c;
+    for (int i = 0; i < nPhis; i++)
+    {
+        cfg.noise_prior_b[i] = prior.phis[i].b;
+        cfg.noise_prior_c[i] = prior.phis[i].c;
+        cfg.noise_post_b[i] = post.phis[i].b;
+        cfg.noise_post_c[i] = post.phis[i].c;
+    }
     cfg.locked_noise_stdev = -1;
     phi_index.assign(n_times, 0);
     if (!m_masked_tpoints.empty())

@@ -40,7 +40,8 @@ int fail(int code, const std::string &msg)
 
 int noise_outputs(const fvb_config *cfg)
 {
-    return cfg->noise == FVB_NOISE_WHITE ? cfg->n_phis : 3;
+    // AR(1): (alphas, phi means), noisemodel_ar.cc:287-300
+    return cfg->noise == FVB_NOISE_WHITE ? cfg->n_phis : 2 + cfg->ar_cross_terms + cfg->n_phis;
 }
 
 int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_noise = false)
@@ -58,8 +59,17 @@ int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_no
         return fail(-5, "n_phis out of range");
     if (cfg->noise != FVB_NOISE_WHITE && cfg->noise != FVB_NOISE_AR1)
         return fail(-6, "noise model not supported by this build");
-    if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis != 1)
-        return fail(-6, "AR(1) noise: only num-echoes = 1 with ar1-cross-terms = none is built");
+    if (cfg->noise == FVB_NOISE_AR1) // noisemodel_ar.cc:322-349
+    {
+        if (cfg->n_phis != 1 && cfg->n_phis != 2)
+            return fail(-6, "AR(1) noise: num-echoes must be 1 or 2");
+        if (cfg->ar_cross_terms < 0 || cfg->ar_cross_terms > 2)
+            return fail(-6, "AR(1) noise: unknown ar1-cross-terms");
+        if (cfg->n_phis == 1 && cfg->ar_cross_terms != 0)
+            return fail(-6, "AR(1) noise: you must use ar1-cross-terms=none with num-echoes=1");
+        if (cfg->n_times % cfg->n_phis != 0)
+            return fail(-6, "AR(1) noise: the number of timepoints is not a multiple of num-echoes");
+    }
     if (cfg->convergence < FVB_CONV_MAXITS || cfg->convergence > FVB_CONV_LM)
         return fail(-7, "unknown convergence detector");
     if (cfg->max_iterations <= 0)

@@ -38,11 +38,14 @@ struct WaveLayout
     int y, gl, r, k, J, pv, rden, A, u, s, kq, trs, cnt, b, c, m, ml, pm, pprec, rhs, Lam, Sig, W, W2;
     int sv_m, sv_Lam, sv_Sig, sv_pm, sv_pprec, sv_b, sv_c;
     int part; // 64 partial sums of the chunked contractions
+    // AR(1) noise (vb_wave_ar_kernel.h): z = y - g + J ml, X J and J Sigma [T][Ps], the band of the
+    // current weighting matrix [T][7] (offsets -3..3, noisemodel_ar.cc:23)
+    int z, XJ, JS, band;
     int n_doubles;
     size_t bytes;
 };
 
-FVB_HD WaveLayout wave_layout(int T, int P, int N)
+FVB_HD WaveLayout wave_layout(int T, int P, int N, bool ar = false)
 {
     WaveLayout L;
     L.T = T;
@@ -87,6 +90,10 @@ FVB_HD WaveLayout wave_layout(int T, int P, int N)
     FVB_WL(sv_b, N)
     FVB_WL(sv_c, N)
     FVB_WL(part, 64)
+    FVB_WL(z, ar ? T : 0)
+    FVB_WL(XJ, ar ? T * L.Ps : 0)
+    FVB_WL(JS, ar ? T * L.Ps : 0)
+    FVB_WL(band, ar ? 7 * T : 0)
 #undef FVB_WL
     L.n_doubles = o;
     L.bytes = sizeof(double) * (size_t)o + sizeof(int32_t) * (size_t)T;
@@ -202,7 +209,8 @@ __device__ __forceinline__ bool wave_ensure_prec(WaveCtx &cx)
 
 // LinearizedFwdModel::ReCentre about the current means (fwdmodel_linear.cc:126-182) followed by
 // the per-phi moments A_i = J'Q_iJ, u_i = J'Q_i r, s_i = r'Q_i r with r = y - g(ml).
-__device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelArgs &ma, WaveCtx &cx)
+// moments = false: only g, J and r (the AR kernel forms its own contractions)
+__device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelArgs &ma, WaveCtx &cx, bool moments = true)
 {
     const WaveLayout &L = cx.L;
     const int T = L.T, P = L.P, N = L.N, Ps = L.Ps, PT = L.PT;
@@ -270,6 +278,11 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
     }
     }
     wave_sync();
+    if (!moments)
+    {
+        const bool any_offset = __any(bad_offset), any_jac = __any(bad_jac);
+        return any_offset ? FVB_BAD_OFFSET : (any_jac ? FVB_BAD_JACOBIAN : FVB_OK);
+    }
     // One output entry per lane; with fewer than 33 entries the spare lanes split each entry's
     // t range into C chunks whose partial sums are added in chunk order (fixed, so the result is
     // reproducible run to run).
@@ -860,8 +873,6 @@ __global__ __launch_bounds__(64) void vb_wave_kernel(const KernelArgs ka, const 
             ka.out.iterations[v] = it;
     }
 }
-
-#undef FVB_WAVE_FOR
 
 #endif // __HIPCC__
 

@@ -14,7 +14,7 @@ import numpy as np
 
 FVB_MAX_PARAMS = 16
 FVB_MAX_PHIS = 8
-FVB_ABI_VERSION = 4
+FVB_ABI_VERSION = 5
 
 MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
 TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)
@@ -63,6 +63,7 @@ class FvbConfig(C.Structure):
         ("init_mvn", C.c_void_p),
         ("f_history_rows", C.c_int32),
         ("data_f64", C.c_int32),
+        ("ar_cross_terms", C.c_int32),
     ]
 
 
@@ -175,14 +176,14 @@ class ConfigHolder:
 
     @property
     def n_noise_outputs(self):
-        return self.cfg.n_phis if self.cfg.noise == NOISE_WHITE else 3
+        return self.cfg.n_phis if self.cfg.noise == NOISE_WHITE else 2 + self.cfg.ar_cross_terms + self.cfg.n_phis
 
 
 def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps=1, dt=1.0,
                  convergence="maxits", max_iterations=10, min_fchange=0.01, max_trials=10,
                  need_f=None, f_history_rows=0, noise_pattern="1", masked_timepoints=(),
                  prior_noise_stddev=-1.0, locked_noise_stdev=-1.0, param_overrides=None,
-                 image_priors=None, init_mvn=None, noise=NOISE_WHITE):
+                 image_priors=None, init_mvn=None, noise=NOISE_WHITE, num_echoes=1, ar_cross_terms="none"):
     """Resolve options into an fvb_config whose pointer members are HOST numpy arrays.
 
     param_overrides: {name: dict(type=, mean=, prec=, transform=)} == PSP_byname options
@@ -278,9 +279,12 @@ def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps
             b = 1 / (prior_noise_stddev * prior_noise_stddev * c)
             cfg.noise_prior_b[i] = cfg.noise_post_b[i] = b
             cfg.noise_prior_c[i] = cfg.noise_post_c[i] = c
-    if noise == NOISE_AR1:  # noisemodel_ar.cc:379-403
-        cfg.noise_prior_b[0], cfg.noise_prior_c[0] = 1e6, 1e-6
-        cfg.noise_post_b[0], cfg.noise_post_c[0] = 1e-8, 1e-6
+    if noise == NOISE_AR1:  # noisemodel_ar.cc:322-403
+        cfg.n_phis = num_echoes
+        cfg.ar_cross_terms = {"none": 0, "same": 1, "dual": 2}[ar_cross_terms]
+        for i in range(num_echoes):
+            cfg.noise_prior_b[i], cfg.noise_prior_c[i] = 1e6, 1e-6
+            cfg.noise_post_b[i], cfg.noise_post_c[i] = 1e-8, 1e-6
     cfg.locked_noise_stdev = locked_noise_stdev
 
     cfg.convergence = CONV_NAMES[convergence] if isinstance(convergence, str) else convergence

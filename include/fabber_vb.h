@@ -44,7 +44,7 @@ extern "C" {
 
 #define FVB_MAX_PARAMS 16
 #define FVB_MAX_PHIS 8
-#define FVB_ABI_VERSION 4
+#define FVB_ABI_VERSION 5
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
@@ -92,7 +92,7 @@ enum fvb_convergence
 enum fvb_noise
 {
     FVB_NOISE_WHITE = 0, /* noisemodel_white.cc */
-    FVB_NOISE_AR1 = 1    /* noisemodel_ar.cc, nPhis = 1, cross terms "none" */
+    FVB_NOISE_AR1 = 1    /* noisemodel_ar.cc: n_phis = num-echoes (1 or 2), fvb_config.ar_cross_terms */
 };
 
 /* Per-voxel status word written by the kernel. Mirrors the exceptions the reference's voxel
@@ -115,7 +115,7 @@ typedef struct fvb_config
     int32_t n_voxels;
     int32_t n_times;
     int32_t n_params; /* P, forward-model parameters */
-    int32_t n_phis;   /* white: number of noise-pattern symbols; AR1: 1 */
+    int32_t n_phis;   /* white: number of noise-pattern symbols; AR1: num-echoes (interleaved series), 1 or 2 */
     int32_t noise;    /* enum fvb_noise */
 
     /* ---- forward model ---- */
@@ -158,6 +158,11 @@ typedef struct fvb_config
     int32_t f_history_rows; /* 0 = do not record (save-free-energy-history) */
     int32_t data_f64;       /* 0: data is float32 (fabber_capi, fabber_capi.h:109); 1: data is float64
                                (the C++ FabberRunData::SetVoxelData(Matrix) route, rundata.cc:924) */
+
+    /* ---- AR(1) noise (noisemodel_ar.cc:322-377) ---- */
+    int32_t ar_cross_terms; /* option ar1-cross-terms: 0 "none" (2 alphas), 1 "same" (3), 2 "dual" (4); must be 0
+                               with one echo. The noise block of the MVN is (alphas, phi means): 2 +
+                               ar_cross_terms + n_phis entries (noisemodel_ar.cc:287-300) */
 } fvb_config;
 
 /* Result arrays; any pointer may be NULL if that output is not wanted, except mvn. */

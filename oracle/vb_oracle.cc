@@ -1263,6 +1263,7 @@ static inline double load_data(const fvb_config *cfg, const void *data, size_t i
 }
 
 #include "vb_oracle_ar.inc"
+#include "vb_oracle_arn.inc"
 #include "vb_oracle_spatial.inc"
 #include "vb_oracle_nlls.inc"
 
@@ -1300,6 +1301,10 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
             for (int t = 0; t < T; t++)
                 if (cfg->phi_index[t] == 255)
                     return -3; // masked timepoints are rejected for AR noise (noisemodel_ar.cc:351-355)
+        // noisemodel_ar.cc:334-349: one or two echoes, cross terms only with two
+        if (cfg->n_phis < 1 || cfg->n_phis > 2 || cfg->ar_cross_terms < 0 || cfg->ar_cross_terms > 2
+            || (cfg->n_phis == 1 && cfg->ar_cross_terms != 0) || T % cfg->n_phis != 0)
+            return -4;
         int32_t first = 0;
         for (int v = v_begin; v < v_end; v++)
         {
@@ -1307,7 +1312,11 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
             for (int t = 0; t < T; t++)
                 y[t] = load_data(cfg, data, (size_t)t * V + v);
             model.data = y;
-            int st = run_voxel_ar(cfg, out, v, model, y, cfg->need_f != 0);
+            // one echo without cross terms: the stencil restatement (vb_oracle_ar.inc) unless the
+            // general one (vb_oracle_arn.inc) is asked for, which covers every configuration
+            const bool general = cfg->n_phis != 1 || cfg->ar_cross_terms != 0 || getenv("ORACLE_AR_GENERAL") != nullptr;
+            int st = general ? run_voxel_arn(cfg, out, v, model, y, cfg->need_f != 0)
+                             : run_voxel_ar(cfg, out, v, model, y, cfg->need_f != 0);
             if (st != FVB_OK && halt_bad_voxel && first == 0)
             {
                 first = v + 1;
@@ -1460,7 +1469,8 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
 // InferenceTechnique::SaveResults (inference.cc:112-281), Vb::SaveResults (inference_vb.cc:966-995)
 int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp)
 {
-    const int T = cfg->n_times, P = cfg->n_params, N = cfg->n_phis, n = P + N;
+    const int T = cfg->n_times, P = cfg->n_params;
+    const int N = cfg->noise == FVB_NOISE_AR1 ? 2 + cfg->ar_cross_terms + cfg->n_phis : cfg->n_phis, n = P + N;
     const size_t V = cfg->n_voxels;
     const int nCov = n * (n + 1) / 2;
     Model model;

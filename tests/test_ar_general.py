@@ -1,0 +1,294 @@
+"""AR(1) noise with two interleaved echoes and the cross-term variants (num-echoes = 2,
+ar1-cross-terms = none / same / dual; noisemodel_ar.cc:83-769).
+
+The oracle keeps the reference's alpha matrices as lines (oracle/vb_oracle_arn.inc). It is checked
+here against (1) its own one-echo stencil restatement (vb_oracle_ar.inc), which the reference's
+stored outputs pin, and (2) an independent NumPy transcription that builds the DENSE matrices with
+the reference's loops and runs the update equations on them. GPU: the wave-per-voxel AR kernel
+against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from fabber_core_amd import vbabi
+
+AR = vbabi.NOISE_AR1
+
+
+# ---- dense NumPy transcription (linear model: J = design, g = J theta) -------------------------
+def alpha_matrix(n, a12, a34, n_phis, n_times):
+    """Ar1cMatrixCache::Update, noisemodel_ar.cc:112-181 (1-based rows and columns)."""
+    row, col = {0: (1 + n_phis, 1 + n_phis), 10: (1, 1 + n_phis), 20: (1, 1), 1: (4, 3), 11: (4, 1), 2: (4, 4)}[a12 * 10 + a34]
+    value = -1.0 if a12 + a34 == 1 else 1.0
+    if n == 2:
+        row = row - 1 + 2 * (row % 2)
+        col = col - 1 + 2 * (col % 2)
+    m = np.zeros((n_times * n_phis, n_times * n_phis))
+    for _ in range(n_times - 1):
+        m[row - 1, col - 1] = m[col - 1, row - 1] = value
+        row += n_phis
+        col += n_phis
+    return m
+
+
+def dense_ar_vb(X, y, n_phis, n_alphas, iterations):
+    """Vb::DoCalculationsVoxelwise with Ar1cNoiseModel for one voxel of a linear model with the
+    default priors (precision 1e-12 on theta): UpdateTheta, UpdateAlpha, UpdatePhi per iteration."""
+    T, P = X.shape
+    nT = T // n_phis
+    M = lambda n, a, b: alpha_matrix(n, a, b, n_phis, nT)
+    L0, m0 = np.eye(P) * 1e-12, np.zeros(P)
+    theta = np.zeros(P)
+    A0 = np.eye(n_alphas) * 1e-4
+    a_mean, a_prec = np.zeros(n_alphas), A0.copy()
+    b0, c0 = 1e6, 1e-6
+    b = np.full(n_phis, 1e-8)
+    c = np.full(n_phis, c0 + (nT - 1) * 0.5)          # Precalculate, :765-768
+
+    def marginals():
+        cp = np.linalg.inv(a_prec) + np.outer(a_mean, a_mean)
+        out = []
+        for n in range(1, n_phis + 1):
+            q = M(n, 0, 0) + M(n, 1, 0) * a_mean[n - 1] + M(n, 2, 0) * cp[n - 1, n - 1]
+            if n_alphas >= 3:
+                t = (2 + n if n_alphas == 4 else 3) - 1
+                q = q + M(n, 0, 1) * a_mean[t] + M(n, 1, 1) * cp[n - 1, t] + M(n, 0, 2) * cp[t, t]
+            out.append(q)
+        return out
+
+    Q = marginals()
+    for _ in range(iterations):
+        ml = theta.copy()                              # linearisation centre; g = X ml, J = X
+        Xq = sum(b[i] * c[i] * Q[i] for i in range(n_phis))
+        Lam = L0 + X.T @ Xq @ X                        # :589-591
+        theta = np.linalg.solve(Lam, X.T @ Xq @ (y - X @ ml + X @ ml) + L0 @ m0)   # :604-609
+        k = y - X @ ml + X @ (ml - theta)
+        Li = np.linalg.inv(Lam)
+        op = lambda mat: k @ mat @ k + np.trace(Li @ X.T @ mat @ X)   # OperatorKLJ, :433-445
+        sc = b * c
+        prec = A0.copy()
+        for i in range(1, n_phis + 1):
+            prec[i - 1, i - 1] += sc[i - 1] * op(M(i, 2, 0))
+        Tn = n_alphas
+        if Tn > 2:                                     # :476-485
+            prec[2, 0] += 0.5 * sc[0] * op(M(1, 1, 1)); prec[0, 2] = prec[2, 0]
+            prec[Tn - 1, 1] += 0.5 * sc[1] * op(M(2, 1, 1)); prec[1, Tn - 1] = prec[Tn - 1, 1]
+            prec[2, 2] += sc[0] * op(M(1, 0, 2))
+            prec[Tn - 1, Tn - 1] += sc[1] * op(M(2, 0, 2))
+        tmp = A0 @ np.zeros(n_alphas)
+        for i in range(1, n_phis + 1):
+            tmp[i - 1] += -0.5 * sc[i - 1] * op(M(i, 1, 0))
+        if Tn > 2:
+            tmp[2] += -0.5 * sc[0] * op(M(1, 0, 1))
+            tmp[Tn - 1] += -0.5 * sc[1] * op(M(2, 0, 1))
+        a_prec = prec
+        a_mean = np.linalg.solve(prec, tmp)
+        Q = marginals()
+        for i in range(n_phis):                        # UpdatePhi, :530-556
+            t2 = k @ Q[i] @ k + np.trace(Li @ X.T @ Q[i] @ X)
+            b[i] = 1 / (t2 * 0.5 + 1 / b0)
+            c[i] = (nT - 1) * 0.5 + c0
+    return theta, Li, a_mean, np.linalg.inv(a_prec), b * c
+
+
+def two_echo_problem(n_voxels, n_times, seed, cross, **opts):
+    """Two interleaved series with different noise levels and AR coefficients, linear model."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_times, dtype=np.float64)
+    X = np.stack([np.ones(n_times), (t % 2), np.sin(2 * np.pi * t / 17), np.cos(2 * np.pi * t / 17)], axis=1)
+    theta = rng.normal(0, 5, size=(4, n_voxels))
+    noise = np.zeros((n_times, n_voxels))
+    for echo, (rho, sd) in enumerate(((0.4, 1.0), (-0.2, 0.5))):
+        e = rng.normal(0, sd, size=(n_times // 2, n_voxels))
+        for i in range(1, n_times // 2):
+            e[i] += rho * e[i - 1]
+        noise[echo::2] = e
+    y = X @ theta + noise
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, n_voxels, n_times, design=X, noise=AR, num_echoes=2, ar_cross_terms=cross, **opts)
+    return h, y, X
+
+
+def unpack(res, h, v):
+    n = h.cfg.n_params + h.n_noise_outputs
+    cov = np.zeros((n, n))
+    row = 0
+    for r in range(n):
+        for c in range(r + 1):
+            cov[r, c] = cov[c, r] = res["mvn"][row, v]
+            row += 1
+    return res["mvn"][row:row + n, v], cov
+
+
+def test_general_form_reproduces_the_one_echo_restatement(monkeypatch):
+    h, y = cases.linear_problem(30, 50, seed=3, max_iterations=8, noise=AR, need_f=True)
+    a = oracle.run(h, y)
+    monkeypatch.setenv("ORACLE_AR_GENERAL", "1")
+    b = oracle.run(h, y)
+    assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
+    assert np.allclose(a["mvn"], b["mvn"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(a["free_energy"], b["free_energy"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("cross,n_alphas", [("none", 2), ("same", 3), ("dual", 4)])
+def test_two_echoes_against_the_dense_transcription(cross, n_alphas):
+    h, y, X = two_echo_problem(6, 40, seed=5, cross=cross, max_iterations=5)
+    res = oracle.run(h, y.astype(np.float64))
+    assert np.all(res["status"] == 0)
+    assert res["mvn"].shape[0] == vbabi.mvn_rows(4 + n_alphas + 2)
+    for v in range(6):
+        theta, cov, a_mean, a_cov, phi = dense_ar_vb(X, y[:, v], 2, n_alphas, 5)
+        means, full = unpack(res, h, v)
+        assert np.allclose(means[:4], theta, rtol=1e-6, atol=1e-8), (cross, v)
+        assert np.allclose(full[:4, :4], cov, rtol=1e-5, atol=1e-12)
+        assert np.allclose(means[4:4 + n_alphas], a_mean, rtol=1e-6, atol=1e-9)
+        assert np.allclose(full[4:4 + n_alphas, 4:4 + n_alphas], a_cov, rtol=1e-5, atol=1e-12)
+        assert np.allclose(means[4 + n_alphas:], phi, rtol=1e-6)
+
+
+def test_two_echoes_recover_the_two_noise_levels():
+    h, y, _ = two_echo_problem(40, 200, seed=6, cross="none", max_iterations=10)
+    res = oracle.run(h, y.astype(np.float32))
+    n = 4 + 2 + 2
+    off = n * (n + 1) // 2
+    alpha, phi = res["mvn"][off + 4:off + 6], res["mvn"][off + 6:off + 8]
+    assert abs(np.median(alpha[0]) - 0.4) < 0.1 and abs(np.median(alpha[1]) + 0.2) < 0.1
+    assert abs(np.median(phi[0]) - 1.0) < 0.25 and abs(np.median(phi[1]) - 4.0) < 1.0
+
+
+def test_invalid_echo_settings_are_refused():
+    h, y = cases.linear_problem(4, 21, seed=1, noise=AR, num_echoes=2)     # odd length
+    with pytest.raises(RuntimeError):
+        oracle.run(h, y)
+    h, y = cases.linear_problem(4, 20, seed=1, noise=AR, num_echoes=1, ar_cross_terms="dual")
+    with pytest.raises(RuntimeError):
+        oracle.run(h, y)
+
+
+# ---- HIP: the wave-per-voxel AR kernel (csrc/vb_wave_ar_kernel.h) against the oracle ------------
+from fabber_core_amd import hiplib  # noqa: E402
+import hipengine  # noqa: E402
+
+
+def assert_close_to_oracle(h, y, ref=None, rtol=1e-6):
+    ref = ref or oracle.run(h, y)
+    got = hipengine.run(h, y)
+    assert np.array_equal(ref["status"], got["status"])
+    ok = ref["status"] == 0
+    n = h.cfg.n_params + h.n_noise_outputs
+    off = n * (n + 1) // 2
+    sd = np.sqrt(np.abs(np.stack([ref["mvn"][p * (p + 1) // 2 + p] for p in range(n)])))
+    scale = np.maximum(np.abs(ref["mvn"][off:off + n]), sd)
+    err = np.abs(got["mvn"][off:off + n] - ref["mvn"][off:off + n]) / scale
+    assert err[:, ok].max() < rtol, err[:, ok].max()
+    row = 0
+    for r in range(n):
+        for c in range(r + 1):
+            d = np.abs(got["mvn"][row] - ref["mvn"][row])[ok] / np.maximum(sd[r] * sd[c], 1e-300)[ok]
+            assert d.max() < 10 * rtol, (r, c, d.max())
+            row += 1
+    if h.cfg.need_f:
+        assert np.allclose(got["free_energy"][ok], ref["free_energy"][ok], rtol=1e-7, atol=1e-6)
+    return ref, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross", ["none", "same", "dual"])
+@pytest.mark.parametrize("need_f", [False, True])
+def test_two_echoes_on_the_gpu(cross, need_f):
+    h, y, _ = two_echo_problem(200, 60, seed=7, cross=cross, max_iterations=8, need_f=need_f)
+    assert_close_to_oracle(h, y.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_one_echo_wave_kernel_matches_oracle_and_lane_kernel():
+    h, y = cases.linear_problem(300, 80, seed=3, max_iterations=8, noise=AR, need_f=True)
+    hiplib.set_variant("wave")
+    try:
+        assert "wave" in hiplib.kernel_name(h)
+        _, wave = assert_close_to_oracle(h, y)
+    finally:
+        hiplib.set_variant("auto")
+    lane = hipengine.run(h, y)
+    assert "lane_ar1" in hiplib.kernel_name(h)
+    assert np.allclose(wave["mvn"], lane["mvn"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(wave["free_energy"], lane["free_energy"], rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_one_echo_with_a_parameter_count_the_lane_kernels_do_not_cover():
+    rng = np.random.default_rng(11)
+    T, P, V = 64, 9, 100
+    t = np.arange(T)
+    X = np.stack([np.cos(np.pi * (t + 0.5) * k / T) for k in range(P)], axis=1)
+    y = X @ rng.normal(0, 3, (P, V)) + rng.normal(0, 0.5, (T, V))
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, noise=AR, max_iterations=6, need_f=True)
+    assert "wave" in hiplib.kernel_name(h)
+    assert_close_to_oracle(h, y.astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv", ["pointzeroone", "freduce", "trialmode"])
+def test_two_echoes_with_free_energy_detectors(conv):
+    h, y, _ = two_echo_problem(150, 60, seed=8, cross="dual", max_iterations=20, convergence=conv, min_fchange=0.01)
+    ref = oracle.run(h, y.astype(np.float32))
+    got = hipengine.run(h, y.astype(np.float32))
+    same = ref["iterations"] == got["iterations"]
+    assert same.mean() > 0.97
+    n = 4 + 4 + 2
+    off = n * (n + 1) // 2
+    assert np.allclose(got["mvn"][off:off + 4, same], ref["mvn"][off:off + 4, same], rtol=1e-5, atol=1e-7)
+    assert np.allclose(got["free_energy"][same], ref["free_energy"][same], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_two_echoes_continue_from_mvn_and_exponential_model():
+    h, y, X = two_echo_problem(64, 60, seed=9, cross="same", max_iterations=3)
+    first = hipengine.run(h, y.astype(np.float32))
+    h2 = vbabi.build_config(vbabi.MODEL_LINEAR, 64, 60, design=X, noise=AR, num_echoes=2, ar_cross_terms="same",
+                            max_iterations=3, init_mvn=first["mvn"])
+    assert_close_to_oracle(h2, y.astype(np.float32))
+    he, ye = cases.exp_problem(128, 60, 1, 0.04, seed=3, noise_sd=0.05, noise=AR, num_echoes=2, max_iterations=8, need_f=True)
+    assert_close_to_oracle(he, ye, rtol=1e-5)
+
+
+# ---- through the reference's API: noise=ar num-echoes=2 ar1-cross-terms=... (fabber_capi.h) -----
+from fabber_core_amd import fabber  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross,n_alphas", [("none", 2), ("dual", 4)])
+def test_two_echoes_through_the_c_abi(cross, n_alphas, tmp_path):
+    h, y, X = two_echo_problem(48, 60, seed=10, cross=cross, max_iterations=6)
+    design = tmp_path / "design.mat"
+    np.savetxt(design, X)
+    vol = y.astype(np.float32).T.reshape(4, 4, 3, 60, order="F")
+    out = fabber.run(vol, {"model": "linear", "basis": str(design), "noise": "ar", "num-echoes": 2, "ar1-cross-terms": cross,
+                           "method": "vb", "max-iterations": 6, "save-mean": True, "save-mvn": True, "save-noise-mean": True,
+                           "save-noise-std": True})
+    eng = hipengine.run(h, y.astype(np.float32))
+    n = 4 + n_alphas + 2
+    assert out["finalMVN"].shape[3] == vbabi.mvn_rows(n)
+    assert np.allclose(out["finalMVN"].reshape(48, -1, order="F").T, eng["mvn"], rtol=2e-6, atol=1e-10)
+    # noise_means holds the first NumParams() = num-echoes noise entries, i.e. alpha_1, alpha_2
+    # (noisemodel_ar.cc:362-365, inference_vb.cc:981-989)
+    off = n * (n + 1) // 2
+    assert out["noise_means"].shape == (4, 4, 3, 2)
+    assert np.allclose(out["noise_means"].reshape(48, 2, order="F").T, eng["mvn"][off + 4:off + 6], rtol=2e-6, atol=1e-9)
+
+
+def test_echo_options_are_validated():
+    with fabber.Fabber() as f:
+        f.set_extent((2, 2, 1))
+        f.set_options({"model": "poly", "degree": 1, "noise": "ar", "method": "vb", "num-echoes": 1, "ar1-cross-terms": "dual"})
+        f.set_data("data", np.ones((2, 2, 1, 10), dtype=np.float32))
+        with pytest.raises(fabber.FabberError, match="ar1-cross-terms=none with num-echoes=1"):
+            f.run()
+    with fabber.Fabber() as f:
+        f.set_extent((2, 2, 1))
+        f.set_options({"model": "poly", "degree": 1, "noise": "ar", "method": "vb", "num-echoes": 3})
+        f.set_data("data", np.ones((2, 2, 1, 10), dtype=np.float32))
+        with pytest.raises(fabber.FabberError, match="Must be 1 or 2"):
+            f.run()
