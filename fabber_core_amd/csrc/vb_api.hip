@@ -96,9 +96,10 @@ int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_no
 
 // Below this many voxels the lane kernel (V/64 wavefronts, each taking the full per-voxel latency)
 // leaves most of the 1024 SIMDs empty and the wave-per-voxel kernel (V wavefronts) finishes
-// first; measured crossovers on MI355X: ~17k voxels for the bi-exponential C3 fit, ~8k for the
-// single-exponential C2 fit (profiles/r1_lane_vs_wave.jsonl).
-constexpr int WAVE_KERNEL_BELOW_VOXELS = 8192;
+// first. Measured crossovers on MI355X (profiles/r1_lane_vs_wave.jsonl): ~6k voxels for the
+// bi-exponential C3 fit (lane 2.2 ms flat, wave 0.4 us per voxel), ~2.5k for the single-exponential
+// C2 fit (lane 0.12 ms flat, wave 0.04 us per voxel).
+constexpr int WAVE_KERNEL_BELOW_VOXELS = 4096;
 
 LaneKernelInfo select_lane(const fvb_config *cfg)
 {

@@ -92,7 +92,7 @@ def test_parameter_counts_without_a_lane_instantiation():
 
 def test_automatic_choice_between_the_two_mappings():
     hiplib.set_variant("auto")
-    small, _ = cases.exp_problem(4096, 50, 1, 0.04, seed=1)
+    small, _ = cases.exp_problem(4095, 50, 1, 0.04, seed=1)
     large, _ = cases.exp_problem(8192, 50, 1, 0.04, seed=1)
     assert hiplib.kernel_name(small) == "wave" and hiplib.kernel_name(large) == "lane<exp,2>"
     # a series too long for the LDS stays on the lane kernel however few voxels there are
