@@ -349,6 +349,32 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
     sp_load<P>(sa, v, st, mo);
     const int dims = sa.spatial_dims;
     double Fprior = 0;
+    // Neighbour ids and their status do not depend on the parameter: fetched once, with every load
+    // unconditional (absent neighbours read the voxel itself and are masked afterwards), so that
+    // the six chains id -> status / mean run side by side instead of one after the other - this
+    // kernel is launched once per level and its time is the latency of its dependent loads.
+    // Vb::IgnoreVoxel (inference_vb.cc:266-297) deletes a failed voxel from the first-neighbour
+    // lists of its neighbours and from the second-neighbour lists of its second neighbours; the
+    // second-neighbour list itself was fixed when it was built, so it still reaches across a
+    // failed intermediate voxel. With fixed tables: test the status of every END point, never of
+    // the intermediate one.
+    bool any_second = false;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+        any_second |= (ka.cfg.prior_type[k] == FVB_PRIOR_SPATIAL_P || ka.cfg.prior_type[k] == FVB_PRIOR_SPATIAL_p);
+    int n1[6];
+    bool ok1[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+    {
+        const int u = sa.nn[(size_t)v * 6 + a];
+        n1[a] = (u < 0) ? v : u;
+        ok1[a] = (u >= 0);
+    }
+    bool live1[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+        live1[a] = ok1[a] && (sa.status[n1[a]] == 0);
 #pragma unroll
     for (int k = 0; k < P; k++)
     {
@@ -359,31 +385,44 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             const double *mk = sa.state + (size_t)(L::M + k) * V;
             int nn = 0, nn2 = 0;
             double contrib_nn = 0, contrib_nn2 = 0;
-            // Vb::IgnoreVoxel (inference_vb.cc:266-297) deletes a failed voxel from the first-neighbour
-            // lists of its neighbours and from the second-neighbour lists of its second neighbours;
-            // the second-neighbour list itself was fixed when it was built, so it still reaches
-            // across a failed intermediate voxel. With fixed tables: test the status of every END
-            // point, never of the intermediate one.
+            double m1[6];
+#pragma unroll
             for (int a = 0; a < 6; a++)
-            {
-                const int u = sa.nn[(size_t)v * 6 + a];
-                if (u < 0)
-                    continue;
-                if (sa.status[u] == 0)
+                m1[a] = mk[n1[a]];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+                if (live1[a])
                 {
                     nn++;
-                    contrib_nn += mk[u];
+                    contrib_nn += m1[a];
                 }
-                if (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p)
+            if (any_second && (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p))
+            {
+                for (int a = 0; a < 6; a++)
+                {
+                    if (!ok1[a])
+                        continue;
+                    int n2[6];
+#pragma unroll
+                    for (int b = 0; b < 6; b++)
+                        n2[b] = sa.nn[(size_t)n1[a] * 6 + b];
+                    bool live2[6];
+                    double m2[6];
+#pragma unroll
                     for (int b = 0; b < 6; b++)
                     {
-                        const int w = sa.nn[(size_t)u * 6 + b];
-                        if (w >= 0 && w != v && sa.status[w] == 0)
+                        const int w = (n2[b] < 0) ? v : n2[b];
+                        live2[b] = (n2[b] >= 0) && (n2[b] != v) && (sa.status[w] == 0);
+                        m2[b] = mk[w];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 6; b++)
+                        if (live2[b])
                         {
                             nn2++;
-                            contrib_nn2 += -mk[w];
+                            contrib_nn2 += -m2[b];
                         }
-                    }
+                }
             }
             if (type == FVB_PRIOR_SPATIAL_p || type == FVB_PRIOR_SPATIAL_m)
             {
