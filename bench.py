@@ -102,7 +102,7 @@ def pmc_traffic(workload, V, kernel, args):
         return {"traffic": None}
     prof = json.load(open(path))
     name = (prof.get("kernel_trace") or {}).get("name", "")
-    tag = kernel.replace("lane<", "").rstrip(">").split(",")  # e.g. lane<exp,4> -> ["exp", "4"]
+    tag = kernel[kernel.find("<") + 1:].rstrip(">").split(",")  # e.g. lane<exp,4> / lane_ar1<linear,4> -> ["exp", "4"]
     if len(tag) < 2 or ("%sModel<%s>" % (tag[0].capitalize(), tag[1])) not in name:
         return {"traffic": None}
     cal, ctr = prof["calibration"], prof["counters"]
