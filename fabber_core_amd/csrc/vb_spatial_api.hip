@@ -174,6 +174,134 @@ struct DevMem
     }
 };
 
+// ---- the same table built on the device -----------------------------------------------------------
+// For the usual geometry (non-negative co-ordinates, a mask that fills a fair share of its bounding
+// box) the table is a handful of independent look-ups per voxel: 22 ms of single-threaded host
+// time plus a 50 MB upload for 128^3 voxels, well under a millisecond as three kernels on the
+// co-ordinates (24 MB upload). Anything else takes the host path above.
+struct GeomScan
+{
+    int32_t xmax, ymax, cmin, bad_order;
+};
+
+__global__ __launch_bounds__(256) void geom_scan_kernel(const int32_t *coords, int V, GeomScan *out)
+{
+    const int32_t *X = coords, *Y = coords + V, *Z = coords + 2 * (size_t)V;
+    int xmax = 0, ymax = 0, cmin = 0, bad = 0;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x)
+    {
+        xmax = max(xmax, X[v]);
+        ymax = max(ymax, Y[v]);
+        cmin = min(cmin, min(X[v], min(Y[v], Z[v])));
+        if (v + 1 < V) // CheckCoordMatrixCorrectlyOrdered, inference_vb.cc:769-793
+        {
+            const int dx = X[v + 1] - X[v], dy = Y[v + 1] - Y[v], dz = Z[v + 1] - Z[v];
+            const int key = ((dx > 0) - (dx < 0)) + 10 * ((dy > 0) - (dy < 0)) + 100 * ((dz > 0) - (dz < 0));
+            bad |= (key <= 0);
+        }
+    }
+    atomicMax(&out->xmax, xmax);
+    atomicMax(&out->ymax, ymax);
+    atomicMin(&out->cmin, cmin);
+    if (bad)
+        atomicOr(&out->bad_order, 1);
+}
+
+__global__ __launch_bounds__(256) void geom_dense_kernel(const int32_t *coords, int V, int xsize, int ysize, long long base,
+    int32_t *dense)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V)
+        return;
+    const long long off = (long long)coords[2 * (size_t)V + v] * xsize * ysize + (long long)coords[(size_t)V + v] * xsize + coords[v];
+    dense[off - base] = v;
+}
+
+// Vb::CalcNeighbours (inference_vb.cc:830-964) for non-negative co-ordinates: the wrap-around tests
+// (:906-925) read "x is on the last / first column", "y is on the last / first row"
+__global__ __launch_bounds__(256) void geom_neighbours_kernel(const int32_t *coords, int V, int xsize, int ysize, long long base,
+    long long span, int max_delta, const int32_t *dense, int32_t *nn)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V)
+        return;
+    const int x = coords[v], y = coords[(size_t)V + v], z = coords[2 * (size_t)V + v];
+    const long long rel0 = (long long)z * xsize * ysize + (long long)y * xsize + x - base;
+    const long long delta[6] = { 1, -1, xsize, -xsize, (long long)xsize * ysize, -(long long)xsize * ysize };
+    const bool ok[6] = { x < xsize - 1, x > 0, y < ysize - 1, y > 0, true, true };
+    int32_t row[6] = { -1, -1, -1, -1, -1, -1 };
+    int slot = 0;
+#pragma unroll
+    for (int n = 0; n < 6; n++)
+    {
+        const long long rel = rel0 + delta[n];
+        if (n > max_delta || !ok[n] || rel < 0 || rel >= span)
+            continue;
+        const int32_t found = dense[rel];
+        if (found >= 0)
+        {
+#pragma unroll
+            for (int q = 0; q < 6; q++) // (compile-time indices: the row stays in registers)
+                if (q == slot)
+                    row[q] = found;
+            slot++;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        nn[(size_t)v * 6 + q] = row[q];
+}
+
+// Returns 0 (d_nn filled), 1 (geometry not suited: use the host path) or a negative error code.
+int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d_nn, hipStream_t stream, std::string &err)
+{
+#define FVB_GEOM_CHECK(expr)                                                                                 \
+    do                                                                                                       \
+    {                                                                                                        \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+        {                                                                                                    \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                                         \
+            return -100 - (int)e_;                                                                           \
+        }                                                                                                    \
+    } while (0)
+    DevMem d_coords, d_scan, d_dense;
+    FVB_GEOM_CHECK(d_coords.alloc(sizeof(int32_t) * 3 * (size_t)V));
+    FVB_GEOM_CHECK(d_scan.alloc(sizeof(GeomScan)));
+    FVB_GEOM_CHECK(hipMemcpyAsync(d_coords.p, h_coords, sizeof(int32_t) * 3 * (size_t)V, hipMemcpyHostToDevice, stream));
+    FVB_GEOM_CHECK(hipMemsetAsync(d_scan.p, 0, sizeof(GeomScan), stream));
+    const unsigned blocks = (unsigned)std::min(1024, (V + 255) / 256);
+    hipLaunchKernelGGL(geom_scan_kernel, dim3(blocks), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, (GeomScan *)d_scan.p);
+    GeomScan scan;
+    FVB_GEOM_CHECK(hipMemcpyAsync(&scan, d_scan.p, sizeof(scan), hipMemcpyDeviceToHost, stream));
+    FVB_GEOM_CHECK(hipStreamSynchronize(stream));
+    if (scan.bad_order)
+    {
+        err = "Coordinate matrix must be in correct order to use adjacency-based priors.";
+        return -41;
+    }
+    if (scan.cmin < 0)
+        return 1;
+    const int xsize = scan.xmax + 1, ysize = scan.ymax + 1;
+    const int32_t *X = h_coords, *Y = h_coords + V, *Z = h_coords + 2 * (size_t)V;
+    const long long first = (long long)Z[0] * xsize * ysize + (long long)Y[0] * xsize + X[0];
+    const long long last = (long long)Z[V - 1] * xsize * ysize + (long long)Y[V - 1] * xsize + X[V - 1];
+    const long long span = last - first + 1;
+    if (span <= 0 || span > std::max<long long>(64LL * V, 1 << 20))
+        return 1;
+    FVB_GEOM_CHECK(d_dense.alloc(sizeof(int32_t) * (size_t)span));
+    FVB_GEOM_CHECK(hipMemsetAsync(d_dense.p, 0xff, sizeof(int32_t) * (size_t)span, stream)); // -1
+    const unsigned grid = (unsigned)((V + 255) / 256);
+    hipLaunchKernelGGL(geom_dense_kernel, dim3(grid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, xsize, ysize, first,
+        (int32_t *)d_dense.p);
+    hipLaunchKernelGGL(geom_neighbours_kernel, dim3(grid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, xsize, ysize,
+        first, span, dims * 2 - 1, (const int32_t *)d_dense.p, d_nn);
+    FVB_GEOM_CHECK(hipGetLastError());
+    FVB_GEOM_CHECK(hipStreamSynchronize(stream)); // the temporaries are freed on return
+#undef FVB_GEOM_CHECK
+    return 0;
+}
+
 } // namespace
 
 // One spatial VB run on one device: geometry, work buffers and the per-iteration steps. A single
@@ -190,7 +318,7 @@ struct fvb_spatial_run
     bool has_spatial = false;
     std::vector<int32_t> level_begin;
     DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums;
-    double t_geometry_ms = 0;
+    double t_geometry_ms = 0, t_neighbours_ms = 0;
 
     int open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out, hipStream_t stream_);
     int ak_sums(double *host_sums);
@@ -235,12 +363,24 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     if (!k.setup)
         return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
 
-    // ---- host-side geometry ----
+    // ---- geometry: neighbour table on the device where the geometry allows, else on the host ----
     const auto t_start = std::chrono::steady_clock::now();
-    std::vector<int32_t> nn;
-    std::string err = build_neighbours(sp.coords, V, sp.spatial_dims, nn);
-    if (!err.empty())
-        return api_fail(-41, err);
+    FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6));
+    std::string err;
+    const int on_device = (V > 0 && !getenv("FVB_SPATIAL_HOST_GEOMETRY"))
+        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err) : 1;
+    if (on_device < 0)
+        return api_fail(on_device, err);
+    if (on_device == 1)
+    {
+        std::vector<int32_t> nn;
+        err = build_neighbours(sp.coords, V, sp.spatial_dims, nn);
+        if (!err.empty())
+            return api_fail(-41, err);
+        FVB_HIP_CHECK(hipMemcpyAsync(d_nn.p, nn.data(), sizeof(int32_t) * (size_t)V * 6, hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // nn is a local
+    }
+    t_neighbours_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     const int32_t *X = sp.coords, *Y = sp.coords + V, *Z = sp.coords + 2 * (size_t)V;
     // Level function a x + b y + c z: a stencil offset that leads to a smaller voxel index must
     // lower the level, one that leads to a larger index must raise it. First neighbours only
@@ -300,14 +440,12 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     // ---- device memory ----
     const int n_blocks = std::max(1, std::min(1024, (n_owned + 255) / 256));
     FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V));
-    FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6));
     FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * order.size()));
     FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS));
     FVB_HIP_CHECK(d_sums.alloc(sizeof(double) * FVB_MAX_PARAMS * 2));
     FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)n_blocks * P * 2));
     FVB_HIP_CHECK(d_fprior.alloc(sizeof(double)));
     FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V));
-    FVB_HIP_CHECK(hipMemcpyAsync(d_nn.p, nn.data(), sizeof(int32_t) * (size_t)V * 6, hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, stream));
     double aK0[FVB_MAX_PARAMS];
     for (int i = 0; i < FVB_MAX_PARAMS; i++)
@@ -474,8 +612,8 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
     if ((rc = run.finish()) != 0)
         return rc;
     if (timing)
-        fprintf(stderr, "[fvb spatial] V=%d levels=%zu: geometry %.1f ms, alloc+upload+setup %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
-            run.V, run.level_begin.size() - 1, run.t_geometry_ms, ms(t_start, t_open) - run.t_geometry_ms, ms(t_open, t_enq),
+        fprintf(stderr, "[fvb spatial] V=%d levels=%zu: geometry %.1f ms (neighbours %.1f), alloc+upload+setup %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
+            run.V, run.level_begin.size() - 1, run.t_geometry_ms, run.t_neighbours_ms, ms(t_start, t_open) - run.t_geometry_ms, ms(t_open, t_enq),
             ms(t_enq, now()));
     return 0;
 }

@@ -321,3 +321,38 @@ def test_c5_biexponential_mrf_population():
     calls = []
     hiplib.run_spatial_host(h, sp, y, progress_cb=lambda i, n: calls.append((i, n)))
     assert calls == [(i, 10) for i in range(10)]
+
+
+@gpu
+@pytest.mark.parametrize("dims", [3, 2])
+def test_neighbour_table_built_on_the_device_gives_the_same_run(dims, monkeypatch):
+    """The driver builds the first-neighbour table in three kernels when the geometry allows
+    (non-negative co-ordinates, reasonably dense mask) and on the host otherwise; the host table
+    is checked against the reference's lists above. Same run bit for bit either way."""
+    mask, coords = masked_volume((12, 10, 8), seed=21, keep=0.8)
+    V = coords.shape[1]
+    _, y = smooth_exp_data(coords, 40, 0.04, seed=22)
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 40, num_exps=1, dt=0.04, max_iterations=5, param_overrides={"amp1": dict(type="P")})
+    sp = vbabi.SpatialHolder(coords, spatial_dims=dims)
+    dev = hiplib.run_spatial_host(h, sp, y)
+    monkeypatch.setenv("FVB_SPATIAL_HOST_GEOMETRY", "1")
+    host = hiplib.run_spatial_host(h, sp, y)
+    assert np.array_equal(dev["mvn"], host["mvn"]) and np.array_equal(dev["status"], host["status"])
+    # a geometry the device path declines (two slabs 10 000 planes apart: the offset -> voxel map
+    # would be far larger than the mask) takes the host path by itself, with the same lists
+    monkeypatch.delenv("FVB_SPATIAL_HOST_GEOMETRY")
+    far = coords.copy()
+    far[2, coords[2] >= 4] += 10000
+    a = hiplib.run_spatial_host(h, vbabi.SpatialHolder(far, spatial_dims=dims), y)
+    monkeypatch.setenv("FVB_SPATIAL_HOST_GEOMETRY", "1")
+    b = hiplib.run_spatial_host(h, vbabi.SpatialHolder(far, spatial_dims=dims), y)
+    assert np.array_equal(a["mvn"], b["mvn"])
+    assert np.array_equal(a["mvn"], host["mvn"]) == (dims == 2)     # (in 3 dimensions the cut removed neighbours)
+
+
+@gpu
+def test_misordered_coordinates_are_rejected_by_the_device_scan():
+    coords = vbabi.grid_coords((4, 4, 2))[:, ::-1].copy()
+    h = vbabi.build_config(vbabi.MODEL_POLY, 32, 10, degree=0, param_overrides={"c0": dict(type="M")})
+    with pytest.raises(hiplib.HipEngineError, match="correct order"):
+        hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), np.ones((10, 32), dtype=np.float32))
