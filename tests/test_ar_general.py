@@ -292,3 +292,15 @@ def test_echo_options_are_validated():
         f.set_data("data", np.ones((2, 2, 1, 10), dtype=np.float32))
         with pytest.raises(fabber.FabberError, match="Must be 1 or 2"):
             f.run()
+
+
+@pytest.mark.gpu
+def test_long_series_many_parameters_use_the_large_lds_path():
+    """T = 400, P = 8, two echoes: ~125 KB of LDS per voxel (above the 64 KB default limit)."""
+    rng = np.random.default_rng(12)
+    T, P, V = 400, 8, 24
+    t = np.arange(T)
+    X = np.stack([np.cos(np.pi * (t + 0.5) * k / T) for k in range(P)], axis=1)
+    y = X @ rng.normal(0, 3, (P, V)) + rng.normal(0, 0.5, (T, V))
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, noise=AR, num_echoes=2, ar_cross_terms="dual", max_iterations=4)
+    assert_close_to_oracle(h, y.astype(np.float32))
