@@ -239,6 +239,10 @@ int api_validate(const fvb_config *cfg, bool allow_spatial)
 {
     return validate(cfg, allow_spatial);
 }
+int api_variant()
+{
+    return g_variant;
+}
 int api_residual_mode()
 {
     return g_residual_mode;

@@ -15,6 +15,7 @@ using namespace fvb;
 namespace fvb
 {
 int api_fail(int code, const std::string &msg); // vb_api.hip
+int api_variant();                               // fabber_vb_set_variant: 0 auto, 1 lane, 2 wave
 
 #define FVB_NLLS_CASE(MODEL, TAG, PP)                                                                        \
     case PP:                                                                                                 \
@@ -101,9 +102,11 @@ int validate_nlls(const fvb_config *cfg, const fvb_nlls *nl)
         return api_fail(-12, "poly model: n_params != degree + 1");
     if (nl->max_iterations < 0 || !(nl->lambda0 > 0) || !(nl->lambda_max > 0))
         return api_fail(-60, "bad minimiser settings");
-    if (!get_nlls_kernel(cfg->model, cfg->n_params).fn)
-        return api_fail(-61, "no NLLS kernel is built for this model / number of parameters "
-                             "(poly and linear up to 6 parameters, exp with 1 to 3 exponentials)");
+    if (cfg->model != FVB_MODEL_POLY && cfg->model != FVB_MODEL_LINEAR && cfg->model != FVB_MODEL_EXP)
+        return api_fail(-61, "method=nlls needs a forward model with a device body");
+    if (!get_nlls_kernel(cfg->model, cfg->n_params).fn && wave_layout(cfg->n_times, cfg->n_params, 1).bytes > 160 * 1024)
+        return api_fail(-61, "no NLLS kernel for this problem: no lane instantiation for the model / parameter count and the "
+                             "series does not fit the 160 KB of LDS the wave-per-voxel kernel needs");
     return 0;
 }
 } // namespace
@@ -139,8 +142,22 @@ int32_t fabber_nlls_run_device(const fvb_config *cfg, const fvb_nlls *nl, const 
     na.ka.n_unmasked = n_unmasked;
     na.nl = *nl;
     const NllsKernelInfo k = get_nlls_kernel(cfg->model, cfg->n_params);
-    const unsigned grid = (unsigned)((cfg->n_voxels + 63) / 64);
-    hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64), 0, (hipStream_t)stream, na);
+    const WaveLayout L = wave_layout(cfg->n_times, cfg->n_params, 1);
+    // lane per voxel where an instantiation exists and there are enough voxels to fill the chip
+    // (as the VB kernels, vb_api.cc); wave per voxel otherwise
+    const bool wave_fits = L.bytes <= 160 * 1024;
+    const int variant = api_variant();
+    if (k.fn && variant != 2 && (variant == 1 || cfg->n_voxels >= 4096 || !wave_fits))
+    {
+        const unsigned grid = (unsigned)((cfg->n_voxels + 63) / 64);
+        hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64), 0, (hipStream_t)stream, na);
+    }
+    else
+    {
+        if (L.bytes > 64 * 1024)
+            FVB_HIP_CHECK(hipFuncSetAttribute((const void *)nlls_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes));
+        hipLaunchKernelGGL(nlls_wave_kernel, dim3((unsigned)cfg->n_voxels), dim3(64), L.bytes, (hipStream_t)stream, na, L);
+    }
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }

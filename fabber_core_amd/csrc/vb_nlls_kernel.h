@@ -200,3 +200,178 @@ struct NllsKernelInfo
 };
 NllsKernelInfo get_nlls_kernel(int model, int P);
 } // namespace fvb
+
+// ---------------------------------------------------------------------------------------------
+// The same algorithm, one WAVEFRONT per voxel (any parameter count up to FVB_MAX_PARAMS, any
+// built-in model; also what small volumes use): the linearisation, the moments J'J, J'r, r'r and
+// the symmetric sweep inverse are the wave kernel's (vb_wave_kernel.h); every lane holds the same
+// scalars, so the minimiser's control flow is wave-uniform.
+// ---------------------------------------------------------------------------------------------
+#include "vb_wave_kernel.h"
+
+namespace fvb
+{
+#if defined(__HIPCC__)
+
+__global__ __launch_bounds__(64) void nlls_wave_kernel(const NllsArgs na, const WaveLayout L)
+{
+    extern __shared__ double wave_lds[];
+    const KernelArgs &ka = na.ka;
+    WaveCtx cx;
+    cx.L = L;
+    cx.sh = wave_lds;
+    cx.phi = (int32_t *)(wave_lds + L.n_doubles);
+    cx.lane = threadIdx.x;
+    cx.v = blockIdx.x;
+    cx.V = (size_t)ka.cfg.n_voxels;
+    cx.lin = nullptr;
+    cx.precValid = cx.covValid = false;
+    cx.logdetLam = 0;
+    cx.sv_prec = false;
+    const int v = cx.v, T = L.T, P = L.P, PT = L.PT, PP = L.PP;
+    const size_t V = cx.V;
+    double *sh = cx.sh;
+
+    ModelArgs ma;
+    ma.iopt0 = ka.cfg.model_iopt[0];
+    ma.dopt0 = ka.cfg.model_dopt[0];
+    ma.design = ka.cfg.design;
+
+    FVB_WAVE_FOR(t, T)
+    {
+        sh[L.y + t] = load_data(ka, (size_t)t * V + v);
+        const int idx = ka.cfg.phi_index ? (int)ka.cfg.phi_index[t] : 0;
+        cx.phi[t] = (idx == 255) ? -1 : 0; // masked timepoints drop out of every sum
+    }
+    FVB_WAVE_FOR(i, P)
+    {
+        sh[L.m + i] = ka.cfg.post_mean[i]; // starting estimate, Fabber space
+        sh[L.sv_pm + i] = ka.cfg.post_mean[i]; // sv_pm = the accepted parameters
+    }
+    wave_sync();
+
+    // accepted point: parameters sv_pm, moments sv_Lam (J'J, packed) and sv_m (J'r)
+    int status = wave_recentre(ka, ma, cx);
+    double cf = sh[L.s];
+    FVB_WAVE_FOR(e, PT)
+    sh[L.sv_Lam + e] = sh[L.A + e];
+    FVB_WAVE_FOR(i, P)
+    sh[L.sv_m + i] = sh[L.u + i];
+    wave_sync();
+
+    double lambda = na.nl.lambda0;
+    int niter = 0;
+    bool running = (status == FVB_OK);
+    while (running && niter < na.nl.max_iterations)
+    {
+        niter++;
+        FVB_WAVE_FOR(e, PP)
+        {
+            const int i = e / P, j = e % P;
+            double h = 2.0 * sh[L.sv_Lam + tri(i, j)];
+            if (i == j)
+                h = na.nl.lm ? h * (1.0 + lambda) : h + lambda;
+            sh[L.Lam + e] = h;
+        }
+        wave_sync();
+        double la;
+        int sg;
+        bool solved = wave_sweep_inverse(cx, sh + L.Lam, sh + L.Sig, 0.0, la, sg);
+        FVB_WAVE_FOR(i, P)
+        {
+            double step = 0;
+            for (int j = 0; j < P; j++)
+                step += sh[L.Sig + i * P + j] * (2.0 * sh[L.sv_m + j]);
+            sh[L.rhs + i] = step;
+        }
+        wave_sync();
+        for (int i = 0; i < P; i++)
+            solved = solved && is_finite(sh[L.rhs + i]);
+        FVB_WAVE_FOR(i, P)
+        sh[L.m + i] = sh[L.sv_pm + i] + (solved ? sh[L.rhs + i] : 0.0);
+        wave_sync();
+        const int st = wave_recentre(ka, ma, cx);
+        const double ncf = sh[L.s];
+        if (solved && ncf < cf)
+        {
+            FVB_WAVE_FOR(i, P)
+            {
+                sh[L.sv_pm + i] = sh[L.m + i];
+                sh[L.sv_m + i] = sh[L.u + i];
+            }
+            FVB_WAVE_FOR(e, PT)
+            sh[L.sv_Lam + e] = sh[L.A + e];
+            wave_sync();
+            lambda *= 0.1;
+            const bool converged = 2.0 * fabs(cf - ncf) <= na.nl.cf_tolerance * (fabs(cf) + fabs(ncf) + DBL_EPSILON);
+            cf = ncf;
+            if (st != FVB_OK)
+            {
+                status = st;
+                running = false;
+            }
+            if (converged)
+                running = false;
+        }
+        else
+        {
+            lambda *= 10.0;
+            if (lambda > na.nl.lambda_max)
+                running = false;
+        }
+    }
+
+    // ---- the NLLS precision (inference_nlls.cc:160-184) ----
+    bool fallback = (status != FVB_OK);
+    if (!fallback)
+    {
+        const double mse = cf / (double)(ka.n_unmasked - P);
+        FVB_WAVE_FOR(e, PP)
+        {
+            const int i = e / P, j = e % P;
+            double p = sh[L.sv_Lam + tri(i, j)] / mse;
+            if (i == j && p < 1e-6)
+                p = 1e-6;
+            sh[L.Lam + e] = p;
+        }
+        wave_sync();
+        bool finite = true;
+        for (int e = 0; e < PT; e++)
+            finite = finite && is_finite(sh[L.sv_Lam + e] / mse);
+        double la;
+        bool ok = finite && wave_mvn_invert(cx, sh + L.Lam, sh + L.Sig, la);
+        if (ok)
+            for (int e = 0; e < PP; e++)
+                ok = ok && is_finite(sh[L.Sig + e]);
+        if (!ok)
+        {
+            fallback = true;
+            if (finite)
+                status = FVB_BAD_RESULT;
+        }
+    }
+    double *dst = ka.out.mvn + v;
+    FVB_WAVE_FOR(e, PT)
+    {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= e)
+            i++;
+        const int j = e - i * (i + 1) / 2;
+        dst[(size_t)e * V] = fallback ? ((i == j) ? 1e12 : 0.0) : sh[L.Sig + i * P + j];
+    }
+    FVB_WAVE_FOR(i, P)
+    dst[(size_t)(PT + i) * V] = sh[L.sv_pm + i];
+    if (cx.lane == 0)
+    {
+        dst[(size_t)(PT + P) * V] = 1.0;
+        if (ka.out.status)
+            ka.out.status[v] = status;
+        if (ka.out.iterations)
+            ka.out.iterations[v] = niter;
+        if (ka.out.free_energy)
+            ka.out.free_energy[v] = cf;
+    }
+}
+
+#endif // __HIPCC__
+} // namespace fvb

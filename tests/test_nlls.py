@@ -18,11 +18,20 @@ def oracle_engine(h, data, **kw):
     return oracle.run_nlls(h, data, **kw)
 
 
-def hip_engine(h, data, **kw):
-    return hiplib.nlls_run_host(h, data, **kw)
+def hip_engine(variant):
+    """The HIP path with the lane-per-voxel or the wave-per-voxel kernel forced (the automatic
+    choice takes the wave kernel below 4096 voxels and where no lane instantiation exists)."""
+    def run(h, data, **kw):
+        hiplib.set_variant(variant)
+        try:
+            return hiplib.nlls_run_host(h, data, **kw)
+        finally:
+            hiplib.set_variant("auto")
+    return run
 
 
-ENGINES = [pytest.param(oracle_engine, id="oracle"), pytest.param(hip_engine, id="hip", marks=pytest.mark.gpu)]
+ENGINES = [pytest.param(oracle_engine, id="oracle"), pytest.param(hip_engine("lane"), id="hip-lane", marks=pytest.mark.gpu),
+           pytest.param(hip_engine("wave"), id="hip-wave", marks=pytest.mark.gpu)]
 
 
 def means(res, h):
@@ -141,7 +150,7 @@ def test_non_finite_data_gives_the_uninformative_precision():
 
 
 # ---- oracle vs HIP --------------------------------------------------------------------------------
-def assert_parity(h, data, tol=1e-4, **kw):
+def assert_parity(h, data, tol=1e-4, variant="lane", **kw):
     """Means within `tol` of max(|mean|, sd) - the north star's 1e-4 - and far better in practice
     (checked at 1e-6 for 99 % of the voxels). What is NOT compared is the number of iterations: at
     the minimum a step changes the cost by rounding only, so whether `ncf < cf` holds - and with it
@@ -149,7 +158,7 @@ def assert_parity(h, data, tol=1e-4, **kw):
     either implementation; the stopping rule (relative cost change 1e-8) leaves the parameters
     themselves defined to ~1e-4 sd."""
     ref = oracle.run_nlls(h, data, **kw)
-    got = hiplib.nlls_run_host(h, data, **kw)
+    got = hip_engine(variant)(h, data, **kw)
     assert np.array_equal(ref["status"], got["status"])
     ok = ref["status"] == 0
     P = h.cfg.n_params
@@ -171,23 +180,26 @@ def assert_parity(h, data, tol=1e-4, **kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["lane", "wave"])
 @pytest.mark.parametrize("lm", [False, True])
-def test_parity_polynomial(lm):
+def test_parity_polynomial(lm, variant):
     h, data = cases.poly_problem(512, 10, 2, seed=20260101)
-    assert_parity(h, data, lm=lm)
+    assert_parity(h, data, lm=lm, variant=variant)
 
 
 @pytest.mark.gpu
-def test_parity_linear_model_with_masked_timepoints():
+@pytest.mark.parametrize("variant", ["lane", "wave"])
+def test_parity_linear_model_with_masked_timepoints(variant):
     h, data = cases.linear_problem(300, 200, seed=20260104, masked_timepoints=(5, 17, 100))
-    assert_parity(h, data)
+    assert_parity(h, data, variant=variant)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["lane", "wave"])
 @pytest.mark.parametrize("lm", [False, True])
-def test_parity_single_exponential(lm):
+def test_parity_single_exponential(lm, variant):
     h, data = cases.exp_problem(2048, 50, 1, 0.04, seed=20260102)
-    assert_parity(h, data, lm=lm)
+    assert_parity(h, data, lm=lm, variant=variant)
 
 
 @pytest.mark.gpu
@@ -209,16 +221,21 @@ def test_non_finite_model_on_the_gpu():
     h, data = cases.exp_problem(70, 20, 1, 0.04, seed=1)
     h.cfg.transform[1] = vbabi.TRANSFORM_IDENTITY
     ref = oracle.run_nlls(h, data, start=[0.0, -1e6])
-    got = hiplib.nlls_run_host(h, data, start=[0.0, -1e6])
-    assert np.array_equal(ref["status"] != 0, got["status"] != 0)
-    assert np.array_equal(ref["mvn"], got["mvn"])
+    for variant in ("lane", "wave"):
+        got = hip_engine(variant)(h, data, start=[0.0, -1e6])
+        assert np.array_equal(ref["status"] != 0, got["status"] != 0)
+        assert np.array_equal(ref["mvn"], got["mvn"])
 
 
 @pytest.mark.gpu
-def test_unsupported_parameter_count_is_refused_with_a_message():
-    h = vbabi.build_config(vbabi.MODEL_POLY, 8, 12, degree=8)
-    with pytest.raises(hiplib.HipEngineError, match="no NLLS kernel"):
-        hiplib.nlls_run_host(h, np.zeros((12, 8), dtype=np.float32))
+def test_parameter_counts_without_a_lane_kernel_run_on_the_wave_kernel():
+    rng = np.random.default_rng(5)
+    T, P, V = 64, 9, 200
+    t = np.arange(T)
+    X = np.stack([np.cos(np.pi * (t + 0.5) * k / T) for k in range(P)], axis=1)
+    data = (X @ rng.normal(0, 3, (P, V)) + rng.normal(0, 0.5, (T, V))).astype(np.float32)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X)
+    assert_parity(h, data, variant="auto")
 
 
 # ---- through the reference's API (fabber_capi.h, method=nlls; setup.cc:31-33) ------------------
