@@ -144,11 +144,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the VB engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # FVB_BENCH_REHEARSAL=1: several ranks share ONE GPU and talk over gloo - a rehearsal of the
+    # multi-rank code path on a box with a single GPU (the numbers mean nothing and the line says so)
+    rehearsal = os.environ.get("FVB_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import cases
     from fabber_core_amd import hiplib, parallel
@@ -270,7 +277,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["desc"], "voxels_per_gpu": V, "total_voxels": total_voxels, "timepoints": T,
                        "params": P, "iterations": w["its"], "need_f": bool(args.need_f), "parallelism": "voxel-shard x%d" % world,
-                       "input_dtype": "f32", "mean_iterations": mean_its, "bad_voxels": int(summ[2])},
+                       "input_dtype": "f32", "mean_iterations": mean_its, "bad_voxels": int(summ[2]),
+                       **({"rehearsal": "ranks share one GPU over gloo: not a measurement"} if rehearsal else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
