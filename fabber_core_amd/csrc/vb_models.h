@@ -336,7 +336,7 @@ struct ExpModel
         // not from the one term that differs (f2 - f3 = (amp2 - amp3) e0 for an amplitude,
         // amp (e2 - e3) for a rate): the rounding of those sums, ~1e-16 |g| / (c2 - c3) of noise in
         // J, is part of the reference's behaviour on this model. Measured on the bi-exponential C3
-        // problem with the CPU oracle (tools/measure/structured_j.py): with the noise-free quotient
+        // problem with the CPU oracle (tests/measure/structured_j.py): with the noise-free quotient
         // 0.60 % of the voxels end in a non-finite prediction (most of them in iterations 8-9)
         // against 0.14 % with the reference's arithmetic - the kernel saved 20 % of its time and
         // failed twice as many voxels as the reference, so it is not done.

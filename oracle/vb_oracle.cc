@@ -114,7 +114,7 @@ static bool lu_decompose(Mat &lu, std::vector<int> &piv, int &sign)
 static Mat inverse(const Mat &m)
 {
     const int n = m.n;
-    // Experiment switch (tools/measure/structured_j.py): symmetric sweep inverse without pivoting,
+    // Experiment switch (tests/measure/structured_j.py): symmetric sweep inverse without pivoting,
     // the algorithm of the kernels (vb_math.h). Never set in tests.
     static const bool use_sweep = getenv("ORACLE_SWEEP_INVERSE") != nullptr;
     if (use_sweep)
@@ -552,7 +552,7 @@ struct Linearized
             for (int t = 0; t < T; t++)
                 J[(size_t)t * P + i] = (offset2[t] - offset3[t]) / denom; // :170
         }
-        // Experiment switch (tools/measure/structured_j.py): the same difference quotient for the
+        // Experiment switch (tests/measure/structured_j.py): the same difference quotient for the
         // exponential model without the cancellation of the unperturbed terms. Never set in tests.
         static const bool structured = getenv("ORACLE_STRUCTURED_J") != nullptr;
         if (structured && model->cfg->model == FVB_MODEL_EXP)
