@@ -29,6 +29,7 @@
 #pragma once
 
 #include "vb_lane_kernel.h"
+#include "vb_wave_kernel.h"
 
 #include <cfloat>
 
@@ -207,8 +208,6 @@ NllsKernelInfo get_nlls_kernel(int model, int P);
 // the symmetric sweep inverse are the wave kernel's (vb_wave_kernel.h); every lane holds the same
 // scalars, so the minimiser's control flow is wave-uniform.
 // ---------------------------------------------------------------------------------------------
-#include "vb_wave_kernel.h"
-
 namespace fvb
 {
 #if defined(__HIPCC__)
