@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace fvb;
@@ -394,42 +396,89 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     const long long cy = second_neighbours ? 2 : 1, cz = second_neighbours ? 3 : 1;
     const int n_owned = owned_end - owned_begin;
-    std::vector<long long> level(n_owned);
-    long long lmin = 0, lmax = 0;
-    for (int i = 0; i < n_owned; i++)
-    {
+    auto level_of = [&](int i) -> long long {
         const int v = owned_begin + i;
-        level[i] = (long long)X[v] + cy * Y[v] + cz * Z[v];
-        lmin = (i == 0 || level[i] < lmin) ? level[i] : lmin;
-        lmax = (i == 0 || level[i] > lmax) ? level[i] : lmax;
-    }
+        return (long long)X[v] + cy * Y[v] + cz * Z[v];
+    };
+    // a few host threads over contiguous index ranges (the passes are memory-bound scans of the
+    // co-ordinates); per-thread histograms keep the counting sort stable
+    int nt = (n_owned >= (1 << 18)) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+    if (const char *forced = getenv("FVB_SPATIAL_HOST_THREADS")) // tests: threads on small volumes
+        nt = std::max(1, std::min(64, atoi(forced)));
+    nt = std::max(1, std::min(nt, std::max(n_owned, 1)));
+    auto chunk = [&](int t) { return (int)((long long)n_owned * t / nt); };
+    auto parallel = [&](const std::function<void(int)> &body) {
+        if (nt == 1)
+            return body(0);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++)
+            pool.emplace_back(body, t);
+        body(0);
+        for (auto &th : pool)
+            th.join();
+    };
+    std::vector<long long> tmin(nt, 0), tmax(nt, 0);
+    parallel([&](int t) {
+        long long lo = 0, hi = 0;
+        for (int i = chunk(t); i < chunk(t + 1); i++)
+        {
+            const long long l = level_of(i);
+            lo = (i == chunk(t) || l < lo) ? l : lo;
+            hi = (i == chunk(t) || l > hi) ? l : hi;
+        }
+        tmin[t] = lo;
+        tmax[t] = hi;
+    });
+    long long lmin = 0, lmax = 0;
+    bool first = true;
+    for (int t = 0; t < nt; t++)
+        if (chunk(t + 1) > chunk(t))
+        {
+            lmin = (first || tmin[t] < lmin) ? tmin[t] : lmin;
+            lmax = (first || tmax[t] > lmax) ? tmax[t] : lmax;
+            first = false;
+        }
     std::vector<int32_t> order(std::max(n_owned, 1));
     level_begin.clear();
-    if (lmax - lmin < (1LL << 24))
+    if (lmax - lmin < (1LL << 22))
     {
         // counting sort (stable: voxels of a level stay in index order)
         const size_t nl = (size_t)(lmax - lmin + 1);
-        std::vector<int32_t> start(nl + 1, 0);
-        for (int i = 0; i < n_owned; i++)
-            start[(size_t)(level[i] - lmin) + 1]++;
+        std::vector<std::vector<int32_t> > count(nt, std::vector<int32_t>(nl, 0));
+        parallel([&](int t) {
+            int32_t *c = count[t].data();
+            for (int i = chunk(t); i < chunk(t + 1); i++)
+                c[(size_t)(level_of(i) - lmin)]++;
+        });
+        int32_t running = 0;
         for (size_t l = 0; l < nl; l++)
-            start[l + 1] += start[l];
-        for (size_t l = 0; l < nl; l++)
-            if (start[l + 1] > start[l])
-                level_begin.push_back(start[l]);
+        {
+            const int32_t begin = running;
+            for (int t = 0; t < nt; t++) // thread order = index order
+            {
+                const int32_t n = count[t][l];
+                count[t][l] = running; // becomes this thread's first slot in level l
+                running += n;
+            }
+            if (running > begin)
+                level_begin.push_back(begin);
+        }
         level_begin.push_back(n_owned);
-        for (int i = 0; i < n_owned; i++)
-            order[start[(size_t)(level[i] - lmin)]++] = owned_begin + i;
+        parallel([&](int t) {
+            int32_t *c = count[t].data();
+            for (int i = chunk(t); i < chunk(t + 1); i++)
+                order[c[(size_t)(level_of(i) - lmin)]++] = owned_begin + i;
+        });
     }
     else
     {
         std::vector<int32_t> idx(n_owned);
         for (int i = 0; i < n_owned; i++)
             idx[i] = i;
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level[a] < level[b]; });
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level_of(a) < level_of(b); });
         for (int i = 0; i < n_owned; i++)
         {
-            if (i == 0 || level[idx[i]] != level[idx[i - 1]])
+            if (i == 0 || level_of(idx[i]) != level_of(idx[i - 1]))
                 level_begin.push_back(i);
             order[i] = owned_begin + idx[i];
         }

@@ -356,3 +356,19 @@ def test_misordered_coordinates_are_rejected_by_the_device_scan():
     h = vbabi.build_config(vbabi.MODEL_POLY, 32, 10, degree=0, param_overrides={"c0": dict(type="M")})
     with pytest.raises(hiplib.HipEngineError, match="correct order"):
         hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), np.ones((10, 32), dtype=np.float32))
+
+
+@gpu
+def test_level_order_built_by_several_host_threads_is_the_same(monkeypatch):
+    """Volumes from 262 144 voxels up sort their sweep levels with a few host threads (stable
+    counting sort with per-thread histograms): forced here on a small volume."""
+    mask, coords = masked_volume((13, 11, 9), seed=31, keep=0.85)
+    V = coords.shape[1]
+    _, y = smooth_exp_data(coords, 30, 0.04, seed=32)
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 30, num_exps=1, dt=0.04, max_iterations=4, param_overrides={"amp1": dict(type="P")})
+    sp = vbabi.SpatialHolder(coords)
+    one = hiplib.run_spatial_host(h, sp, y)
+    for n in ("3", "7"):
+        monkeypatch.setenv("FVB_SPATIAL_HOST_THREADS", n)
+        many = hiplib.run_spatial_host(h, sp, y)
+        assert np.array_equal(one["mvn"], many["mvn"]) and np.array_equal(one["status"], many["status"])
