@@ -44,7 +44,8 @@ def voxel_errors(holder, a, b, mask=None):
     return e_mean, e_cov, rel
 
 
-def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=None, allow_iter_mismatch=0, cpu2=None):
+def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=None, allow_iter_mismatch=0, cpu2=None,
+           tol_f=TOL_F):
     """Per-voxel parity: status and iteration counts identical, values within tolerance.
 
     cpu2 (optional) = result of the second CPU build (oracle.run_fma). If two CPU builds of the
@@ -53,7 +54,6 @@ def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=No
     raised to 10x that measured floor - but never beyond the north-star bound of 1e-4 on the
     means (1e-2 sd_i sd_j on covariances)."""
     cfg = holder.cfg
-    tol_f = TOL_F
     if cpu2 is not None:
         okf = (a["status"] == 0) & (cpu2["status"] == 0) & (a["iterations"] == cpu2["iterations"])
         if okf.any():
