@@ -116,3 +116,68 @@ def test_random_cases_are_valid_for_the_oracle():
         h, y, _, desc = random_case(seed)
         res = oracle.run(h, y)
         assert np.mean(res["status"] != 0) < 0.05, desc
+
+
+# ---- spatial VB -----------------------------------------------------------------------------------
+def random_spatial_case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    shape = tuple(int(x) for x in rng.integers(5, 12, 3))
+    mask = rng.random(shape) < rng.uniform(0.7, 1.0)
+    mask[0, 0, 0] = True
+    coords = vbabi.grid_coords(shape, mask)
+    V = coords.shape[1]
+    T = int(rng.integers(10, 40))
+    t = np.arange(T, dtype=np.float64)
+    field = 1.0 + 0.5 * np.sin(coords[0] / 2.0) * np.cos(coords[1] / 3.0) + 0.1 * coords[2]
+    if rng.random() < 0.5:
+        degree = int(rng.integers(0, 3))
+        y = field[None, :] + sum(rng.normal(0, 0.3) * (t[:, None] / T) ** n for n in range(1, degree + 1))
+        opts = dict(degree=degree)
+        model, names = vbabi.MODEL_POLY, ["c%d" % n for n in range(degree + 1)]
+    else:
+        dt = 2.0 / T
+        y = field[None, :] * np.exp(-rng.uniform(0.7, 1.5) * t[:, None] * dt)
+        opts = dict(num_exps=1, dt=dt)
+        model, names = vbabi.MODEL_EXP, ["amp1", "r1"]
+    y = y + rng.normal(0, 0.05, (T, V))
+    overrides, images = {}, {}
+    spatial_types = ["M", "m", "P", "p"]
+    overrides[names[0]] = dict(type=str(rng.choice(spatial_types)))
+    for name in names[1:]:
+        r = rng.random()
+        if r < 0.3:
+            overrides[name] = dict(type=str(rng.choice(spatial_types)))
+        elif r < 0.45 and model == vbabi.MODEL_POLY:
+            overrides[name] = dict(type="A")
+        elif r < 0.6 and model == vbabi.MODEL_POLY:
+            overrides[name] = dict(type="I", prec=float(10 ** rng.uniform(-3, 0)))
+            images[name] = rng.normal(0, 0.3, V)
+    h = vbabi.build_config(model, V, T, max_iterations=int(rng.integers(3, 8)), need_f=bool(rng.random() < 0.4),
+                           param_overrides=overrides, image_priors=images, **opts)
+    sp = vbabi.SpatialHolder(coords, spatial_dims=int(rng.choice([3, 3, 2, 1])),
+                             spatial_speed=float(rng.choice([-1.0, -1.0, 1.5, 3.0])), q1=float(rng.choice([10.0, 5.0])),
+                             q2=float(rng.choice([1.0, 2.0])), update_first_iter=bool(rng.random() < 0.3))
+    desc = "spatial seed %d: shape %s V=%d T=%d model %d priors %s dims %d speed %g first %d F %d" % (
+        seed, shape, V, T, model, {k: v["type"] for k, v in overrides.items()}, sp.sp.spatial_dims, sp.sp.spatial_speed,
+        sp.sp.update_first_iter, h.cfg.need_f)
+    return h, sp, y.astype(np.float32), desc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(32))
+def test_random_spatial_configuration(seed):
+    h, sp, y, desc = random_spatial_case(seed)
+    cpu = oracle.run_spatial(h, sp, y)
+    cpu2 = oracle.run_spatial_fma(h, sp, y)
+    got = hiplib.run_spatial_host(h, sp, y)
+    for r in (cpu, cpu2):
+        r.setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
+    tol_f = 2e-5 if h.cfg.model == vbabi.MODEL_EXP else parity.TOL_F
+    parity.strict(h, cpu, got, what=desc, cpu2=cpu2, tol_f=tol_f)
+
+
+def test_random_spatial_cases_are_valid_for_the_oracle():
+    for seed in range(32):
+        h, sp, y, desc = random_spatial_case(seed)
+        res = oracle.run_spatial(h, sp, y)
+        assert np.mean(res["status"] != 0) < 0.2, desc    # (failed voxels are part of what is compared)
