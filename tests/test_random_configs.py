@@ -82,6 +82,7 @@ def random_case(seed):
         kw["need_f"] = True
     model_id = opts.pop("model")
     h = vbabi.build_config(model_id, V, T, **opts, **kw)
+    h.spec = dict(model=str(model), opts=dict(opts), kw=dict(kw), names=names, noise_kind=str(noise_kind), conv=conv)
     desc = "seed %d: %s T=%d V=%d %s conv=%s variant=%s priors=%s" % (seed, model, T, V, noise_kind, conv, variant,
                                                                   {k: v.get("type", "N") for k, v in overrides.items()})
     return h, y.astype(np.float32), variant, desc
@@ -181,3 +182,71 @@ def test_random_spatial_cases_are_valid_for_the_oracle():
         h, sp, y, desc = random_spatial_case(seed)
         res = oracle.run_spatial(h, sp, y)
         assert np.mean(res["status"] != 0) < 0.2, desc    # (failed voxels are part of what is compared)
+
+
+# ---- the same configurations through the reference's API ------------------------------------------
+def capi_options(h, tmp_path):
+    """The fabber options that describe configuration h (built by random_case) + extra data sets."""
+    sp, kw = h.spec, h.spec["kw"]
+    o = {"method": "vb", "max-iterations": kw["max_iterations"], "save-mvn": True, "save-mean": True, "allow-bad-voxels": True}
+    extra = {}
+    if sp["model"] == "poly":
+        o.update(model="poly", degree=sp["opts"]["degree"])
+    elif sp["model"] == "linear":
+        design = tmp_path / "design.mat"
+        np.savetxt(design, sp["opts"]["design"], fmt="%.17g")
+        o.update(model="linear", basis=str(design))
+    else:
+        o.update(model="exp", **{"num-exps": 1, "dt": repr(sp["opts"]["dt"])})
+    for n, (name, ov) in enumerate(kw["param_overrides"].items(), start=1):
+        o["PSP_byname%d" % n] = name
+        if "type" in ov:
+            o["PSP_byname%d_type" % n] = ov["type"]
+        if "mean" in ov:
+            o["PSP_byname%d_mean" % n] = repr(ov["mean"])
+        if "prec" in ov:
+            o["PSP_byname%d_prec" % n] = repr(ov["prec"])
+        if ov.get("type") == "I":
+            o["PSP_byname%d_image" % n] = "img_" + name
+            extra["img_" + name] = kw["image_priors"][name]
+    kind = sp["noise_kind"]
+    o["noise"] = "white" if kind.startswith("white") else "ar"
+    if "noise_pattern" in kw:
+        o["noise-pattern"] = kw["noise_pattern"]
+    if kind == "ar2":
+        o.update({"num-echoes": 2, "ar1-cross-terms": kw["ar_cross_terms"]})
+    for i, mt in enumerate(kw.get("masked_timepoints", ()), start=1):
+        o["mt%d" % i] = mt
+    if "prior_noise_stddev" in kw:
+        o["prior-noise-stddev"] = repr(kw["prior_noise_stddev"])
+    if sp["conv"] != "maxits":
+        o.update({"convergence": sp["conv"], "min-fchange": kw["min_fchange"]})
+        if sp["conv"] == "lm":
+            o["max-fchange"] = kw["min_fchange"]
+    if kw.get("need_f"):
+        o["save-free-energy"] = True
+    return o, extra
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 96, 3))
+def test_random_configuration_through_the_c_abi(seed, tmp_path):
+    """Two independent routes to the engine's problem block: the C++ host layer resolving the
+    reference's options (FwdModel::GetParameters, noise model / detector options) and
+    vbabi.build_config. Same data, same results."""
+    from fabber_core_amd import fabber
+    h, y, _, desc = random_case(seed)
+    V = h.cfg.n_voxels
+    options, extra = capi_options(h, tmp_path)
+    vol = y.T.reshape(V, 1, 1, -1)
+    extra = {k: np.asarray(v, dtype=np.float32).reshape(V, 1, 1) for k, v in extra.items()}
+    # (image priors travel as float32 through the C ABI: give the direct route the same values)
+    for name, img in h.spec["kw"]["image_priors"].items():
+        img[:] = img.astype(np.float32)
+    out = fabber.run(vol, options, extra_data=extra)
+    eng = hipengine.run(h, y)
+    got = out["finalMVN"].reshape(V, -1).T
+    scale = np.maximum(np.abs(eng["mvn"]), 1e-30)
+    ok = eng["status"] == 0
+    err = (np.abs(got - eng["mvn"]) / scale)[:, ok]
+    assert err.max() < 5e-6, (desc, options, float(err.max()), np.unravel_index(err.argmax(), err.shape))
