@@ -70,7 +70,10 @@ def main():
     idx = np.nonzero(mask.reshape(-1) > 0)[0]
     assert len(idx) == 147
     out = {"mask_index": idx.astype(np.int64), "mask_shape": np.array(mask.shape[::-1], dtype=np.int64)}
-    for run in ("poly", "linear_vb", "linear_spatialvb"):
+    # outdata_linear_nlls: the method=nlls run of the SAME data and design (test_commandline.cc:108-137
+    # runs LinearModelVest once per method), so the series rebuilt from the linear_vb posterior has
+    # the sufficient statistics of that run too and its least-squares answer must be this golden.
+    for run in ("poly", "linear_vb", "linear_spatialvb", "linear_nlls"):
         d = os.path.join(REF, "outdata_" + run)
         for f in sorted(os.listdir(d)):
             if f.endswith(".nii.gz") and f != "modelstd.nii.gz":
