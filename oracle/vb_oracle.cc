@@ -41,7 +41,30 @@ struct SingularError : std::runtime_error
     }
 };
 
-typedef std::vector<double> vec;
+
+// The arithmetic type of the restated algorithm. liboracle.so / liboracle_fma.so: double, as the
+// reference. liboracle_quad.so (-DORACLE_QUAD, make liboracle_quad.so): IEEE binary128 through
+// libquadmath, the SAME statements evaluated with 113-bit significands - the ground truth against
+// which the rounding error of an fp64 build (CPU or GPU) of this algorithm is measured
+// (tests/test_reference_chaos.py). Inputs, constants and outputs stay double.
+#ifdef ORACLE_QUAD
+#include <quadmath.h>
+typedef __float128 real;
+static inline real r_exp(real x) { return expq(x); }
+static inline real r_log(real x) { return logq(x); }
+static inline real r_sqrt(real x) { return sqrtq(x); }
+static inline real r_fabs(real x) { return fabsq(x); }
+static inline real r_pow(real x, real y) { return powq(x, y); }
+#else
+typedef double real;
+static inline real r_exp(real x) { return std::exp(x); }
+static inline real r_log(real x) { return std::log(x); }
+static inline real r_sqrt(real x) { return std::sqrt(x); }
+static inline real r_fabs(real x) { return std::fabs(x); }
+static inline real r_pow(real x, real y) { return std::pow(x, y); }
+#endif
+
+typedef std::vector<real> vec;
 
 // Dense n x n row-major matrix
 struct Mat
@@ -53,11 +76,11 @@ struct Mat
         , a((size_t)n_ * n_, 0.0)
     {
     }
-    double &operator()(int r, int c)
+    real &operator()(int r, int c)
     {
         return a[(size_t)r * n + c];
     }
-    double operator()(int r, int c) const
+    real operator()(int r, int c) const
     {
         return a[(size_t)r * n + c];
     }
@@ -81,10 +104,10 @@ static bool lu_decompose(Mat &lu, std::vector<int> &piv, int &sign)
     for (int k = 0; k < n; k++)
     {
         int p = k;
-        double best = std::fabs(lu(k, k));
+        real best = r_fabs(lu(k, k));
         for (int r = k + 1; r < n; r++)
         {
-            double val = std::fabs(lu(r, k));
+            real val = r_fabs(lu(r, k));
             if (val > best)
             {
                 best = val;
@@ -103,7 +126,7 @@ static bool lu_decompose(Mat &lu, std::vector<int> &piv, int &sign)
         for (int r = k + 1; r < n; r++)
         {
             lu(r, k) /= lu(k, k);
-            const double f = lu(r, k);
+            const real f = lu(r, k);
             for (int c = k + 1; c < n; c++)
                 lu(r, c) -= f * lu(k, c);
         }
@@ -122,15 +145,15 @@ static Mat inverse(const Mat &m)
         Mat w = m;
         for (int k = 0; k < n; k++)
         {
-            const double d = w(k, k);
+            const real d = w(k, k);
             if (d == 0.0)
                 throw SingularError();
-            const double rd = 1.0 / d;
+            const real rd = 1.0 / d;
             for (int i = 0; i < n; i++)
             {
                 if (i == k)
                     continue;
-                const double cik = w(i, k) * rd;
+                const real cik = w(i, k) * rd;
                 for (int j = 0; j <= i; j++)
                 {
                     if (j == k)
@@ -187,7 +210,7 @@ static Mat inverse(const Mat &m)
 }
 
 // NEWMAT LogDeterminant(): log|det| and sign
-static double logdet(const Mat &m, int &sign)
+static real logdet(const Mat &m, int &sign)
 {
     Mat lu = m;
     std::vector<int> piv;
@@ -196,16 +219,16 @@ static double logdet(const Mat &m, int &sign)
         sign = 0;
         return -INFINITY;
     }
-    double l = 0;
+    real l = 0;
     for (int i = 0; i < m.n; i++)
     {
-        double d = lu(i, i);
+        real d = lu(i, i);
         if (d < 0)
         {
             sign = -sign;
             d = -d;
         }
-        l += std::log(d);
+        l += r_log(d);
     }
     return l;
 }
@@ -311,72 +334,72 @@ struct Mvn
 // Scalar special functions
 // ---------------------------------------------------------------------------------------------
 // tools.cc:87-98 (6-term Lanczos)
-static double gammaln(double x)
+static real gammaln(real x)
 {
-    static const double series[7] = { 2.5066282746310005, 76.18009172947146, -86.50532032941677,
+    static const real series[7] = { 2.5066282746310005, 76.18009172947146, -86.50532032941677,
         24.01409824083091, -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5 };
-    double total = 1.000000000190015;
+    real total = 1.000000000190015;
     for (int i = 2; i <= 7; i++)
         total += series[i - 1] / (x + i - 1);
-    return std::log(series[0] * total / x) + (x + 0.5) * std::log(x + 5.5) - x - 5.5;
+    return r_log(series[0] * total / x) + (x + 0.5) * r_log(x + 5.5) - x - 5.5;
 }
 
 // MISCMATHS::digamma is third-party (FSL miscmaths, not in the reference tree). Restated from
 // the function's definition in fp64: psi(x) = psi(x+1) - 1/x until x >= 10, then the
 // asymptotic expansion ln x - 1/2x - sum B_2k / (2k x^2k).
-static double digamma(double x)
+static real digamma(real x)
 {
-    double r = 0;
+    real r = 0;
     while (x < 10.0)
     {
         r -= 1.0 / x;
         x += 1.0;
     }
-    const double f = 1.0 / (x * x);
-    const double t = f
+    const real f = 1.0 / (x * x);
+    const real t = f
         * (-1.0 / 12.0
               + f * (1.0 / 120.0
                         + f * (-1.0 / 252.0
                                   + f * (1.0 / 240.0
                                             + f * (-1.0 / 132.0
                                                       + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
-    return r + std::log(x) - 0.5 / x + t;
+    return r + r_log(x) - 0.5 / x + t;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Transforms (transforms.h:114-242, transforms.cc:17-25)
 // ---------------------------------------------------------------------------------------------
-static double to_model(int tr, double val)
+static real to_model(int tr, real val)
 {
     switch (tr)
     {
     case FVB_TRANSFORM_LOG:
-        return std::exp(val);
+        return r_exp(val);
     case FVB_TRANSFORM_SOFTPLUS:
-        return (val < 10) ? std::log(1 + std::exp(val)) : val;
+        return (val < 10) ? r_log(1 + r_exp(val)) : val;
     case FVB_TRANSFORM_FRACTIONAL:
-        return 1 / (1 + std::exp(val));
+        return 1 / (1 + r_exp(val));
     case FVB_TRANSFORM_ABS:
-        return std::fabs(val);
+        return r_fabs(val);
     default:
         return val;
     }
 }
-static double to_fabber(int tr, double val)
+static real to_fabber(int tr, real val)
 {
     switch (tr)
     {
     case FVB_TRANSFORM_LOG:
-        return std::log(val);
+        return r_log(val);
     case FVB_TRANSFORM_SOFTPLUS:
-        return (val < 10) ? std::log(std::exp(val) - 1) : val;
+        return (val < 10) ? r_log(r_exp(val) - 1) : val;
     case FVB_TRANSFORM_FRACTIONAL:
-        return std::log(1 / val - 1);
+        return r_log(1 / val - 1);
     default:
         return val;
     }
 }
-static double to_model_var(int tr, double val)
+static real to_model_var(int tr, real val)
 {
     switch (tr)
     {
@@ -384,12 +407,12 @@ static double to_model_var(int tr, double val)
     case FVB_TRANSFORM_FRACTIONAL:
         return val;
     case FVB_TRANSFORM_LOG:
-        return std::exp(val);
+        return r_exp(val);
     default: // transforms.cc:17-20
-        return std::pow(to_model(tr, std::sqrt(val)) - to_model(tr, 0), 2);
+        return r_pow(to_model(tr, r_sqrt(val)) - to_model(tr, 0), 2);
     }
 }
-static double to_fabber_var(int tr, double val)
+static real to_fabber_var(int tr, real val)
 {
     switch (tr)
     {
@@ -397,9 +420,9 @@ static double to_fabber_var(int tr, double val)
     case FVB_TRANSFORM_FRACTIONAL:
         return val;
     case FVB_TRANSFORM_LOG:
-        return std::log(val);
+        return r_log(val);
     default: // transforms.cc:22-25
-        return std::pow(to_fabber(tr, to_model(tr, 0) + std::sqrt(val)), 2);
+        return r_pow(to_fabber(tr, to_model(tr, 0) + r_sqrt(val)), 2);
     }
 }
 
@@ -423,7 +446,7 @@ struct Model
             const int degree = cfg->model_iopt[0];
             for (int i = 1; i <= T; i++)
             {
-                double res = 0;
+                real res = 0;
                 int p = 1;
                 for (int n = 0; n <= degree; n++)
                 {
@@ -438,7 +461,7 @@ struct Model
         {
             for (int t = 0; t < T; t++)
             {
-                double s = 0;
+                real s = 0;
                 for (int j = 0; j < P; j++)
                     s += cfg->design[(size_t)t * P + j] * (params[j] - 0.0);
                 result[t] = s + 0.0;
@@ -448,15 +471,15 @@ struct Model
         case FVB_MODEL_EXP: // examples/fwdmodel_exp.cc:65-82
         {
             const int num = cfg->model_iopt[0];
-            const double dt = cfg->model_dopt[0];
+            const real dt = cfg->model_dopt[0];
             for (int i = 0; i < num; i++)
             {
-                double amp = params[2 * i];
-                double r = params[2 * i + 1];
+                real amp = params[2 * i];
+                real r = params[2 * i + 1];
                 for (int k = 0; k < T; k++)
                 {
-                    double t = double(k) * dt;
-                    double val = amp * std::exp(-r * t);
+                    real t = real(k) * dt;
+                    real val = amp * r_exp(-r * t);
                     result[k] += val;
                 }
             }
@@ -482,7 +505,7 @@ struct Model
         if (cfg->model == FVB_MODEL_EXP) // examples/fwdmodel_exp.cc:84-91
         {
             const int num = cfg->model_iopt[0];
-            double data_max = data[0];
+            real data_max = data[0];
             for (int t = 1; t < T; t++)
                 if (data[t] > data_max)
                     data_max = data[t];
@@ -537,7 +560,7 @@ struct Linearized
         vec centre2, centre3, offset2, offset3;
         for (int i = 0; i < P; i++)
         {
-            double delta = centre[i] * 1e-5; // :157-161
+            real delta = centre[i] * 1e-5; // :157-161
             if (delta < 0)
                 delta = -delta;
             if (delta < 1e-10)
@@ -548,7 +571,7 @@ struct Linearized
             centre3[i] -= delta;
             model->EvaluateFabber(centre2, offset2);
             model->EvaluateFabber(centre3, offset3);
-            const double denom = centre2[i] - centre3[i];
+            const real denom = centre2[i] - centre3[i];
             for (int t = 0; t < T; t++)
                 J[(size_t)t * P + i] = (offset2[t] - offset3[t]) / denom; // :170
         }
@@ -557,27 +580,27 @@ struct Linearized
         static const bool structured = getenv("ORACLE_STRUCTURED_J") != nullptr;
         if (structured && model->cfg->model == FVB_MODEL_EXP)
         {
-            const double dt = model->cfg->model_dopt[0];
+            const real dt = model->cfg->model_dopt[0];
             for (int i = 0; i < P; i++)
             {
-                double delta = centre[i] * 1e-5;
+                real delta = centre[i] * 1e-5;
                 if (delta < 0)
                     delta = -delta;
                 if (delta < 1e-10)
                     delta = 1e-10;
-                const double c2 = centre[i] + delta, c3 = centre[i] - delta;
+                const real c2 = centre[i] + delta, c3 = centre[i] - delta;
                 const int tr = model->cfg->transform[i];
-                const double p2 = to_model(tr, c2), p3 = to_model(tr, c3);
+                const real p2 = to_model(tr, c2), p3 = to_model(tr, c3);
                 const int e = i / 2;
-                const double amp = to_model(model->cfg->transform[2 * e], centre[2 * e]);
-                const double rate = to_model(model->cfg->transform[2 * e + 1], centre[2 * e + 1]);
+                const real amp = to_model(model->cfg->transform[2 * e], centre[2 * e]);
+                const real rate = to_model(model->cfg->transform[2 * e + 1], centre[2 * e + 1]);
                 for (int t = 0; t < T; t++)
                 {
-                    const double tt = double(t) * dt;
+                    const real tt = real(t) * dt;
                     if (i % 2 == 0)
-                        J[(size_t)t * P + i] = ((p2 - p3) / (c2 - c3)) * std::exp(-rate * tt);
+                        J[(size_t)t * P + i] = ((p2 - p3) / (c2 - c3)) * r_exp(-rate * tt);
                     else
-                        J[(size_t)t * P + i] = (std::exp(-p2 * tt) - std::exp(-p3 * tt)) * (amp / (c2 - c3));
+                        J[(size_t)t * P + i] = (r_exp(-p2 * tt) - r_exp(-p3 * tt)) * (amp / (c2 - c3));
                 }
             }
         }
@@ -592,7 +615,7 @@ struct Linearized
 // ---------------------------------------------------------------------------------------------
 struct Gamma
 {
-    double b, c;
+    real b, c;
 };
 typedef std::vector<Gamma> NoiseParams;
 
@@ -628,7 +651,7 @@ struct WhiteNoise
         vec k(T);
         for (int t = 0; t < T; t++)
         {
-            double s = 0;
+            real s = 0;
             for (int j = 0; j < P; j++)
                 s += lin.J[(size_t)t * P + j] * (lin.centre[j] - theta.means[j]);
             k[t] = data[t] - lin.offset[t] + s;
@@ -637,22 +660,22 @@ struct WhiteNoise
         for (int i = 0; i < nPhis; i++)
         {
             const vec &Qi = Qis[i];
-            double kQk = 0;
+            real kQk = 0;
             for (int t = 0; t < T; t++)
                 kQk += k[t] * Qi[t] * k[t];
             // (Sigma * J' * Qi * J).Trace()
-            double tr = 0;
+            real tr = 0;
             for (int a = 0; a < P; a++)
                 for (int b2 = 0; b2 < P; b2++)
                 {
-                    double jqj = 0;
+                    real jqj = 0;
                     for (int t = 0; t < T; t++)
                         jqj += lin.J[(size_t)t * P + b2] * Qi[t] * lin.J[(size_t)t * P + a];
                     tr += Sigma(a, b2) * jqj;
                 }
-            double tmp = kQk + tr;
+            real tmp = kQk + tr;
             post[i].b = 1 / (tmp * 0.5 + 1 / prior[i].b); // :255
-            double nTimes = 0;
+            real nTimes = 0;
             for (int t = 0; t < T; t++)
                 nTimes += Qi[t];
             post[i].c = (nTimes - 1) * 0.5 + prior[i].c; // :263
@@ -677,7 +700,7 @@ struct WhiteNoise
         for (int a = 0; a < P; a++)
             for (int b2 = 0; b2 <= a; b2++)
             {
-                double s = 0;
+                real s = 0;
                 for (int t = 0; t < T; t++)
                     s += J[(size_t)t * P + a] * X[t] * J[(size_t)t * P + b2];
                 Ltmp(a, b2) = Ltmp(b2, a) = s;
@@ -696,14 +719,14 @@ struct WhiteNoise
             vec w(T);
             for (int t = 0; t < T; t++)
             {
-                double s = 0;
+                real s = 0;
                 for (int j = 0; j < P; j++)
                     s += J[(size_t)t * P + j] * ml[j];
                 w[t] = X[t] * (data[t] - gml[t] + s);
             }
             for (int a = 0; a < P; a++)
             {
-                double s = 0;
+                real s = 0;
                 for (int t = 0; t < T; t++)
                     s += J[(size_t)t * P + a] * w[t];
                 mTmp[a] = s;
@@ -711,7 +734,7 @@ struct WhiteNoise
             vec rhs(P);
             for (int a = 0; a < P; a++)
             {
-                double s = 0;
+                real s = 0;
                 for (int b2 = 0; b2 < P; b2++)
                     s += L0(a, b2) * thetaPrior.means[b2];
                 rhs[a] = mTmp[a] + s;
@@ -719,7 +742,7 @@ struct WhiteNoise
             const Mat &Sigma = theta.GetCovariance();
             for (int a = 0; a < P; a++)
             {
-                double s = 0;
+                real s = 0;
                 for (int b2 = 0; b2 < P; b2++)
                     s += Sigma(a, b2) * rhs[b2];
                 theta.means[a] = s; // :327-328
@@ -732,10 +755,10 @@ struct WhiteNoise
             vec Delta(P);
             for (int a = 0; a < P; a++)
             {
-                double s = 0;
+                real s = 0;
                 for (int t = 0; t < T; t++)
                     s += J[(size_t)t * P + a] * X[t] * (data[t] - gml[t]);
-                double p1 = 0, p2 = 0;
+                real p1 = 0, p2 = 0;
                 for (int b2 = 0; b2 < P; b2++)
                 {
                     p1 += L0(a, b2) * thetaPrior.means[b2];
@@ -746,13 +769,13 @@ struct WhiteNoise
             Mat M(P);
             for (int a = 0; a < P; a++)
                 for (int b2 = 0; b2 < P; b2++)
-                    M(a, b2) = prec(a, b2) + ((a == b2) ? (double)LMalpha * prec(a, a) : 0.0);
+                    M(a, b2) = prec(a, b2) + ((a == b2) ? (real)LMalpha * prec(a, a) : 0.0);
             try
             {
                 Mat Mi = inverse(M);
                 for (int a = 0; a < P; a++)
                 {
-                    double s = 0;
+                    real s = 0;
                     for (int b2 = 0; b2 < P; b2++)
                         s += Mi(a, b2) * Delta[b2];
                     theta.means[a] = ml[a] + s;
@@ -766,7 +789,7 @@ struct WhiteNoise
     }
 
     // noisemodel_white.cc:365-454
-    double CalcFreeEnergy(const NoiseParams &noise, const NoiseParams &noisePrior, const Mvn &theta,
+    real CalcFreeEnergy(const NoiseParams &noise, const NoiseParams &noisePrior, const Mvn &theta,
         const Mvn &thetaPrior, const Linearized &lin, const vec &data) const
     {
         const int P = theta.n;
@@ -774,7 +797,7 @@ struct WhiteNoise
         vec k(T);
         for (int t = 0; t < T; t++)
         {
-            double s = 0;
+            real s = 0;
             for (int j = 0; j < P; j++)
                 s += J[(size_t)t * P + j] * (lin.centre[j] - theta.means[j]);
             k[t] = data[t] - lin.offset[t] + s;
@@ -783,51 +806,51 @@ struct WhiteNoise
         int nTimes = T - nMasked;
         int nTheta = P;
         int sgn;
-        double expectedLogThetaDist
-            = +0.5 * logdet(theta.GetPrecisions(), sgn) - 0.5 * nTheta * (std::log(2 * M_PI) + 1);
-        double expectedLogPhiDist = 0;
-        double parts[10];
+        real expectedLogThetaDist
+            = +0.5 * logdet(theta.GetPrecisions(), sgn) - 0.5 * nTheta * (r_log(2 * M_PI) + 1);
+        real expectedLogPhiDist = 0;
+        real parts[10];
         for (int i = 0; i < 10; i++)
             parts[i] = 0;
         for (int i = 0; i < nPhis; i++)
         {
-            double si = noise[i].b, ci = noise[i].c;
-            double siPrior = noisePrior[i].b, ciPrior = noisePrior[i].c;
+            real si = noise[i].b, ci = noise[i].c;
+            real siPrior = noisePrior[i].b, ciPrior = noisePrior[i].c;
             expectedLogPhiDist
-                += -gammaln(ci) - ci * std::log(si) - ci + (ci - 1) * (digamma(ci) + std::log(si));
-            double trQ = 0;
+                += -gammaln(ci) - ci * r_log(si) - ci + (ci - 1) * (digamma(ci) + r_log(si));
+            real trQ = 0;
             for (int t = 0; t < T; t++)
                 trQ += Qis[i][t];
-            parts[0] += (digamma(ci) + std::log(si)) * (trQ * 0.5 + ciPrior - 1);
-            parts[9] += -gammaln(ciPrior) - ciPrior * std::log(siPrior) - si * ci / siPrior;
-            double kk = 0;
+            parts[0] += (digamma(ci) + r_log(si)) * (trQ * 0.5 + ciPrior - 1);
+            parts[9] += -gammaln(ciPrior) - ciPrior * r_log(siPrior) - si * ci / siPrior;
+            real kk = 0;
             for (int t = 0; t < T; t++)
                 kk += (Qis[i][t] * k[t]) * (Qis[i][t] * k[t]);
-            double tr = 0; // (Ji' Ji Linv).Trace()
+            real tr = 0; // (Ji' Ji Linv).Trace()
             for (int a = 0; a < P; a++)
                 for (int b2 = 0; b2 < P; b2++)
                 {
-                    double jj = 0;
+                    real jj = 0;
                     for (int t = 0; t < T; t++)
                         jj += (Qis[i][t] * J[(size_t)t * P + a]) * (Qis[i][t] * J[(size_t)t * P + b2]);
                     tr += jj * Linv(b2, a);
                 }
             parts[2] += -0.5 * si * ci * kk - 0.5 * tr; // :416-417
         }
-        parts[3] = +0.5 * logdet(thetaPrior.GetPrecisions(), sgn) - 0.5 * nTimes * std::log(2 * M_PI)
-            - 0.5 * nTheta * std::log(2 * M_PI);
+        parts[3] = +0.5 * logdet(thetaPrior.GetPrecisions(), sgn) - 0.5 * nTimes * r_log(2 * M_PI)
+            - 0.5 * nTheta * r_log(2 * M_PI);
         const Mat &L0 = thetaPrior.GetPrecisions();
-        double q = 0;
+        real q = 0;
         for (int a = 0; a < P; a++)
             for (int b2 = 0; b2 < P; b2++)
                 q += (theta.means[a] - thetaPrior.means[a]) * L0(a, b2) * (theta.means[b2] - thetaPrior.means[b2]);
         parts[4] = -0.5 * q;
-        double tr2 = 0;
+        real tr2 = 0;
         for (int a = 0; a < P; a++)
             for (int b2 = 0; b2 < P; b2++)
                 tr2 += Linv(a, b2) * L0(b2, a);
         parts[5] = -0.5 * tr2;
-        double F = -expectedLogThetaDist - expectedLogPhiDist;
+        real F = -expectedLogThetaDist - expectedLogPhiDist;
         for (int i = 0; i < 10; i++)
             F += parts[i];
         if (!(F - F == 0)) // :445
@@ -844,8 +867,8 @@ struct Conv
     virtual ~Conv()
     {
     }
-    virtual bool Test(double F) = 0;
-    virtual void Reset(double F = -99e99) = 0;
+    virtual bool Test(real F) = 0;
+    virtual void Reset(real F = -99e99) = 0;
     virtual bool UseF() const
     {
         return false;
@@ -871,36 +894,36 @@ struct CountingConv : Conv // convergence.cc:34-67
         , m_max_its(max_its)
     {
     }
-    bool Test(double)
+    bool Test(real)
     {
         ++m_its;
         return m_its >= m_max_its;
     }
-    void Reset(double = -99e99)
+    void Reset(real = -99e99)
     {
         m_its = 0;
     }
 };
 struct FchangeConv : CountingConv // convergence.cc:69-110
 {
-    double m_prev_f, m_min_fchange;
+    real m_prev_f, m_min_fchange;
     bool m_revert, m_save;
-    FchangeConv(int max_its, double min_fchange)
+    FchangeConv(int max_its, real min_fchange)
         : CountingConv(max_its)
         , m_min_fchange(min_fchange)
     {
         Reset();
     }
-    void Reset(double F = -99e99)
+    void Reset(real F = -99e99)
     {
         CountingConv::Reset();
         m_prev_f = F;
         m_save = false;
         m_revert = false;
     }
-    bool Test(double F)
+    bool Test(real F)
     {
-        double diff = F - m_prev_f;
+        real diff = F - m_prev_f;
         m_prev_f = F;
         diff = diff > 0 ? diff : -diff;
         if (diff < m_min_fchange)
@@ -922,13 +945,13 @@ struct FchangeConv : CountingConv // convergence.cc:69-110
 };
 struct FreduceConv : FchangeConv // convergence.cc:111-139
 {
-    FreduceConv(int max_its, double min_fchange)
+    FreduceConv(int max_its, real min_fchange)
         : FchangeConv(max_its, min_fchange)
     {
     }
-    bool Test(double F)
+    bool Test(real F)
     {
-        double diff = F - m_prev_f;
+        real diff = F - m_prev_f;
         if (diff < 0)
         {
             m_revert = true;
@@ -941,23 +964,23 @@ struct TrialModeConv : FchangeConv // convergence.cc:140-251
 {
     int m_trials, m_max_trials;
     bool m_trialmode;
-    TrialModeConv(int max_its, double min_fchange, int max_trials)
+    TrialModeConv(int max_its, real min_fchange, int max_trials)
         : FchangeConv(max_its, min_fchange)
         , m_max_trials(max_trials)
     {
         m_max_its += 1; // :145
         Reset();
     }
-    void Reset(double = -99e99)
+    void Reset(real = -99e99)
     {
         FchangeConv::Reset();
         m_trials = 0;
         m_save = true;
         m_trialmode = false;
     }
-    bool Test(double F)
+    bool Test(real F)
     {
-        double diff = F - m_prev_f;
+        real diff = F - m_prev_f;
         if (!m_trialmode)
         {
             if (diff < 0)
@@ -969,7 +992,7 @@ struct TrialModeConv : FchangeConv // convergence.cc:140-251
                 m_save = false;
                 return false;
             }
-            double absdiff = diff > 0 ? diff : -diff;
+            real absdiff = diff > 0 ? diff : -diff;
             if (absdiff < m_min_fchange)
             {
                 m_revert = false;
@@ -985,7 +1008,7 @@ struct TrialModeConv : FchangeConv // convergence.cc:140-251
         ++m_trials;
         if (diff > 0)
         {
-            double absdiff = diff > 0 ? diff : -diff;
+            real absdiff = diff > 0 ? diff : -diff;
             if (absdiff < m_min_fchange)
             {
                 m_revert = false;
@@ -1013,16 +1036,16 @@ struct TrialModeConv : FchangeConv // convergence.cc:140-251
 struct LMConv : Conv // convergence.cc:252-385
 {
     int m_its, m_max_its;
-    double m_prev, m_max_fchange;
+    real m_prev, m_max_fchange;
     bool m_save, m_revert, m_LM;
-    double m_alpha, m_alphastart, m_alphamax;
-    LMConv(int max_its, double max_fchange)
+    real m_alpha, m_alphastart, m_alphamax;
+    LMConv(int max_its, real max_fchange)
         : m_max_its(max_its)
         , m_max_fchange(max_fchange)
     {
         Reset();
     }
-    void Reset(double F = -99e99)
+    void Reset(real F = -99e99)
     {
         m_its = 0;
         m_prev = F;
@@ -1049,10 +1072,10 @@ struct LMConv : Conv // convergence.cc:252-385
     {
         return (float)m_alpha;
     }
-    bool Test(double F)
+    bool Test(real F)
     {
-        double diff = F - m_prev;
-        double absdiff = diff < 0 ? -diff : diff;
+        real diff = F - m_prev;
+        real absdiff = diff < 0 ? -diff : diff;
         if (!m_LM)
         {
             if (diff < 0)
@@ -1106,7 +1129,7 @@ struct LMConv : Conv // convergence.cc:252-385
     }
 };
 
-static Conv *make_conv(int conv, int max_its, int max_trials, double min_fchange)
+static Conv *make_conv(int conv, int max_its, int max_trials, real min_fchange)
 {
     switch (conv)
     {
@@ -1127,7 +1150,7 @@ static Conv *make_conv(int conv, int max_its, int max_trials, double min_fchange
 // ---------------------------------------------------------------------------------------------
 // Priors (priors.cc:108-181). Returns the free-energy contribution.
 // ---------------------------------------------------------------------------------------------
-static double apply_prior(const fvb_config *cfg, int k, Mvn *prior, const Mvn &fwd_post, int v, int it)
+static real apply_prior(const fvb_config *cfg, int k, Mvn *prior, const Mvn &fwd_post, int v, int it)
 {
     switch (cfg->prior_type[k])
     {
@@ -1150,9 +1173,9 @@ static double apply_prior(const fvb_config *cfg, int k, Mvn *prior, const Mvn &f
     case FVB_PRIOR_ARD: // ARDPrior::ApplyToMVN :150-181
     {
         Mat cov = prior->GetCovariance();
-        double post_mean = fwd_post.means[k];
-        double post_cov = fwd_post.GetCovariance()(k, k);
-        double new_cov = post_mean * post_mean + post_cov;
+        real post_mean = fwd_post.means[k];
+        real post_cov = fwd_post.GetCovariance()(k, k);
+        real new_cov = post_mean * post_mean + post_cov;
         if (it == 0)
         {
             cov(k, k) = cfg->prior_var[k];
@@ -1163,8 +1186,8 @@ static double apply_prior(const fvb_config *cfg, int k, Mvn *prior, const Mvn &f
             cov(k, k) = new_cov;
         }
         prior->SetCovariance(cov);
-        double b = 2 / new_cov;
-        return -1.5 * (std::log(b) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * std::log(b);
+        real b = 2 / new_cov;
+        return -1.5 * (r_log(b) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * r_log(b);
     }
     default:
         throw std::runtime_error("oracle: spatial priors are handled by the spatial loop");
@@ -1233,7 +1256,7 @@ static void load_from_mvn(const fvb_config *cfg, int v, Mvn &fwd_post, NoisePara
     for (int r = 0; r < n; r++)
         for (int c = 0; c <= r; c++)
         {
-            double val = cfg->init_mvn[(row++) * V + v];
+            real val = cfg->init_mvn[(row++) * V + v];
             cov(r, c) = cov(c, r) = val;
         }
     vec means(n);
@@ -1251,21 +1274,23 @@ static void load_from_mvn(const fvb_config *cfg, int v, Mvn &fwd_post, NoisePara
         fwd_post.means[p] = means[p];
     for (int i = 0; i < N; i++)
     {
-        double m = means[P + i], var = cov(P + i, P + i);
+        real m = means[P + i], var = cov(P + i, P + i);
         noise[i].b = var / m; // dist_gamma.cc:29-33
         noise[i].c = m / noise[i].b;
     }
 }
 
-static inline double load_data(const fvb_config *cfg, const void *data, size_t idx)
+static inline real load_data(const fvb_config *cfg, const void *data, size_t idx)
 {
-    return cfg->data_f64 ? ((const double *)data)[idx] : (double)((const float *)data)[idx];
+    return cfg->data_f64 ? ((const double *)data)[idx] : (real)((const float *)data)[idx];
 }
 
+#ifndef ORACLE_QUAD // the binary128 build restates the white-noise voxelwise loop only
 #include "vb_oracle_ar.inc"
 #include "vb_oracle_arn.inc"
 #include "vb_oracle_spatial.inc"
 #include "vb_oracle_nlls.inc"
+#endif
 
 } // namespace
 
@@ -1295,6 +1320,10 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
     model.T = T;
     model.P = P;
     model.data.assign(T, 0.0);
+#ifdef ORACLE_QUAD
+    if (cfg->noise == FVB_NOISE_AR1)
+        return -2;
+#else
     if (cfg->noise == FVB_NOISE_AR1)
     {
         if (cfg->phi_index)
@@ -1325,6 +1354,7 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
         }
         return first;
     }
+#endif
     WhiteNoise noise_model;
     noise_model.init(cfg);
 
@@ -1342,7 +1372,7 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
 
     for (int v = v_begin; v < v_end; v++)
     {
-        // PassModelData (inference_vb.cc:250-264): float image -> double column
+        // PassModelData (inference_vb.cc:250-264): float image -> real column
         vec y(T);
         for (int t = 0; t < T; t++)
             y[t] = load_data(cfg, data, (size_t)t * V + v);
@@ -1355,8 +1385,8 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
         Linearized lin;
         lin.model = &model;
         Mvn fwd_prior(P); // :159 mean 0, precision I
-        double F = 1234.5678;
-        double Fprior = 0;
+        real F = 1234.5678;
+        real Fprior = 0;
         int it = 0;
         int status = FVB_OK;
         int hist_len = 0;
@@ -1466,6 +1496,7 @@ int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs
     return first_bad;
 }
 
+#ifndef ORACLE_QUAD
 // InferenceTechnique::SaveResults (inference.cc:112-281), Vb::SaveResults (inference_vb.cc:966-995)
 int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp)
 {
@@ -1676,5 +1707,6 @@ double oracle_logdet(int32_t n, const double *a, int32_t *sign)
         *sign = s;
     return l;
 }
+#endif // !ORACLE_QUAD
 
 } // extern "C"

@@ -13,6 +13,7 @@ from fabber_core_amd import vbabi
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
 _LIB_FMA = None
+_LIB_QUAD = None
 
 
 class OracleTrace(C.Structure):
@@ -68,6 +69,23 @@ def lib_fma():
     return _LIB_FMA
 
 
+def lib_quad():
+    """The white-noise voxelwise loop evaluated in IEEE binary128 (oracle/Makefile, -DORACLE_QUAD):
+    the ground truth for the rounding error of any fp64 build of the algorithm."""
+    global _LIB_QUAD
+    if _LIB_QUAD is None:
+        path = os.path.join(_ROOT, "oracle", "liboracle_quad.so")
+        src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_quad.so"])
+        L = C.CDLL(path)
+        L.oracle_vb_run.restype = C.c_int32
+        L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        _LIB_QUAD = L
+    return _LIB_QUAD
+
+
 def alloc_outputs(holder):
     """Host result arrays for a config, plus the FvbOutputs struct pointing at them."""
     cfg = holder.cfg
@@ -100,9 +118,14 @@ def prepare_data(holder, data):
     return data
 
 
-def run_fma(holder, data):
+def run_fma(holder, data, **kw):
     """The oracle compiled with FMA contraction: same algorithm, different rounding."""
-    return run(holder, data, _lib=lib_fma())
+    return run(holder, data, _lib=lib_fma(), **kw)
+
+
+def run_quad(holder, data, **kw):
+    """Ground truth: the same statements in binary128 (white noise, voxelwise)."""
+    return run(holder, data, _lib=lib_quad(), **kw)
 
 
 def run(holder, data, v_begin=0, v_end=None, halt_bad_voxel=False, trace_rows=0, _lib=None):

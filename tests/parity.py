@@ -18,6 +18,9 @@ Two kinds of comparison are needed because of a property of the REFERENCE ALGORI
   can and must agree is the population: share of voxels that agree, share of failed voxels,
   distribution of the fitted noise precision / free energy.
 """
+import hashlib
+import os
+
 import numpy as np
 
 import oracle
@@ -37,47 +40,80 @@ def voxel_errors(holder, a, b, mask=None):
     cov_a, mean_a = oracle.unpack_mvn(a["mvn"][:, mask], n)
     cov_b, mean_b = oracle.unpack_mvn(b["mvn"][:, mask], n)
     sd = np.sqrt(np.abs(np.einsum("vii->vi", cov_a)))
-    with np.errstate(divide="ignore", invalid="ignore"):
-        e_mean = np.nanmax(np.abs(mean_a - mean_b) / np.maximum(np.abs(mean_a), sd), axis=1)
-        e_cov = np.nanmax((np.abs(cov_a - cov_b) / (sd[:, :, None] * sd[:, None, :])).reshape(len(sd), -1), axis=1)
-        rel = np.nanmax(np.abs(mean_a[:, :P] - mean_b[:, :P]) / np.maximum(np.abs(mean_a[:, :P]), 1e-12), axis=1)
+
+    def ratio(num, den):
+        # 0 / 0 (an entry with zero spread that both sides reproduce exactly) counts as no error; a
+        # NaN or an infinity on ONE side only must not disappear in a nan-aware maximum: it is inf
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = num / den
+        q = np.where((num == 0) & (den == 0), 0.0, q)
+        return np.where(np.isnan(q), np.inf, q)
+
+    same_nonfinite = (~np.isfinite(mean_a)) & ((mean_a == mean_b) | (np.isnan(mean_a) & np.isnan(mean_b)))
+    e_mean = np.where(same_nonfinite, 0.0, ratio(np.abs(mean_a - mean_b), np.maximum(np.abs(mean_a), sd))).max(axis=1)
+    same_cov = (~np.isfinite(cov_a)) & ((cov_a == cov_b) | (np.isnan(cov_a) & np.isnan(cov_b)))
+    e_cov = np.where(same_cov, 0.0, ratio(np.abs(cov_a - cov_b), sd[:, :, None] * sd[:, None, :])).reshape(len(sd), -1).max(axis=1)
+    rel = np.where(same_nonfinite[:, :P], 0.0,
+                   ratio(np.abs(mean_a[:, :P] - mean_b[:, :P]), np.maximum(np.abs(mean_a[:, :P]), 1e-12))).max(axis=1)
     return e_mean, e_cov, rel
 
 
+RAISED = []  # (what, dict of the tolerances applied) for every strict() call that ran at a raised bound
+
+
 def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=None, allow_iter_mismatch=0, cpu2=None,
-           tol_f=TOL_F):
-    """Per-voxel parity: status and iteration counts identical, values within tolerance.
+           tol_f=TOL_F, allow_floor=False):
+    """Per-voxel parity: status and iteration counts identical, every value finite where the CPU's is,
+    values within tolerance. Returns the observed errors AND the tolerances that were applied.
 
     cpu2 (optional) = result of the second CPU build (oracle.run_fma). If two CPU builds of the
     same source already differ by more than the base tolerance on this problem (the
-    finite-difference Jacobian amplifies rounding, see module docstring), the tolerance is
-    raised to 10x that measured floor - but never beyond the north-star bound of 1e-4 on the
-    means (1e-2 sd_i sd_j on covariances)."""
+    finite-difference Jacobian amplifies rounding, see module docstring), the tolerance MAY be
+    raised to 10x that measured floor - never beyond the north-star bound of 1e-4 on the means
+    (1e-2 sd_i sd_j on covariances) - but only for a caller that opted in with allow_floor=True:
+    a test that needs the raised bound without having asked for it fails, and every call that ran
+    at a raised bound is recorded in RAISED (tests/conftest.py prints them at the end of the run;
+    DESIGN.md section 5.2 lists the tests that opt in)."""
     cfg = holder.cfg
+    base = dict(tol_mean=tol_mean, tol_cov=tol_cov, tol_f=tol_f)
+    floor = dict(tol_mean=0.0, tol_cov=0.0, tol_f=0.0)
     if cpu2 is not None:
         okf = (a["status"] == 0) & (cpu2["status"] == 0) & (a["iterations"] == cpu2["iterations"])
         if okf.any():
             f_mean, f_cov, _ = voxel_errors(holder, a, cpu2, okf)
-            tol_mean = min(max(tol_mean, 10 * float(f_mean.max())), NORTH_STAR)
-            tol_cov = min(max(tol_cov, 10 * float(f_cov.max())), 1e-2)
+            floor["tol_mean"] = min(10 * float(f_mean.max()), NORTH_STAR)
+            floor["tol_cov"] = min(10 * float(f_cov.max()), 1e-2)
             if cfg.need_f:
                 Fa, Fc = a["free_energy"][okf], cpu2["free_energy"][okf]
-                tol_f = min(max(tol_f, 10 * float(np.max(np.abs(Fa - Fc) / np.maximum(1.0, np.abs(Fa))))), 1e-3)
+                floor["tol_f"] = min(10 * float(np.max(np.abs(Fa - Fc) / np.maximum(1.0, np.abs(Fa)))), 1e-3)
     assert np.array_equal(a["status"], b["status"]), (what, "status", np.flatnonzero(a["status"] != b["status"])[:8])
     n_it = int(np.count_nonzero(a["iterations"] != b["iterations"]))
     assert n_it <= allow_iter_mismatch, (what, "iterations differ on %d voxels" % n_it)
     ok = (a["status"] == 0) & (a["iterations"] == b["iterations"])
-    out = dict(err_means=0.0, err_cov=0.0, rel_means=0.0, err_f=0.0)
+    out = dict(err_means=0.0, err_cov=0.0, rel_means=0.0, err_f=0.0, raised=False, **base)
     if not ok.any():
         return out
     e_mean, e_cov, rel = voxel_errors(holder, a, b, ok)
     out.update(err_means=float(e_mean.max()), err_cov=float(e_cov.max()), rel_means=float(rel.max()))
-    assert out["err_means"] <= tol_mean, (what, "means", out["err_means"], tol_mean)
-    assert out["err_cov"] <= tol_cov, (what, "cov", out["err_cov"], tol_cov)
+    errs = dict(tol_mean=out["err_means"], tol_cov=out["err_cov"])
     if check_f if check_f is not None else bool(cfg.need_f):
         Fa, Fb = a["free_energy"][ok], b["free_energy"][ok]
+        assert np.all(np.isfinite(Fb) | ~np.isfinite(Fa)), (what, "non-finite F")
         out["err_f"] = float(np.max(np.abs(Fa - Fb) / np.maximum(1.0, np.abs(Fa))))
-        assert out["err_f"] <= tol_f, (what, "F", out["err_f"], tol_f)
+        errs["tol_f"] = out["err_f"]
+    label = dict(tol_mean="means", tol_cov="cov", tol_f="F")
+    for k, err in errs.items():
+        if err <= base[k]:
+            continue
+        # beyond the base tolerance: only acceptable below the measured CPU-vs-CPU floor, and only on request
+        assert err <= floor[k], (what, label[k], err, "base tolerance %g, 10 x CPU-vs-CPU floor %g" % (base[k], floor[k]))
+        assert allow_floor or os.environ.get("PARITY_RECORD_ONLY"), (
+            what, label[k], err, "within 10 x the CPU-vs-CPU floor (%g) but beyond the base tolerance %g, and the "
+            "test did not opt in with allow_floor=True" % (floor[k], base[k]))
+        out[k] = floor[k]
+        out["raised"] = True
+    if out["raised"]:
+        RAISED.append((what, {k: out[k] for k in base}, {k: errs.get(k, 0.0) for k in base}))
     return out
 
 
@@ -112,3 +148,47 @@ def population(holder, cpu, gpu, floor, what="", slack=0.05):
     assert np.allclose(s["phi_quantiles_b"], s["phi_quantiles_a"], rtol=0.03), (what, s)
     assert abs(s["iters_b"] - s["iters_a"]) <= 0.05 * max(s["iters_a"], 1.0) + 0.5, (what, s)
     return s
+
+
+# ---- binary128 ground truth for the bi-exponential fit (tests/golden/make_c3_truth.py) ---------------
+def load_c3_truth():
+    """The committed ground truth; checks that cases.exp_problem still generates the series it was
+    computed from."""
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if gdir not in sys.path:
+        sys.path.insert(0, gdir)
+    import make_c3_truth as mt
+    f = np.load(os.path.join(gdir, "c3_truth_binary128.npz"))
+    V = int(f["n_voxels"])
+    _, y = mt.problem(V)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == str(f["data_sha256"]), "the seeded series changed"
+    return dict(mvn=f["mvn"], status=f["status"], iterations=f["iterations"], its=[int(i) for i in f["its"]],
+                trace_means=f["trace_means"], n_voxels=V)
+
+
+def truth_stats(holder, truth, r):
+    """Distribution of the per-voxel error of result r against the ground truth: the scaled metric of
+    voxel_errors and SURVEY 8d's pure relative one, over the voxels r finished."""
+    ok = (r["status"] == 0) & (truth["status"] == 0)
+    e, e_cov, rel = voxel_errors(holder, truth, r, ok)
+    q = lambda x, p: float(np.quantile(x, p))
+    return dict(failed=float(np.mean(r["status"] != 0)), within_1e4=float(np.mean(e <= NORTH_STAR)),
+                within_1e6=float(np.mean(e <= 1e-6)), within_1e4_rel=float(np.mean(rel <= NORTH_STAR)),
+                median=q(e, 0.5), p75=q(e, 0.75), p90=q(e, 0.9), p99=q(e, 0.99),
+                median_rel=q(rel, 0.5), p90_rel=q(rel, 0.9), median_cov=q(e_cov, 0.5))
+
+
+def truth_trace_stats(holder, truth_means, r):
+    """Relative error |m - truth| / max(|truth|, 1e-12) (max over the parameters) of the posterior means
+    after a fixed number of iterations; truth_means [P][V]."""
+    P = holder.cfg.n_params
+    n = P + holder.n_noise_outputs
+    off = n * (n + 1) // 2
+    m = r["mvn"][off:off + P]
+    ok = (r["status"] == 0) & np.isfinite(truth_means).all(axis=0)
+    with np.errstate(invalid="ignore"):
+        rel = np.max(np.abs(m[:, ok] - truth_means[:, ok]) / np.maximum(np.abs(truth_means[:, ok]), 1e-12), axis=0)
+    rel = np.where(np.isnan(rel), np.inf, rel)
+    return dict(median=float(np.median(rel)), p90=float(np.quantile(rel, 0.9)), p99=float(np.quantile(rel, 0.99)),
+                within_1e4=float(np.mean(rel <= NORTH_STAR)), failed=float(np.mean(r["status"] != 0)))
