@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: voxels/s of the voxelwise VB hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c4] [--voxels V]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c4|c5] [--voxels V | --grid N]
 
 A "step" is one complete pass of the hot path (every voxel of this rank's shard fitted to VB
 convergence: fabber_vb_run_device = Vb::DoCalculationsVoxelwise) over one batch of synthetic
@@ -43,6 +43,9 @@ WORKLOADS = {
                desc="BASELINE configs[1]: exp single-exponential, white noise, 50 timepoints, 128x128x64 voxels, max-iterations 10"),
     "c1": dict(kind="poly", degree=2, T=10, voxels=8 * 8 * 8, its=10,
                desc="BASELINE configs[0]: poly degree 2, white noise, 10 timepoints, 8x8x8 volume, max-iterations 10"),
+    "c5": dict(kind="spatial", num_exps=2, T=100, dt=0.02, grid=128, voxels=128 ** 3, its=10,
+               desc="BASELINE configs[4]: spatial VB, bi-exponential with a 6-neighbour MRF prior (type M) on amp1, "
+                    "128^3 voxels, 100 timepoints, max-iterations 10 (one GPU: the whole volume)"),
     "c4": dict(kind="linear_ar", T=200, voxels=2_000_000, its=10,
                desc="BASELINE configs[3] model: linear design (4 regressors), AR(1) noise, 200 timepoints, max-iterations 10; "
                     "2e6 voxels per GPU by default (the 256^3 volume is --voxels 16777216: 13 GB of series)"),
@@ -122,6 +125,74 @@ def pmc_traffic(workload, V, kernel, args):
                                        "Infinity Cache at this size) and register spill traffic; see DESIGN.md"}}
 
 
+def bench_spatial(args, world, rank, device):
+    """--workload c5: one step = one complete spatial VB run (Vb::DoCalculationsSpatial: geometry, set-up and
+    `its` Gauss-Seidel sweeps) of the whole volume on one GPU, series resident in HBM."""
+    if world != 1:
+        raise SystemExit("--workload c5 runs on one GPU (the slab decomposition is fabber_core_amd/spatial_mgpu.py)")
+    import cases
+    from fabber_core_amd import vbabi
+    from fabber_core_amd.device import DeviceProblem
+    w = WORKLOADS["c5"]
+    n = args.grid or w["grid"]
+    holder, coords, y, _ = cases.c5_problem((n, n, n), max_iterations=w["its"], need_f=bool(args.need_f))
+    V, T, P = holder.cfg.n_voxels, w["T"], holder.cfg.n_params
+    sp = vbabi.SpatialHolder(coords)
+    prob = DeviceProblem(holder, y, device)
+    for _ in range(args.warmup):
+        prob.run_spatial(sp)
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        prob.run_spatial(sp)  # returns when the stream has drained
+        ev[i][1].record()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    got = prob.results()
+    rows = holder.n_mvn_rows
+    alg_bytes = (4 * T + 4 * rows + w["its"] * 6 * 8) * V  # SURVEY 8d: C3's bytes + 6 neighbour means per iteration
+    roofline = {"bound": "hbm", "kernel": "spatial<exp,%d>: vb_spatial_* kernels of one run" % P,
+                "achieved": alg_bytes / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dev_ms,
+                "note": "device time of one run between HIP events (all its kernels; the host builds no tables in between); "
+                        "per-kernel durations: profiles/r2_kernel_stats_c5.csv"}
+    cpu = None
+    if args.cpu_sample > 0:
+        import oracle
+        import parity
+        m = min(32, n)
+        keep = np.flatnonzero((coords[0] < m) & (coords[1] < m) & (coords[2] < m))
+        hs, _, _, _ = cases.c5_problem((m, m, m), max_iterations=w["its"], need_f=bool(args.need_f))  # (config only)
+        ys = np.ascontiguousarray(y[:, keep])
+        sps = vbabi.SpatialHolder(np.ascontiguousarray(coords[:, keep]))
+        c0 = time.perf_counter()
+        ref = oracle.run_spatial(hs, sps, ys)
+        cpu_s = time.perf_counter() - c0
+        from fabber_core_amd import hiplib
+        sub = hiplib.run_spatial_host(hs, sps, ys)
+        floor = parity.population_stats(hs, ref, oracle.run_spatial_fma(hs, sps, ys))
+        stats = parity.population_stats(hs, ref, sub)
+        tolist = lambda d: {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in d.items()}
+        cpu = {"value": len(keep) / cpu_s, "unit": "voxels/s", "cores": 1, "kind": "port",
+               "sample": "the %d^3 corner block of the volume as a spatial problem of its own, same model / prior / iterations, "
+                         "oracle/liboracle.so single thread, %.1f s" % (m, cpu_s),
+               "gpu_over_cpu_single_thread": (V / (dev_ms * 1e-3)) / (len(keep) / cpu_s),
+               "gpu_vs_cpu_on_the_block": tolist(stats), "cpu_vs_cpu_fma_build_floor": tolist(floor)}
+    result = {"metric": "voxels/sec to VB convergence", "value": V * args.steps / elapsed, "unit": "voxels/s", "n_gpus": 1,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": w["desc"], "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
+                         "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32",
+                         "bad_voxels": int(np.count_nonzero(got["status"])), "ms_per_iteration": dev_ms / w["its"]},
+              "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(result), flush=True)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +200,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--voxels", type=int, default=None, help="voxels per GPU (default: the workload's)")
+    ap.add_argument("--grid", type=int, default=None, help="c5: side of the cubic volume (default 128)")
     ap.add_argument("--need-f", action="store_true", help="also evaluate the free energy 4x per iteration (CLI default of the reference)")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="voxels timed on the CPU oracle (0 = skip)")
     ap.add_argument("--variant", default="auto", choices=["auto", "lane", "wave"])
@@ -161,6 +233,8 @@ def main():
     from fabber_core_amd import hiplib, parallel
     from fabber_core_amd.device import DeviceProblem
 
+    if WORKLOADS[args.workload].get("kind") == "spatial":
+        return bench_spatial(args, world, rank, device)
     hiplib.set_variant(args.variant)
     hiplib.set_residual_mode(args.residual)
     if args.residual_tol is not None:

@@ -67,7 +67,20 @@ def _compile_one(args):
     return obj, True, p.stderr
 
 
-def build_hip(force=False, jobs=None, verbose=True, extra_flags=()):
+def build_hip(force=False, jobs=None, verbose=True, extra_flags=(), variant=None):
+    """variant: build an experiment copy of the engine - objects under build/obj_<variant>, library
+    lib/libfabber_vb_hip_<variant>.so (load it with FVB_LIB_PATH=...) - next to the product library."""
+    global OBJDIR
+    objdir_product = OBJDIR
+    if variant:
+        OBJDIR = os.path.join(HERE, "build", "obj_" + variant)
+    try:
+        return _build_hip(force, jobs, verbose, extra_flags, variant)
+    finally:
+        OBJDIR = objdir_product
+
+
+def _build_hip(force, jobs, verbose, extra_flags, variant):
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     flags = HIP_FLAGS + list(extra_flags) + os.environ.get("FVB_EXTRA_HIPCC_FLAGS", "").split()
@@ -82,7 +95,7 @@ def build_hip(force=False, jobs=None, verbose=True, extra_flags=()):
                 print("[build] compiled", os.path.basename(obj), file=sys.stderr)
             if verbose and warn.strip():
                 print(warn, file=sys.stderr)
-    lib = os.path.join(LIBDIR, "libfabber_vb_hip.so")
+    lib = os.path.join(LIBDIR, "libfabber_vb_hip%s.so" % ("_" + variant if variant else ""))
     if rebuilt or not os.path.exists(lib):
         cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         p = subprocess.run(cmd, capture_output=True, text=True)
@@ -179,6 +192,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--variant", default=None, help="experiment copy of the HIP engine only (with --flags)")
+    ap.add_argument("--flags", default="", help="extra hipcc flags for --variant, e.g. '-DFVB_NO_RESCUE'")
     a = ap.parse_args()
+    if a.variant:
+        print(build_hip(force=a.force, jobs=a.jobs, extra_flags=a.flags.split(), variant=a.variant))
+        sys.exit(0)
     for l in build_all(force=a.force, jobs=a.jobs):
         print(l)

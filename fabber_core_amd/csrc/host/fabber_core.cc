@@ -1,10 +1,20 @@
 /* fabber_core.cc - the `fabber` command line tool on the MI355X engine.
  *
- * Behaviour of the reference's execute() (fabber_core.cc:88-323): options with --key[=value] or
- * -f <file>; the information queries (--help, --version, --listmodels, --listmethods,
- * --listparams, --descparams, --listoutputs, --evaluate) answer on stdout without touching any
- * data; otherwise data / mask are NIfTI files, results go to --output as NIfTI plus logfile and
- * paramnames.txt. Exit code 0 on success, 1 after any exception (message on stderr and in the log). */
+ * What the tool does (the behaviour of the reference's execute(), fabber_core.cc:88-323, and of
+ * tests/test_cli_nifti.py):
+ *   - options come as --key, --key=value or from "-f <file>" (one key=value per line);
+ *   - a set of "questions" is answered on stdout without touching any image: no arguments / --help
+ *     (general usage, or that of --model / --method), --version (of the tool or of --model),
+ *     --listmodels, --listmethods, --listparams / --descparams, --listoutputs, --evaluate[=<output>]
+ *     with --evaluate-params, --evaluate-nt and optionally --evaluate-data;
+ *   - anything else is a fit: data and mask are NIfTI files, the result images, the logfile and
+ *     paramnames.txt go to --output (made unique with '+' signs, "<output>_latest" links to it);
+ *   - exit code 0 on success, 1 after any exception; the message goes to stderr and to the logfile, or,
+ *     when the failure came before the logfile existed, everything logged so far goes to stderr.
+ *
+ * Structure: the questions are rows of one table (flag -> predicate -> answer); execute() parses,
+ * walks the table and otherwise hands over to fit(); Session owns the log and the exit bookkeeping.
+ */
 #include "fabber_core/fabber_core.h"
 
 #include "fabber_core/fwdmodel.h"
@@ -15,210 +25,255 @@
 
 #include "armawrap/newmat.h"
 
+#include <cstdlib>
 #include <exception>
 #include <iostream>
 #include <memory>
-#include <stdlib.h>
 #include <string>
 #include <vector>
 
-using namespace std;
-using NEWMAT::ColumnVector;
-using NEWMAT::Matrix;
-
-static void Version()
+namespace
 {
-    cout << "Fabber " << fabber_version() << " : " << fabber_source_date() << endl;
+typedef FabberRunDataNewimage Options;
+
+void print_lines(const std::vector<std::string> &lines)
+{
+    for (const std::string &l : lines)
+        std::cout << l << std::endl;
 }
 
-static void Usage()
+void print_banner_version()
 {
-    Version();
-    cout << "Usage: fabber [--<option>|--<option>=<value> ...]" << endl
-         << endl
-         << "Use -f <file> to read options in option=value form" << endl
-         << "Use -@ <file> to read options in command line form (DEPRECATED)." << endl
-         << endl
-         << "General options " << endl
-         << endl;
-    vector<OptionSpec> options;
-    FabberRunData::GetOptions(options);
-    for (unsigned int i = 0; i < options.size(); i++)
-        cout << options[i] << endl;
+    std::cout << "Fabber " << fabber_version() << " : " << fabber_source_date() << std::endl;
 }
 
-/** A model set up from the options, with its log output swallowed */
-static std::unique_ptr<FwdModel> quiet_model(FabberRunData &params, EasyLog &sink)
+/** The model named by --model, initialised from the options, talking to a log nobody reads. */
+struct SilentModel
 {
-    std::unique_ptr<FwdModel> fwd_model(FwdModel::NewFromName(params.GetStringDefault("model", "")));
-    fwd_model->SetLogger(&sink);
-    fwd_model->Initialize(params);
-    return fwd_model;
+    EasyLog sink;
+    std::unique_ptr<FwdModel> model;
+    explicit SilentModel(Options &opts)
+        : model(FwdModel::NewFromName(opts.GetStringDefault("model", "")))
+    {
+        model->SetLogger(&sink);
+        model->Initialize(opts);
+    }
+    FwdModel *operator->()
+    {
+        return model.get();
+    }
+};
+
+// ---- the questions ---------------------------------------------------------------------------------
+void answer_help(Options &opts)
+{
+    const std::string model = opts.GetStringDefault("model", ""), method = opts.GetStringDefault("method", "");
+    if (!model.empty())
+    {
+        FwdModel::UsageFromName(model, std::cout);
+        return;
+    }
+    if (!method.empty())
+    {
+        InferenceTechnique::UsageFromName(method, std::cout);
+        return;
+    }
+    print_banner_version();
+    std::cout << "Usage: fabber [--<option>|--<option>=<value> ...]\n\n"
+              << "Use -f <file> to read options in option=value form\n"
+              << "Use -@ <file> to read options in command line form (DEPRECATED).\n\n"
+              << "General options \n"
+              << std::endl;
+    std::vector<OptionSpec> general;
+    FabberRunData::GetOptions(general);
+    for (const OptionSpec &o : general)
+        std::cout << o << std::endl;
 }
 
-int execute(int argc, char **argv)
+void answer_version(Options &opts)
 {
+    const std::string model = opts.GetStringDefault("model", "");
+    if (model.empty())
+        print_banner_version();
+    else
+        std::cout << std::unique_ptr<FwdModel>(FwdModel::NewFromName(model))->ModelVersion() << std::endl;
+}
+
+void answer_models(Options &)
+{
+    print_lines(FwdModel::GetKnown());
+}
+
+void answer_methods(Options &)
+{
+    print_lines(InferenceTechnique::GetKnown());
+}
+
+void answer_params(Options &opts)
+{
+    SilentModel m(opts);
+    std::vector<Parameter> ps;
+    m->GetParameters(opts, ps);
+    const bool with_description = opts.GetBool("descparams");
+    for (const Parameter &p : ps)
+    {
+        std::cout << p.name;
+        if (with_description)
+        {
+            std::cout << " " << p.desc;
+            if (!p.units.empty())
+                std::cout << " (units: " << p.units << ")";
+        }
+        std::cout << std::endl;
+    }
+}
+
+void answer_outputs(Options &opts)
+{
+    SilentModel m(opts);
+    std::vector<std::string> names;
+    m->GetOutputs(names);
+    print_lines(names);
+}
+
+/** --evaluate: one model evaluation for the parameter values in a matrix file */
+void answer_evaluate(Options &opts)
+{
+    SilentModel m(opts);
+    const NEWMAT::ColumnVector values = fabber::read_matrix_file(opts.GetString("evaluate-params")).Column(1);
+    const int n = opts.GetInt("evaluate-nt", 0);
+    NEWMAT::ColumnVector series(n);
+    series = 0.0;
+    if (opts.HaveKey("evaluate-data"))
+        series = fabber::read_matrix_file(opts.GetString("evaluate-data")).Column(1);
+    NEWMAT::ColumnVector where(3);
+    where = 1.0;
+    m->PassData(1, series, where);
+    NEWMAT::ColumnVector prediction(n);
+    m->EvaluateModel(values, prediction, opts.GetStringDefault("evaluate", ""));
+    for (int t = 1; t <= prediction.Nrows(); t++)
+        std::cout << prediction(t) << std::endl;
+}
+
+struct Question
+{
+    bool (*asked)(Options &, int argc);
+    void (*answer)(Options &);
+};
+
+template <const char *const &FLAG>
+bool flag_set(Options &o, int)
+{
+    return o.GetBool(FLAG);
+}
+const char *const F_VERSION = "version", *const F_MODELS = "listmodels", *const F_METHODS = "listmethods",
+                  *const F_OUTPUTS = "listoutputs";
+
+// in the order they take precedence
+const Question QUESTIONS[] = {
+    { [](Options &o, int argc) { return argc == 1 || o.GetBool("help"); }, answer_help },
+    { flag_set<F_VERSION>, answer_version },
+    { flag_set<F_MODELS>, answer_models },
+    { flag_set<F_METHODS>, answer_methods },
+    { [](Options &o, int) { return o.GetBool("listparams") || o.GetBool("descparams"); }, answer_params },
+    { flag_set<F_OUTPUTS>, answer_outputs },
+    { [](Options &o, int) { return o.HaveKey("evaluate"); }, answer_evaluate },
+};
+
+// ---- a fit -----------------------------------------------------------------------------------------
+/** The log of one invocation and what has to happen to it whichever way the invocation ends. */
+class Session
+{
+public:
     EasyLog log;
-    bool gzLog = false;
-    bool simple_output = false;
-    int ret = 1;
+    bool quiet = false;    // --simple-output
+    bool compress = false; // --gzip-log, honoured only after a clean finish
 
-    try
-    {
-        setenv("FSLOUTPUTTYPE", "NIFTI_GZ", 0); // may be missing if FSL is not installed
-
-        FabberRunDataNewimage paramso(true);
-        FabberRunDataNewimage *params = &paramso;
-        params->SetLogger(&log);
-        params->Parse(argc, argv);
-
-        if (params->GetBool("help") || argc == 1)
-        {
-            string model = params->GetStringDefault("model", "");
-            string method = params->GetStringDefault("method", "");
-            if (model != "")
-                FwdModel::UsageFromName(model, cout);
-            else if (method != "")
-                InferenceTechnique::UsageFromName(method, cout);
-            else
-                Usage();
-            return 0;
-        }
-        if (params->GetBool("version"))
-        {
-            string model_name = params->GetStringDefault("model", "");
-            if (model_name != "")
-            {
-                std::unique_ptr<FwdModel> model(FwdModel::NewFromName(model_name));
-                cout << model->ModelVersion() << endl;
-            }
-            else
-                Version();
-            return 0;
-        }
-        if (params->GetBool("listmodels"))
-        {
-            vector<string> models = FwdModel::GetKnown();
-            for (size_t i = 0; i < models.size(); i++)
-                cout << models[i] << endl;
-            return 0;
-        }
-        if (params->GetBool("listmethods"))
-        {
-            vector<string> infers = InferenceTechnique::GetKnown();
-            for (size_t i = 0; i < infers.size(); i++)
-                cout << infers[i] << endl;
-            return 0;
-        }
-        if (params->GetBool("listparams") || params->GetBool("descparams"))
-        {
-            const bool describe = params->GetBool("descparams");
-            EasyLog sink;
-            std::unique_ptr<FwdModel> fwd_model = quiet_model(*params, sink);
-            vector<Parameter> model_params;
-            fwd_model->GetParameters(*params, model_params);
-            for (size_t i = 0; i < model_params.size(); i++)
-            {
-                cout << model_params[i].name;
-                if (describe)
-                {
-                    cout << " " << model_params[i].desc;
-                    if (model_params[i].units != "")
-                        cout << " (units: " << model_params[i].units << ")";
-                }
-                cout << endl;
-            }
-            return 0;
-        }
-        if (params->GetBool("listoutputs"))
-        {
-            EasyLog sink;
-            std::unique_ptr<FwdModel> fwd_model = quiet_model(*params, sink);
-            vector<string> model_outputs;
-            fwd_model->GetOutputs(model_outputs);
-            for (size_t i = 0; i < model_outputs.size(); i++)
-                cout << model_outputs[i] << endl;
-            return 0;
-        }
-        if (params->HaveKey("evaluate"))
-        {
-            EasyLog sink;
-            std::unique_ptr<FwdModel> fwd_model = quiet_model(*params, sink);
-            Matrix param_values = fabber::read_matrix_file(params->GetString("evaluate-params"));
-            ColumnVector p_vec = param_values.Column(1);
-            int n_ts = params->GetInt("evaluate-nt", 0);
-            ColumnVector data_vec(n_ts);
-            for (int i = 1; i <= n_ts; i++)
-                data_vec(i) = 0;
-            if (params->HaveKey("evaluate-data"))
-            {
-                Matrix data_values = fabber::read_matrix_file(params->GetString("evaluate-data"));
-                data_vec = data_values.Column(1);
-            }
-            ColumnVector coords(3);
-            coords(1) = coords(2) = coords(3) = 1;
-            fwd_model->PassData(1, data_vec, coords);
-            ColumnVector o_vec(n_ts);
-            fwd_model->EvaluateModel(p_vec, o_vec, params->GetStringDefault("evaluate", ""));
-            for (int i = 0; i < o_vec.Nrows(); i++)
-                cout << o_vec(i + 1) << endl;
-            return 0;
-        }
-
-        params->SetBool("dump-param-names"); // the command line tool writes paramnames.txt
-        params->SetBool("link-to-latest");
-        params->SetExtentFromData();
-        simple_output = params->GetBool("simple-output");
-
-        log.StartLog(params->GetOutputDir());
-        if (!simple_output)
-        {
-            cout << "----------------------" << endl;
-            cout << "Welcome to FABBER " << fabber_version() << endl;
-            cout << "----------------------" << endl;
-            cout << "Last commit: " << fabber_source_date() << endl;
-            cout << "Logfile started: " << log.GetOutputDirectory() << "/logfile" << endl;
-            PercentProgressCheck progress;
-            params->Run(&progress);
-        }
-        else
-        {
-            SimpleProgressCheck progress;
-            params->Run(&progress);
-        }
-        log.ReissueWarnings();
-        gzLog = params->GetBool("gzip-log"); // only gzip the log if we exit normally
-        ret = 0;
-    }
-    catch (NEWMAT::Exception &e)
+    void failed(const std::string &headline, const char *detail)
     {
         log.ReissueWarnings();
-        log.LogStream() << "NEWMAT exception caught in fabber:\n  " << e.what() << endl;
-        cerr << "NEWMAT exception caught in fabber:\n  " << e.what() << endl;
-    }
-    catch (const exception &e)
-    {
-        log.ReissueWarnings();
-        log.LogStream() << "Exception caught in fabber:\n  " << e.what() << endl;
-        cerr << "Exception caught in fabber:\n  " << e.what() << endl;
-    }
-    catch (...)
-    {
-        log.ReissueWarnings();
-        log.LogStream() << "Some other exception caught in fabber!" << endl;
-        cerr << "Some other exception caught in fabber!" << endl;
+        for (std::ostream *to : { &log.LogStream(), static_cast<std::ostream *>(&std::cerr) })
+        {
+            *to << headline;
+            if (detail)
+                *to << "\n  " << detail;
+            *to << std::endl;
+        }
     }
 
-    if (log.LogStarted())
+    void close()
     {
-        if (!simple_output)
-            cout << endl << "Final logfile: " << log.GetOutputDirectory() << (gzLog ? "/logfile.gz" : "/logfile") << endl;
-        log.StopLog(gzLog);
+        if (!log.LogStarted())
+        {
+            // nothing was ever written to a file: what was buffered goes to stderr
+            log.StartLog(std::cerr);
+            log.StopLog();
+            return;
+        }
+        if (!quiet)
+            std::cout << std::endl
+                      << "Final logfile: " << log.GetOutputDirectory() << (compress ? "/logfile.gz" : "/logfile") << std::endl;
+        log.StopLog(compress);
+    }
+};
+
+void fit(Options &opts, Session &s)
+{
+    opts.SetBool("dump-param-names"); // paramnames.txt is part of the tool's output
+    opts.SetBool("link-to-latest");
+    opts.SetExtentFromData();
+    s.quiet = opts.GetBool("simple-output");
+    s.log.StartLog(opts.GetOutputDir());
+    if (s.quiet)
+    {
+        SimpleProgressCheck progress;
+        opts.Run(&progress);
     }
     else
     {
-        log.StartLog(cerr); // never got as far as the logfile: flush what was buffered to stderr
-        log.StopLog();
+        const std::string rule(22, '-');
+        std::cout << rule << "\nWelcome to FABBER " << fabber_version() << "\n" << rule << std::endl;
+        std::cout << "Last commit: " << fabber_source_date() << std::endl;
+        std::cout << "Logfile started: " << s.log.GetOutputDirectory() << "/logfile" << std::endl;
+        PercentProgressCheck progress;
+        opts.Run(&progress);
     }
-    return ret;
+    s.log.ReissueWarnings();
+    s.compress = opts.GetBool("gzip-log");
+}
+} // namespace
+
+int execute(int argc, char **argv)
+{
+    Session session;
+    int exit_code = 1;
+    try
+    {
+        setenv("FSLOUTPUTTYPE", "NIFTI_GZ", 0); // image writers look at it; absent without an FSL installation
+        Options opts(true);
+        opts.SetLogger(&session.log);
+        opts.Parse(argc, argv);
+        for (const Question &q : QUESTIONS)
+            if (q.asked(opts, argc))
+            {
+                q.answer(opts);
+                return 0;
+            }
+        fit(opts, session);
+        exit_code = 0;
+    }
+    catch (NEWMAT::Exception &e)
+    {
+        session.failed("NEWMAT exception caught in fabber:", e.what());
+    }
+    catch (const std::exception &e)
+    {
+        session.failed("Exception caught in fabber:", e.what());
+    }
+    catch (...)
+    {
+        session.failed("Some other exception caught in fabber!", nullptr);
+    }
+    session.close();
+    return exit_code;
 }

@@ -504,7 +504,27 @@ void Vb::DoCalculations(FabberRunData &rundata)
         out.f_history = m_f_history.Store();
         out.f_history_len = hist_len.data();
     }
-    const int device = rundata.GetIntDefault("device", 0, 0);
+    // devices=all | devices=0,1,...: voxelwise VB shards the voxel list over several GPUs of the node
+    // (fabber_vb_run_host_multi); everything else runs on the first of them (or on device=<index>)
+    vector<int32_t> device_list;
+    const string devices_opt = rundata.GetStringDefault("devices", "");
+    if (devices_opt != "" && devices_opt != "all")
+    {
+        string item;
+        for (size_t i = 0; i <= devices_opt.size(); i++)
+        {
+            if (i == devices_opt.size() || devices_opt[i] == ',')
+            {
+                if (item == "")
+                    throw InvalidOptionValue("devices", devices_opt, "Must be 'all' or a comma-separated list of device indices");
+                device_list.push_back(convertTo<int>(item));
+                item = "";
+            }
+            else
+                item += devices_opt[i];
+        }
+    }
+    const int device = device_list.empty() ? rundata.GetIntDefault("device", 0, 0) : device_list[0];
     const Matrix &coords = rundata.GetVoxelCoords();
     int rc;
     if (m_locked_linear)
@@ -582,7 +602,18 @@ void Vb::DoCalculations(FabberRunData &rundata)
     {
         LOG << "Vb::Voxelwise calculations on the MI355X engine, kernel " << fabber_vb_kernel_name(&cfg) << ", "
             << m_nvoxels << " voxels x " << cfg.n_times << " timepoints" << endl;
-        rc = fabber_vb_run_host(&cfg, data.Store(), &out, device);
+        if (devices_opt != "")
+        {
+            fvb_summary total;
+            rc = fabber_vb_run_host_multi(&cfg, data.Store(), &out, device_list.empty() ? NULL : device_list.data(),
+                (int32_t)device_list.size(), &total);
+            if (rc == 0)
+                LOG << "Vb::devices=" << devices_opt << ": " << total.sum_iterations << " voxel-iterations, " << total.bad_voxels
+                    << " voxels stopped on a numerical error" << (m_needF ? ", global free energy " : "")
+                    << (m_needF ? stringify(total.sum_free_energy) : string("")) << endl;
+        }
+        else
+            rc = fabber_vb_run_host(&cfg, data.Store(), &out, device);
     }
     if (rc != 0)
         throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());

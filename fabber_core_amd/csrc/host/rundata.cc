@@ -99,6 +99,7 @@ static OptionSpec RUN_OPTIONS[] = {
     { "optfile", OPT_BOOL, "File with additional options, one per line, as on the command line", OPT_NONREQ, "" },
     { "debug", OPT_BOOL, "Very verbose logging; only for tiny numbers of voxels", OPT_NONREQ, "" },
     { "device", OPT_INT, "MI355X: index of the GPU to run on", OPT_NONREQ, "0" },
+    { "devices", OPT_STR, "MI355X: 'all' or a comma-separated list of GPU indices; voxelwise VB shards the voxels over them", OPT_NONREQ, "" },
     { "" },
 };
 

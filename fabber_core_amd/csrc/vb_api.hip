@@ -11,8 +11,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace fvb;
@@ -22,6 +25,9 @@ namespace
 thread_local std::string g_last_error;
 int g_variant = 0; // 0 auto, 1 lane, 2 wave
 int g_residual_mode = 0; // 0 adaptive, 1 always exact, 2 moments only
+// linearisations of a run that evaluate the model pointwise (vb_lane_kernel.h); the environment variable is an experiment switch
+int g_precise_passes = getenv("FVB_PRECISE_PASSES") ? atoi(getenv("FVB_PRECISE_PASSES")) : 2;
+bool g_tiled = getenv("FVB_NO_TILES") == nullptr; // experiment switch: FVB_NO_TILES=1 keeps the in-place (strided) feed
 double g_residual_tol = 1e-10; // moments value keeps >= 6 significant digits where it is used
 
 int fail(int code, const std::string &msg)
@@ -303,8 +309,24 @@ const char *fabber_vb_kernel_name(const fvb_config *cfg)
     return "wave";
 }
 
+namespace
+{
+int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *out, hipStream_t stream, int n_unmasked,
+    int kernel_voxels);
+}
+
 int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream_,
     int32_t n_unmasked)
+{
+    return run_device_as(cfg, data, out, (hipStream_t)stream_, n_unmasked, cfg ? cfg->n_voxels : 0);
+}
+
+namespace
+{
+// kernel_voxels: the voxel count the kernel choice (lane / wave) is made for - the whole problem's when
+// cfg describes one block of it (fabber_vb_run_host_multi), so that every block runs the same code
+int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *out, hipStream_t stream, int n_unmasked,
+    int kernel_voxels)
 {
     int rc = validate(cfg);
     if (rc)
@@ -317,30 +339,59 @@ int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const f
         return fail(-21, "data is NULL");
     if (cfg->noise == FVB_NOISE_AR1 && n_unmasked != cfg->n_times)
         return fail(-15, "Masked time points are not supported for the AR noise model"); // noisemodel_ar.cc:351-355
-    hipStream_t stream = (hipStream_t)stream_;
     KernelArgs ka;
     ka.cfg = *cfg;
     ka.out = *out;
     ka.data = data;
+    ka.tiles = nullptr;
     ka.save = nullptr;
     ka.n_unmasked = n_unmasked;
     ka.residual_mode = g_residual_mode;
     ka.residual_tol = g_residual_tol;
+    ka.precise_passes = g_precise_passes;
 
-    LaneKernelInfo lk = select_lane(cfg);
+    fvb_config choice = *cfg;
+    choice.n_voxels = kernel_voxels;
+    LaneKernelInfo lk = select_lane(&choice);
     if (lk.fn)
     {
         if (needs_save(cfg))
             FVB_HIP_CHECK(hipMallocAsync((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels, stream));
         const unsigned grid = (unsigned)((cfg->n_voxels + 63) / 64);
-        hipLaunchKernelGGL(lk.fn, dim3(grid), dim3(64), 0, stream, ka);
+        LaneKernelFn fn = lk.fn;
+        void *tiles = nullptr;
+        // White noise, no masked timepoints: the series is re-laid per wavefront once (one read and one
+        // write of the image) and every pass of the voxel loop streams that block (vb_lane_kernel.h).
+        if (lk.fn_tiles_f32 && n_unmasked == cfg->n_times && g_residual_mode != 1 && g_tiled)
+        {
+            const int V = cfg->n_voxels, T = cfg->n_times;
+            const unsigned rgrid = (unsigned)((V + 255) / 256);
+            if (cfg->data_f64)
+            {
+                FVB_HIP_CHECK(hipMallocAsync(&tiles, Tile<double>::bytes(V, T), stream));
+                hipLaunchKernelGGL(retile_series<double>, dim3(rgrid), dim3(256), 0, stream, (const double *)data, (double *)tiles, V, T);
+                fn = lk.fn_tiles_f64;
+            }
+            else
+            {
+                FVB_HIP_CHECK(hipMallocAsync(&tiles, Tile<float>::bytes(V, T), stream));
+                hipLaunchKernelGGL(retile_series<float>, dim3(rgrid), dim3(256), 0, stream, (const float *)data, (float *)tiles, V, T);
+                fn = lk.fn_tiles_f32;
+            }
+            FVB_HIP_CHECK(hipGetLastError());
+            ka.tiles = tiles;
+        }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, stream, ka);
         FVB_HIP_CHECK(hipGetLastError());
+        if (tiles)
+            FVB_HIP_CHECK(hipFreeAsync(tiles, stream));
         if (ka.save)
             FVB_HIP_CHECK(hipFreeAsync(ka.save, stream));
         return 0;
     }
     return launch_wave_kernel(ka, stream, g_last_error);
 }
+} // namespace
 
 int32_t fabber_vb_run_device(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream)
 {
@@ -357,6 +408,110 @@ int32_t fabber_vb_run_device(const fvb_config *cfg, const void *data, const fvb_
     return fabber_vb_run_device_ex(cfg, data, out, stream, n_unmasked);
 }
 
+namespace
+{
+// Voxels [v0, v1) of a host-resident problem on one device: the block's columns of every [row][voxel]
+// image go up and down as 2-D copies (row pitch = the caller's n_voxels), the kernels see a problem of
+// v1 - v0 voxels. Runs on `stream`; returns after the block's results are in the caller's arrays.
+int run_host_block(const fvb_config *cfg, const void *data, const fvb_outputs *out, int device, int v0, int v1,
+    hipStream_t stream, int kernel_voxels)
+{
+    FVB_HIP_CHECK(hipSetDevice(device));
+    const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times, Vb = (size_t)(v1 - v0);
+    if (Vb == 0)
+        return 0;
+    const int P = cfg->n_params;
+    const int rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
+    const size_t esz = cfg->data_f64 ? 8 : 4;
+    auto upload = [&](void *dst, const void *src, size_t elem, size_t nrows) {
+        return hipMemcpy2DAsync(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows,
+            hipMemcpyHostToDevice, stream);
+    };
+    auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
+        return hipMemcpy2DAsync((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows,
+            hipMemcpyDeviceToHost, stream);
+    };
+    fvb_config d = *cfg;
+    d.n_voxels = (int32_t)Vb;
+    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS];
+    FVB_HIP_CHECK(b_data.alloc(T * Vb * esz));
+    FVB_HIP_CHECK(upload(b_data.p, data, esz, T));
+    if (cfg->design)
+    {
+        FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P));
+        FVB_HIP_CHECK(hipMemcpyAsync(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice, stream));
+        d.design = (const double *)b_design.p;
+    }
+    if (cfg->phi_index)
+    {
+        FVB_HIP_CHECK(b_phi.alloc(T));
+        FVB_HIP_CHECK(hipMemcpyAsync(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice, stream));
+        d.phi_index = (const uint8_t *)b_phi.p;
+    }
+    if (cfg->init_mvn)
+    {
+        FVB_HIP_CHECK(b_init.alloc(sizeof(double) * rows * Vb));
+        FVB_HIP_CHECK(upload(b_init.p, cfg->init_mvn, sizeof(double), rows));
+        d.init_mvn = (const double *)b_init.p;
+    }
+    for (int k = 0; k < P; k++)
+        if (cfg->image_prior[k])
+        {
+            FVB_HIP_CHECK(b_img[k].alloc(sizeof(double) * Vb));
+            FVB_HIP_CHECK(upload(b_img[k].p, cfg->image_prior[k], sizeof(double), 1));
+            d.image_prior[k] = (const double *)b_img[k].p;
+        }
+    fvb_outputs dout;
+    memset(&dout, 0, sizeof(dout));
+    DevBuf b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
+    FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * Vb));
+    dout.mvn = (double *)b_mvn.p;
+    if (out->free_energy)
+    {
+        FVB_HIP_CHECK(b_f.alloc(sizeof(double) * Vb));
+        dout.free_energy = (double *)b_f.p;
+    }
+    if (out->f_history && cfg->f_history_rows > 0)
+    {
+        FVB_HIP_CHECK(b_hist.alloc(sizeof(double) * cfg->f_history_rows * Vb));
+        FVB_HIP_CHECK(hipMemsetAsync(b_hist.p, 0xff, sizeof(double) * cfg->f_history_rows * Vb, stream)); // NaN fill
+        dout.f_history = (double *)b_hist.p;
+    }
+    if (out->f_history_len)
+    {
+        FVB_HIP_CHECK(b_hlen.alloc(sizeof(int32_t) * Vb));
+        dout.f_history_len = (int32_t *)b_hlen.p;
+    }
+    if (out->status)
+    {
+        FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * Vb));
+        dout.status = (int32_t *)b_status.p;
+    }
+    if (out->iterations)
+    {
+        FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * Vb));
+        dout.iterations = (int32_t *)b_it.p;
+    }
+    // (the uploads above read pageable host memory: the copies have completed on return)
+    int rc = run_device_as(&d, b_data.p, &dout, stream, count_unmasked(cfg, cfg->phi_index), kernel_voxels);
+    if (rc)
+        return rc;
+    FVB_HIP_CHECK(download(out->mvn, dout.mvn, sizeof(double), rows));
+    if (dout.free_energy)
+        FVB_HIP_CHECK(download(out->free_energy, dout.free_energy, sizeof(double), 1));
+    if (dout.f_history)
+        FVB_HIP_CHECK(download(out->f_history, dout.f_history, sizeof(double), cfg->f_history_rows));
+    if (dout.f_history_len)
+        FVB_HIP_CHECK(download(out->f_history_len, dout.f_history_len, sizeof(int32_t), 1));
+    if (dout.status)
+        FVB_HIP_CHECK(download(out->status, dout.status, sizeof(int32_t), 1));
+    if (dout.iterations)
+        FVB_HIP_CHECK(download(out->iterations, dout.iterations, sizeof(int32_t), 1));
+    FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    return 0;
+}
+} // namespace
+
 int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device)
 {
     int rc = validate(cfg);
@@ -366,89 +521,82 @@ int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_ou
         return fail(-20, "outputs.mvn is required");
     if (fabber_vb_device_count() <= 0)
         return fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
-    FVB_HIP_CHECK(hipSetDevice(device));
-    const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times;
-    if (V == 0)
-        return 0;
-    const int P = cfg->n_params;
-    const int rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
-    const size_t esz = cfg->data_f64 ? 8 : 4;
+    return run_host_block(cfg, data, out, device, 0, cfg->n_voxels, nullptr, cfg->n_voxels);
+}
 
-    fvb_config d = *cfg;
-    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS];
-    FVB_HIP_CHECK(b_data.alloc(T * V * esz));
-    FVB_HIP_CHECK(hipMemcpy(b_data.p, data, T * V * esz, hipMemcpyHostToDevice));
-    if (cfg->design)
-    {
-        FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P));
-        FVB_HIP_CHECK(hipMemcpy(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice));
-        d.design = (const double *)b_design.p;
-    }
-    if (cfg->phi_index)
-    {
-        FVB_HIP_CHECK(b_phi.alloc(T));
-        FVB_HIP_CHECK(hipMemcpy(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice));
-        d.phi_index = (const uint8_t *)b_phi.p;
-    }
-    if (cfg->init_mvn)
-    {
-        FVB_HIP_CHECK(b_init.alloc(sizeof(double) * rows * V));
-        FVB_HIP_CHECK(hipMemcpy(b_init.p, cfg->init_mvn, sizeof(double) * rows * V, hipMemcpyHostToDevice));
-        d.init_mvn = (const double *)b_init.p;
-    }
-    for (int k = 0; k < P; k++)
-        if (cfg->image_prior[k])
-        {
-            FVB_HIP_CHECK(b_img[k].alloc(sizeof(double) * V));
-            FVB_HIP_CHECK(hipMemcpy(b_img[k].p, cfg->image_prior[k], sizeof(double) * V, hipMemcpyHostToDevice));
-            d.image_prior[k] = (const double *)b_img[k].p;
-        }
-    fvb_outputs dout;
-    memset(&dout, 0, sizeof(dout));
-    DevBuf b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
-    FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * V));
-    dout.mvn = (double *)b_mvn.p;
-    if (out->free_energy)
-    {
-        FVB_HIP_CHECK(b_f.alloc(sizeof(double) * V));
-        dout.free_energy = (double *)b_f.p;
-    }
-    if (out->f_history && cfg->f_history_rows > 0)
-    {
-        FVB_HIP_CHECK(b_hist.alloc(sizeof(double) * cfg->f_history_rows * V));
-        FVB_HIP_CHECK(hipMemset(b_hist.p, 0xff, sizeof(double) * cfg->f_history_rows * V)); // NaN fill
-        dout.f_history = (double *)b_hist.p;
-    }
-    if (out->f_history_len)
-    {
-        FVB_HIP_CHECK(b_hlen.alloc(sizeof(int32_t) * V));
-        dout.f_history_len = (int32_t *)b_hlen.p;
-    }
-    if (out->status)
-    {
-        FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * V));
-        dout.status = (int32_t *)b_status.p;
-    }
-    if (out->iterations)
-    {
-        FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * V));
-        dout.iterations = (int32_t *)b_it.p;
-    }
-    rc = fabber_vb_run_device_ex(&d, b_data.p, &dout, nullptr, count_unmasked(cfg, cfg->phi_index));
+int32_t fabber_vb_run_host_multi(const fvb_config *cfg, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, fvb_summary *summary)
+{
+    int rc = validate(cfg);
     if (rc)
         return rc;
-    FVB_HIP_CHECK(hipDeviceSynchronize());
-    FVB_HIP_CHECK(hipMemcpy(out->mvn, dout.mvn, sizeof(double) * rows * V, hipMemcpyDeviceToHost));
-    if (dout.free_energy)
-        FVB_HIP_CHECK(hipMemcpy(out->free_energy, dout.free_energy, sizeof(double) * V, hipMemcpyDeviceToHost));
-    if (dout.f_history)
-        FVB_HIP_CHECK(hipMemcpy(out->f_history, dout.f_history, sizeof(double) * cfg->f_history_rows * V, hipMemcpyDeviceToHost));
-    if (dout.f_history_len)
-        FVB_HIP_CHECK(hipMemcpy(out->f_history_len, dout.f_history_len, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
-    if (dout.status)
-        FVB_HIP_CHECK(hipMemcpy(out->status, dout.status, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
-    if (dout.iterations)
-        FVB_HIP_CHECK(hipMemcpy(out->iterations, dout.iterations, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    if (!out || !out->mvn)
+        return fail(-20, "outputs.mvn is required");
+    const int visible = fabber_vb_device_count();
+    if (visible <= 0)
+        return fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
+    std::vector<int> devs;
+    if (devices)
+    {
+        if (n_devices <= 0)
+            return fail(-31, "empty device list");
+        for (int i = 0; i < n_devices; i++)
+        {
+            if (devices[i] < 0 || devices[i] >= visible)
+                return fail(-31, "device index " + std::to_string(devices[i]) + " out of range (" + std::to_string(visible) + " visible)");
+            devs.push_back(devices[i]);
+        }
+    }
+    else
+        for (int i = 0; i < visible; i++)
+            devs.push_back(i);
+    const int n = (int)devs.size();
+    const long long V = cfg->n_voxels;
+    // contiguous blocks, cut on multiples of 64 voxels (a wavefront of the lane kernels) so that a
+    // voxel shares its wavefront with the same neighbours as in a one-device run
+    std::vector<int> cut(n + 1, 0);
+    for (int i = 1; i < n; i++)
+        cut[i] = (int)std::min<long long>(V, ((V * i / n + 63) / 64) * 64);
+    cut[n] = (int)V;
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < n; i++)
+        pool.emplace_back([&, i] {
+            hipStream_t st = nullptr;
+            if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+            {
+                rcs[i] = -32;
+                errs[i] = "cannot create a stream on device " + std::to_string(devs[i]);
+                return;
+            }
+            // every block runs the kernel the whole problem would (kernel choice depends on the voxel count)
+            rcs[i] = run_host_block(cfg, data, out, devs[i], cut[i], cut[i + 1], st, cfg->n_voxels);
+            if (rcs[i])
+                errs[i] = g_last_error; // thread-local: carry it to the caller's thread
+            (void)hipStreamDestroy(st);
+        });
+    for (auto &t : pool)
+        t.join();
+    for (int i = 0; i < n; i++)
+        if (rcs[i])
+            return fail(rcs[i], "block " + std::to_string(i) + " (device " + std::to_string(devs[i]) + "): " + errs[i]);
+    if (summary)
+    {
+        summary->sum_free_energy = 0;
+        summary->sum_iterations = 0;
+        summary->bad_voxels = 0;
+        for (long long v = 0; v < V; v++)
+        {
+            const bool ok = !out->status || (out->status[v] & 0xff) == 0;
+            if (out->status && !ok)
+                summary->bad_voxels++;
+            if (out->free_energy && ok)
+                summary->sum_free_energy += out->free_energy[v];
+            if (out->iterations)
+                summary->sum_iterations += out->iterations[v];
+        }
+    }
     return 0;
 }
 

@@ -10,9 +10,12 @@ typedef void (*LaneKernelFn)(const KernelArgs);
 
 struct LaneKernelInfo
 {
-    LaneKernelFn fn;
+    LaneKernelFn fn; // reads the caller's [t][voxel] image in place (FEED_STRIDED: any element type, masked timepoints)
     int save_rows;
     const char *name;
+    // white noise only: the same loop fed from the tiled series (vb_lane_kernel.h), float / double
+    // elements - what runs unless timepoints are masked
+    LaneKernelFn fn_tiles_f32, fn_tiles_f64;
 };
 
 // Each returns {NULL,0,NULL} when (P, need_f) has no instantiation; the caller then falls back to
@@ -29,9 +32,12 @@ LaneKernelInfo get_lane_ar_kernel_exp(int P, bool need_f);
 #define FVB_LANE_CASE(MODEL, TAG, PP)                                                                        \
     case PP:                                                                                                 \
         if (need_f)                                                                                          \
-            return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, true>, lane_save_rows<PP>(),                \
-                "lane<" TAG "," #PP ",F>" };                                                                 \
-        return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, false>, lane_save_rows<PP>(), "lane<" TAG "," #PP ">" };
+            return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, true, FEED_STRIDED>, lane_save_rows<PP>(),  \
+                "lane<" TAG "," #PP ",F>", vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F32>,              \
+                vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F64> };                                       \
+        return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, false, FEED_STRIDED>, lane_save_rows<PP>(),     \
+            "lane<" TAG "," #PP ">", vb_lane_kernel<MODEL<PP>, PP, false, FEED_TILES_F32>,                   \
+            vb_lane_kernel<MODEL<PP>, PP, false, FEED_TILES_F64> };
 
 #define FVB_LANE_AR_CASE(MODEL, TAG, PP)                                                                     \
     case PP:                                                                                                 \

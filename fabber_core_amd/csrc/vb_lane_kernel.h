@@ -60,9 +60,11 @@ struct KernelArgs
     fvb_config cfg; // pointer members are device pointers
     fvb_outputs out;
     const void *data;
+    const void *tiles; // the series re-laid per wavefront (retile_series below), or NULL: FEED_STRIDED kernels
     double *save;      // [lane_save_rows(P)][V] scratch for save/revert, or NULL
     int32_t n_unmasked; // T - #masked timepoints
     int32_t residual_mode; // k'Qk: 0 = moments with exact fallback, 1 = always exact, 2 = moments only
+    int32_t precise_passes; // the first so many linearisations of a run evaluate the model pointwise (FVB_PRECISE_PASSES)
     double residual_tol;   // mode 0: fall back when k'Qk < residual_tol * (s + 2|d'u| + |d'Ad|)
 };
 
@@ -199,7 +201,9 @@ __device__ __forceinline__ bool ensure_prec(VoxelState<P> &st)
 // f(c - d e_i)(t)) / (c2_i - c3_i) exactly as the reference, except that the division is a
 // multiplication by the once-computed reciprocal (<= 1 ulp per Jacobian entry).
 // precise: ask the model's sweep for its most precise evaluation (vb_models.h). The kernels do
-// so for the FIRST linearisation of a run: parameters that start at a Fabber-space mean of
+// so for the first FVB_PRECISE_PASSES = 2 linearisations of a run (measured against the binary128
+// ground truth, profiles/r2_c3_truth_*.json: with only the first one pointwise the error of the
+// bi-exponential fit after 2-5 iterations is 1.5 x that of a CPU build, with two it is the CPU's): parameters that start at a Fabber-space mean of
 // exactly 0 (log of a rate of 1) get the reference's minimum step of 1e-10 there, f2 - f3 is then
 // ~1e-10 of f, and every rounding in f shows up a million-fold in J.
 template <class Model, int P>
@@ -284,6 +288,203 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
             bad_jac |= !is_finite(mo.A[tri(i, i)]);
     }
     return bad_offset ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tiled series. The caller's image is [t][voxel]: consecutive timepoints of a voxel lie V elements
+// apart (4 MB at a million voxels - a new page and a new DRAM row for every sample). The throughput
+// kernels read each series ~51 times, so it is re-laid ONCE per run (retile_series, one read and one
+// write of the image: ~0.2 ms per GB) as
+//        tiles [wavefront = v / 64][group = t / G][lane = v % 64][G],   G = 16 / sizeof(element)
+// i.e. a wavefront's whole series is ONE contiguous block of 64 * T elements, a lane fetches G
+// consecutive timepoints with one 16-byte load and a wavefront instruction moves 1 KB.
+// ---------------------------------------------------------------------------------------------------
+enum
+{
+    FEED_TILES_F32 = 0, // float series, no masked timepoints: the ABI route and the fast one
+    FEED_TILES_F64 = 1, // double series (the in-memory NEWMAT::Matrix route), no masked timepoints
+    FEED_STRIDED = 2    // general: either element type read in place, masked timepoints, residual mode 1
+};
+
+template <int FEED>
+struct FeedTraits
+{
+    typedef float raw;
+};
+template <>
+struct FeedTraits<FEED_TILES_F64>
+{
+    typedef double raw;
+};
+
+template <typename RAW>
+struct Tile
+{
+    static constexpr int G = 16 / (int)sizeof(RAW); // timepoints per 16-byte group
+    typedef RAW vec __attribute__((ext_vector_type(16 / sizeof(RAW))));
+    static FVB_HD size_t groups(int T)
+    {
+        return (size_t)((T + G - 1) / G);
+    }
+    // elements of one wavefront's block / of the whole workspace
+    static FVB_HD size_t block_elems(int T)
+    {
+        return groups(T) * 64 * G;
+    }
+    static FVB_HD size_t bytes(int V, int T)
+    {
+        return (size_t)((V + 63) / 64) * block_elems(T) * sizeof(RAW);
+    }
+};
+
+template <typename RAW>
+__global__ __launch_bounds__(256) void retile_series(const RAW *__restrict__ data, RAW *__restrict__ tiles, int V, int T)
+{
+    typedef Tile<RAW> TL;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V)
+        return;
+    const int n_groups = (int)TL::groups(T);
+    typename TL::vec *dst = (typename TL::vec *)(tiles + (size_t)(v >> 6) * TL::block_elems(T)) + (v & 63);
+    const RAW *src = data + v;
+    for (int g = 0; g < n_groups; g++)
+    {
+        typename TL::vec q;
+#pragma unroll
+        for (int j = 0; j < TL::G; j++)
+        {
+            const int t = g * TL::G + j;
+            q[j] = (t < T) ? src[(size_t)t * V] : RAW(0);
+        }
+        dst[(size_t)g * 64] = q;
+    }
+}
+
+// recentre() for a tiled series without masked timepoints: the streaming pass of the throughput kernels.
+// Same arithmetic in the same order as recentre() above (the moments of voxel v are bit-identical); what
+// differs is how the samples arrive and that the code exists once:
+//  * the main loop handles FVB_TRIP = 8 timepoints per trip with the position inside the trip known at
+//    compile time, so "exact exponentials at t = 0 mod FVB_EXP_RESYNC, one multiplication otherwise"
+//    is straight-line code; the trip's samples were requested one trip earlier (two register sets, used
+//    alternately; the loads are unconditional - the last one re-reads the final trip - so that the
+//    compiler's wait before a set's first use leaves the other set's loads in flight);
+//  * the first linearisation of a run (precise, see recentre) and the last T mod 8 timepoints go through
+//    one compact loop that decides per timepoint.
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ int recentre_tiles(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile,
+    const double (&centre)[P], Moments<P> &mo, bool precise, double *sweep_park = nullptr)
+{
+    typedef Tile<RAW> TL;
+    constexpr int PT = P * (P + 1) / 2;
+    constexpr int TRIP = 8;
+    constexpr int NL = TRIP / TL::G; // 16-byte loads per trip
+    static_assert(FVB_EXP_RESYNC == 1 || FVB_EXP_RESYNC == 2 || FVB_EXP_RESYNC == 4 || FVB_EXP_RESYNC == 8,
+        "the resync period must divide the trip length");
+    const int T = ka.cfg.n_times;
+    double tp[P], tp2[P], tp3[P], rden[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        const int tr = ka.cfg.transform[i];
+        double delta = centre[i] * 1e-5; // fwdmodel_linear.cc:157-161
+        if (delta < 0)
+            delta = -delta;
+        if (delta < 1e-10)
+            delta = 1e-10;
+        const double c2 = centre[i] + delta;
+        const double c3 = centre[i] - delta;
+        tp[i] = to_model(tr, centre[i]); // fwdmodel.cc:375-379
+        tp2[i] = to_model(tr, c2);
+        tp3[i] = to_model(tr, c3);
+        rden[i] = 1.0 / (c2 - c3);
+        mo.ml[i] = centre[i];
+    }
+    if (sweep_park) // rows [tp | tp2 | tp3 | rden] x P, entry of lane l at [row * 64 + l]: see rescue_tiles
+    {
+        double *q = sweep_park + (threadIdx.x & 63);
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            q[(0 * P + i) * 64] = tp[i];
+            q[(1 * P + i) * 64] = tp2[i];
+            q[(2 * P + i) * 64] = tp3[i];
+            q[(3 * P + i) * 64] = rden[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        mo.A[i] = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        mo.u[i] = 0;
+    mo.s = 0;
+    mo.precise = precise;
+    typename Model::Sweep sweep;
+    sweep.init(ma, tp, tp2, tp3);
+    sweep.set_precise(false);
+    double g_total = 0; // the non-finite tests of g and J are read off the sums, as in recentre()
+    auto accumulate = [&](double y_cur, double g, const double(&J)[P]) {
+        g_total += g;
+        const double r = y_cur - g;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+#pragma unroll
+            for (int j = 0; j <= i; j++)
+                mo.A[tri(i, j)] += J[i] * J[j];
+            mo.u[i] += J[i] * r;
+        }
+        mo.s += r * r;
+    };
+    int t = 0;
+    const int n_trips = precise ? 0 : T / TRIP;
+    if (n_trips > 0)
+    {
+        const typename TL::vec *p = (const typename TL::vec *)lane_tile; // group g of this lane: p[g * 64]
+        typename TL::vec qa[NL], qb[NL];
+        auto fetch = [&](typename TL::vec(&q)[NL], int trip) {
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+                q[l] = p[(size_t)(trip * NL + l) * 64];
+        };
+        auto process = [&](const typename TL::vec(&q)[NL], int t0) {
+#pragma unroll
+            for (int j = 0; j < TRIP; j++)
+            {
+                double g, J[P];
+                if (j % FVB_EXP_RESYNC == 0)
+                    sweep.template step_fast<true>(ma, t0 + j, tp, tp2, tp3, rden, g, J);
+                else
+                    sweep.template step_fast<false>(ma, t0 + j, tp, tp2, tp3, rden, g, J);
+                accumulate((double)q[j / TL::G][j % TL::G], g, J);
+            }
+        };
+        fetch(qa, 0);
+        int k = 0;
+        for (; k + 2 <= n_trips; k += 2)
+        {
+            fetch(qb, k + 1);
+            process(qa, k * TRIP);
+            fetch(qa, (k + 2 < n_trips) ? k + 2 : n_trips - 1);
+            process(qb, (k + 1) * TRIP);
+        }
+        if (k < n_trips)
+            process(qa, k * TRIP);
+        t = n_trips * TRIP;
+    }
+#pragma nounroll
+    for (; t < T; t++)
+    {
+        const double y_cur = (double)lane_tile[(size_t)(t / TL::G) * 64 * TL::G + (t % TL::G)];
+        double g, J[P];
+        sweep.step_any(ma, t, tp, tp2, tp3, rden, g, J, precise);
+        accumulate(y_cur, g, J);
+    }
+    bool bad_jac = false;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        bad_jac |= !is_finite(mo.A[tri(i, i)]);
+    return !is_finite(g_total) ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
 }
 
 // Prior::ApplyToMVN for every parameter (inference_vb.cc:460-463; priors.cc:108-181). Returns
@@ -717,6 +918,102 @@ __device__ __forceinline__ void residual_and_trace(const KernelArgs &ka, const M
     }
 }
 
+// LDS rows for the perturbed parameter vectors of the current linearisation (tp, tp2, tp3 and the
+// reciprocal steps): 4 P rows next to the parked state and the rescue row, if a wave's share allows.
+template <int P, bool NEEDF>
+struct SweepPark
+{
+    static constexpr int ROWS = 4 * P;
+    static constexpr bool FITS = ParkPlan<P, NEEDF>::ROWS + 1 + ROWS <= ParkPlan<P, NEEDF>::BUDGET;
+};
+
+// rescue_residual for the tile-fed kernels, whose wavefronts are always complete (the kernel's lanes past
+// the voxel list repeat the last voxel). For one voxel at a time - lane src - lane l evaluates the model
+// pointwise at the timepoints l, l + 64, ... of THAT voxel's series (which sits in the wavefront's own tile),
+// adds its k_t^2 and a butterfly over the 64 lanes adds the partial sums in a fixed order: what a voxel gets
+// depends on nothing but that voxel. The model-space parameter vectors of the linearisation are read from
+// the LDS rows recentre_tiles left (a broadcast read each) instead of being transformed again by every lane.
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ double rescue_tiles(const KernelArgs &ka, const ModelArgs &ma, const RAW *wave_tile,
+    const double *sweep_park, const Moments<P> &mo, const double (&m)[P], int v, bool want)
+{
+    constexpr int G = Tile<RAW>::G;
+    const int T = ka.cfg.n_times;
+    const int lane = threadIdx.x & 63;
+    double result = 0;
+    // (a lane past the end of the voxel list repeats the last voxel, whose series is in THAT voxel's slot of
+    // the tile: it takes that lane's result below instead of asking for one of its own)
+    unsigned long long todo = __ballot(want && (v & 63) == lane);
+    while (todo) // wave-uniform
+    {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        double tp[P], tp2[P], tp3[P], rden[P], nd[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            tp[i] = sweep_park[(0 * P + i) * 64 + src];
+            tp2[i] = sweep_park[(1 * P + i) * 64 + src];
+            tp3[i] = sweep_park[(2 * P + i) * 64 + src];
+            rden[i] = sweep_park[(3 * P + i) * 64 + src];
+            nd[i] = __shfl(mo.ml[i], src) - __shfl(m[i], src);
+        }
+        PointwiseSweep<Model, P> sweep;
+        double part = 0;
+        for (int t = lane; t < T; t += 64)
+        {
+            const double y = (double)wave_tile[(size_t)(t / G) * 64 * G + (size_t)src * G + (t % G)];
+            double g, f2[P], f3[P];
+            sweep.eval(ma, t, tp, tp2, tp3, g, f2, f3);
+            double Jd = 0;
+#pragma unroll
+            for (int i = 0; i < P; i++)
+            {
+                FVB_NO_CONTRACT
+                Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
+            }
+            const double k = y - g + Jd;
+            part += k * k;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            part += __shfl_xor(part, off);
+        if (lane == src)
+            result = part;
+    }
+    return __shfl(result, v & 63);
+}
+
+// The same for the tile-fed kernels: modes 0 (adaptive, the default) and 2 only - "always exact" is an
+// experiment switch and runs on the FEED_STRIDED kernel.
+template <class Model, int P, bool NEEDF, typename RAW, bool SWEEP_PARKED>
+__device__ __forceinline__ void residual_and_trace_adaptive(const KernelArgs &ka, const ModelArgs &ma, int v,
+    VoxelState<P> &st, const Moments<P> &mo, double &kk, double &trSA, double *park, double *row,
+    const RAW *wave_tile, const double *sweep_park)
+{
+    bool lost;
+    residual_terms<P>(st, mo, ka.residual_tol, kk, trSA, lost);
+    if (ka.residual_mode == 2)
+    {
+        kk = (kk > 0.0) ? kk : ((kk <= 0.0) ? 0.0 : kk); // keep b positive; NaN passes through
+        return;
+    }
+#ifndef FVB_NO_RESCUE // (experiment switch: resource usage of the kernel without the rescue path)
+    if (__builtin_expect(__any(lost), 0)) // wave-uniform
+    {
+        park_state<P, NEEDF>(park, st);
+        double exact;
+        if (SWEEP_PARKED)
+            exact = rescue_tiles<Model, P, RAW>(ka, ma, wave_tile, sweep_park, mo, st.m, v, lost);
+        else
+            exact = rescue_residual<Model, P>(ka, ma, v, mo, st.m, lost, row);
+        unpark_state<P, NEEDF>(park, st);
+        if (lost)
+            kk = exact;
+    }
+#endif
+}
+
 // WhiteNoiseModel::UpdateNoise (noisemodel_white.cc:228-273), one phi
 template <int P>
 __device__ __forceinline__ void update_noise(const KernelArgs &ka, VoxelState<P> &st, double kk, double trSA)
@@ -829,27 +1126,46 @@ __device__ __forceinline__ void restore_state(const KernelArgs &ka, int v, Voxel
     }
 }
 
-template <class Model, int P, bool NEEDF>
+// The voxel loop. FEED says how the series reaches the streaming pass (see the enum above): the two
+// tile feeds share one compact pass (recentre_tiles), FEED_STRIDED is the general one (recentre).
+// The loop of Vb::DoCalculationsVoxelwise is rotated so that the re-linearisation - the only part that
+// streams over the series, i.e. nearly all of the kernel's code and time - exists ONCE: the reference's
+//     ReCentre; do { priors, F, theta, F, noise, F, ReCentre, F, ++it } while (!Test(F)); [revert: ReCentre, F]
+// runs as
+//     for (;;) { ReCentre; first time: skip | after a revert: F, done | else: F, ++it, Test(F) -> done or
+//                revert; priors, F, theta, F, noise, F }
+// which executes the same steps in the same order.
+template <class Model, int P, bool NEEDF, int FEED>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
-    const int v = blockIdx.x * 64 + threadIdx.x;
+    typedef typename FeedTraits<FEED>::raw RAW;
+    // The lanes past the end of the voxel list (last wavefront only) do not leave: they repeat the last
+    // voxel - same loads, same arithmetic, same stores of the same values - so that every wavefront is
+    // complete wherever its lanes work together (the rescue of k'k below).
+    const int v_lane = blockIdx.x * 64 + threadIdx.x;
+    const int v = (v_lane < ka.cfg.n_voxels) ? v_lane : ka.cfg.n_voxels - 1;
     const int T = ka.cfg.n_times;
     const size_t V = (size_t)ka.cfg.n_voxels;
-    if (v >= ka.cfg.n_voxels)
-        return;
 
     ModelArgs ma;
     ma.iopt0 = ka.cfg.model_iopt[0];
     ma.dopt0 = ka.cfg.model_dopt[0];
     ma.design = ka.cfg.design;
+    // this wavefront's block of the tiled series, and this lane's slot in group 0 of it
+    const RAW *wave_tile = (FEED == FEED_STRIDED) ? nullptr : (const RAW *)ka.tiles + (size_t)blockIdx.x * Tile<RAW>::block_elems(T);
+    const RAW *lane_tile = (FEED == FEED_STRIDED) ? nullptr : wave_tile + (size_t)(v & 63) * Tile<RAW>::G;
 
     VoxelState<P> st;
     Moments<P> mo;
     int status = FVB_OK;
     __shared__ double park_lds[ParkPlan<P, NEEDF>::ROWS * 64];
     __shared__ double rescue_row[64];
+    // the perturbed parameter vectors of the current linearisation, for the rescue (tile feeds)
+    constexpr bool SWEEP_PARKED = (FEED != FEED_STRIDED) && SweepPark<P, NEEDF>::FITS;
+    __shared__ double sweep_lds[SWEEP_PARKED ? SweepPark<P, NEEDF>::ROWS * 64 : 1];
     double *park = park_lds + threadIdx.x;
+    double *sweep_park = SWEEP_PARKED ? sweep_lds : nullptr;
 
     // ---- Vb::SetupPerVoxelDists, per-voxel part (inference_vb.cc:207-247) ----
     if (ka.cfg.init_mvn)
@@ -884,11 +1200,26 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
         }
         if (Model::needs_data_max)
         {
-            double data_max = load_data(ka, v);
-            for (int t = 1; t < T; t++)
+            double data_max;
+            if (FEED == FEED_STRIDED)
             {
-                const double y = load_data(ka, (size_t)t * V + v);
-                data_max = (y > data_max) ? y : data_max;
+                data_max = load_data(ka, v);
+                for (int t = 1; t < T; t++)
+                {
+                    const double y = load_data(ka, (size_t)t * V + v);
+                    data_max = (y > data_max) ? y : data_max;
+                }
+            }
+            else
+            {
+                constexpr int G = Tile<RAW>::G;
+                data_max = (double)lane_tile[0];
+#pragma nounroll
+                for (int t = 1; t < T; t++)
+                {
+                    const double y = (double)lane_tile[(size_t)(t / G) * 64 * G + (t % G)];
+                    data_max = (y > data_max) ? y : data_max;
+                }
             }
             Model::init_posterior(ma, data_max, st.m);
         }
@@ -918,24 +1249,21 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
     int hist_len = 0;
     bool setup_failed = false;
 
-    // inference_vb.cc:235 and :443 re-centre about the same means: one pass gives both
-    park_state<P, NEEDF>(park, st);
-    status = recentre<Model, P>(ka, ma, v, st.m, mo, true);
-    unpark_state<P, NEEDF>(park, st);
-    if (status != FVB_OK)
-        setup_failed = true;
-
-    if (status == FVB_OK)
+    ConvState conv;
+    conv_init(conv, ka.cfg.convergence, ka.cfg.max_iterations, ka.cfg.max_trials, ka.cfg.min_fchange);
+    conv_reset(conv);
+    // Only the detectors that watch F save and revert, and they need F: the kernels built
+    // without it carry no save / revert code at all.
+    const bool use_save = NEEDF && (ka.save != nullptr);
+    enum
     {
-        ConvState conv;
-        conv_init(conv, ka.cfg.convergence, ka.cfg.max_iterations, ka.cfg.max_trials, ka.cfg.min_fchange);
-        conv_reset(conv);
-        // Only the detectors that watch F save and revert, and they need F: the kernels built
-        // without it carry no save / revert code at all.
-        const bool use_save = NEEDF && (ka.save != nullptr);
-        if (use_save)
-            save_state<P>(ka, v, st); // :432-434
-        bool stop = false;
+        FIRST,     // inference_vb.cc:235 and :443 re-centre about the same means: one pass gives both
+        ITERATING, // :490
+        REVERTED   // :521
+    };
+    int phase = FIRST;
+    int n_lin = 0; // linearisations done so far
+
 // CalculateF (inference_vb.cc:302-318) with the given residual terms; a failure ends the voxel's
 // loop exactly where the reference's exception would (F keeps its previous value).
 #define FVB_EVAL_F(KK, TR)                                                                                   \
@@ -954,16 +1282,28 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
         }                                                                                                    \
         F = Fn_;                                                                                             \
     }
-        do
+    for (;;)
+    {
+        park_state<P, NEEDF>(park, st);
+        if (FEED == FEED_STRIDED)
+            status = recentre<Model, P>(ka, ma, v, st.m, mo, n_lin < ka.precise_passes);
+        else
+            status = recentre_tiles<Model, P, RAW>(ka, ma, lane_tile, st.m, mo, n_lin < ka.precise_passes, sweep_park);
+        n_lin = (phase == REVERTED) ? n_lin : n_lin + 1;
+        unpark_state<P, NEEDF>(park, st);
+        if (status != FVB_OK)
         {
-            if (use_save && conv_need_save(conv)) // :451-458
-                save_state<P>(ka, v, st);
-            if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
-            {
-                status = FVB_BAD_RESULT;
-                break;
-            }
-            if (NEEDF) // "before" :468 - the centre is the current mean, so k = y - g
+            setup_failed = (phase == FIRST);
+            break;
+        }
+        if (phase == FIRST)
+        {
+            if (use_save)
+                save_state<P>(ka, v, st); // :432-434
+        }
+        else
+        {
+            if (NEEDF) // "lin" :495, or F of the restored state :524
             {
                 if (!ensure_cov<P>(st))
                 {
@@ -972,58 +1312,59 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
                 }
                 FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
             }
-            if (!update_theta<P>(st, mo, conv_lm_alpha(conv)) || !ensure_cov<P>(st)) // :470
-            {
-                status = FVB_BAD_RESULT;
+            if (phase == REVERTED)
                 break;
-            }
-            double kk, trSA;
-            residual_and_trace<Model, P, NEEDF>(ka, ma, v, st, mo, kk, trSA, park, rescue_row);
-            if (NEEDF) // "theta" :477
-                FVB_EVAL_F(kk, trSA)
-            update_noise<P>(ka, st, kk, trSA); // :479
-            if (NEEDF) // "phi" :485
-                FVB_EVAL_F(kk, trSA)
-            park_state<P, NEEDF>(park, st);
-            status = recentre<Model, P>(ka, ma, v, st.m, mo); // :490
-            unpark_state<P, NEEDF>(park, st);
-            if (status != FVB_OK)
-                break;
-            if (NEEDF) // "lin" :495
-                FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
             if (ka.out.f_history && hist_len < ka.cfg.f_history_rows) // :496-497
                 ka.out.f_history[(size_t)hist_len * V + v] = F;
             hist_len++;
             ++it;
-            stop = conv_test(conv, F);
-        } while (!stop);
-
-        if (status == FVB_OK)
-        {
-            if (use_save && conv_need_save(conv)) // :506-513
-                save_state<P>(ka, v, st);
-            if (use_save && conv_need_revert(conv)) // :516-525
+            if (conv_test(conv, F)) // :500
             {
-                restore_state<P>(ka, v, st);
-                park_state<P, NEEDF>(park, st);
-                status = recentre<Model, P>(ka, ma, v, st.m, mo);
-                unpark_state<P, NEEDF>(park, st);
-                if (status == FVB_OK && NEEDF)
+                if (use_save && conv_need_save(conv)) // :506-513
+                    save_state<P>(ka, v, st);
+                if (use_save && conv_need_revert(conv)) // :516-525
                 {
-                    do
-                    {
-                        if (!ensure_cov<P>(st))
-                        {
-                            status = FVB_BAD_RESULT;
-                            break;
-                        }
-                        FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
-                    } while (false);
+                    restore_state<P>(ka, v, st);
+                    phase = REVERTED;
+                    continue;
                 }
+                break;
             }
         }
-#undef FVB_EVAL_F
+        phase = ITERATING;
+        if (use_save && conv_need_save(conv)) // :451-458
+            save_state<P>(ka, v, st);
+        if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
+        {
+            status = FVB_BAD_RESULT;
+            break;
+        }
+        if (NEEDF) // "before" :468 - the centre is the current mean, so k = y - g
+        {
+            if (!ensure_cov<P>(st))
+            {
+                status = FVB_BAD_RESULT;
+                break;
+            }
+            FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
+        }
+        if (!update_theta<P>(st, mo, conv_lm_alpha(conv)) || !ensure_cov<P>(st)) // :470
+        {
+            status = FVB_BAD_RESULT;
+            break;
+        }
+        double kk, trSA;
+        if (FEED == FEED_STRIDED)
+            residual_and_trace<Model, P, NEEDF>(ka, ma, v, st, mo, kk, trSA, park, rescue_row);
+        else
+            residual_and_trace_adaptive<Model, P, NEEDF, RAW, SWEEP_PARKED>(ka, ma, v, st, mo, kk, trSA, park, rescue_row, wave_tile, sweep_park);
+        if (NEEDF) // "theta" :477
+            FVB_EVAL_F(kk, trSA)
+        update_noise<P>(ka, st, kk, trSA); // :479
+        if (NEEDF) // "phi" :485
+            FVB_EVAL_F(kk, trSA)
     }
+#undef FVB_EVAL_F
 
     // ---- result MVN: MVNDist(fwd_post, noise.OutputAsMVN()) packed as MVNDist::Save does
     // (inference_vb.cc:549-550; dist_mvn.cc:57-100,410-429; noisemodel_white.cc:55-68) ----

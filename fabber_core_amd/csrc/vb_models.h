@@ -80,6 +80,21 @@ struct PointwiseSweep
         for (int i = 0; i < P; i++)
             J[i] = (f2[i] - f3[i]) * rden[i];
     }
+    // The two entry points of the lane kernels' streaming pass (vb_lane_kernel.h, recentre_tiles):
+    // step_fast<EXACT> inside the unrolled main loop, where the position of a timepoint within its
+    // block of FVB_EXP_RESYNC is a compile-time constant (EXACT: first of the block) and the sweep is
+    // known not to be in its precise mode; step_any wherever that is only known at run time.
+    template <bool EXACT>
+    FVB_HD void step_fast(const ModelArgs &ma, int t, const double (&tp)[P], const double (&tp2)[P],
+        const double (&tp3)[P], const double (&rden)[P], double &g, double (&J)[P])
+    {
+        eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
+    }
+    FVB_HD void step_any(const ModelArgs &ma, int t, const double (&tp)[P], const double (&tp2)[P],
+        const double (&tp3)[P], const double (&rden)[P], double &g, double (&J)[P], bool)
+    {
+        eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
+    }
 };
 
 // Sweep for a model that is linear in each of its parameters, f = sum_n basis_n(t) p_n (the
@@ -143,6 +158,22 @@ struct LinearInParameterSweep
 #pragma unroll
         for (int i = 0; i < P; i++)
             J[i] = Model::basis(ma, t, i) * ((tp2[i] - tp3[i]) * rden[i]); // (the factor does not depend on t)
+    }
+    template <bool EXACT>
+    FVB_HD void step_fast(const ModelArgs &ma, int t, const double (&tp)[P], const double (&tp2)[P],
+        const double (&tp3)[P], const double (&rden)[P], double &g, double (&J)[P])
+    {
+        FVB_NO_CONTRACT
+        g = Model::eval(ma, t, tp);
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            J[i] = Model::basis(ma, t, i) * ((tp2[i] - tp3[i]) * rden[i]);
+    }
+    FVB_HD void step_any(const ModelArgs &ma, int t, const double (&tp)[P], const double (&tp2)[P],
+        const double (&tp3)[P], const double (&rden)[P], double &g, double (&J)[P], bool prec)
+    {
+        precise = prec;
+        eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
     }
 };
 
@@ -299,6 +330,37 @@ struct ExpModel
         {
             FVB_NO_CONTRACT
             advance(a, t, tp, tp2, tp3);
+            combine(tp, tp2, tp3, g, f2, f3);
+        }
+        // exp(-rate t dt) evaluated as eval() does, for the three rates of every exponential
+        FVB_HD void resync(const ModelArgs &a, int t, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P])
+        {
+            FVB_NO_CONTRACT
+            const double tt = double(t) * a.dopt0;
+#pragma unroll
+            for (int i = 0; i < N; i++)
+            {
+                e0[i] = exp(-tp[2 * i + 1] * tt);
+                e2[i] = exp(-tp2[2 * i + 1] * tt);
+                e3[i] = exp(-tp3[2 * i + 1] * tt);
+            }
+        }
+        FVB_HD void multiply()
+        {
+            FVB_NO_CONTRACT
+#pragma unroll
+            for (int i = 0; i < N; i++)
+            {
+                e0[i] *= s0[i];
+                e2[i] *= s2[i];
+                e3[i] *= s3[i];
+            }
+        }
+        // the 2P + 1 predictions from the current exponentials
+        FVB_HD void combine(const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P], double &g,
+            double (&f2)[P], double (&f3)[P])
+        {
+            FVB_NO_CONTRACT
             // the sums below add the terms in the order of eval(): res = 0; res += amp_j * exp_j
             double val[N];
 #pragma unroll
@@ -346,6 +408,36 @@ struct ExpModel
             FVB_NO_CONTRACT
             double f2[P], f3[P];
             eval(a, t, tp, tp2, tp3, g, f2, f3);
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                J[i] = (f2[i] - f3[i]) * rden[i];
+        }
+        // (see PointwiseSweep::step_fast) EXACT = t is a multiple of FVB_EXP_RESYNC
+        template <bool EXACT>
+        FVB_HD void step_fast(const ModelArgs &a, int t, const double (&tp)[P], const double (&tp2)[P],
+            const double (&tp3)[P], const double (&rden)[P], double &g, double (&J)[P])
+        {
+            FVB_NO_CONTRACT
+            if (EXACT || FVB_EXP_RESYNC <= 1)
+                resync(a, t, tp, tp2, tp3);
+            else
+                multiply();
+            double f2[P], f3[P];
+            combine(tp, tp2, tp3, g, f2, f3);
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                J[i] = (f2[i] - f3[i]) * rden[i];
+        }
+        FVB_HD void step_any(const ModelArgs &a, int t, const double (&tp)[P], const double (&tp2)[P],
+            const double (&tp3)[P], const double (&rden)[P], double &g, double (&J)[P], bool prec)
+        {
+            FVB_NO_CONTRACT
+            if (FVB_EXP_RESYNC <= 1 || prec || (t % FVB_EXP_RESYNC) == 0) // wave-uniform
+                resync(a, t, tp, tp2, tp3);
+            else
+                multiply();
+            double f2[P], f3[P];
+            combine(tp, tp2, tp3, g, f2, f3);
 #pragma unroll
             for (int i = 0; i < P; i++)
                 J[i] = (f2[i] - f3[i]) * rden[i];

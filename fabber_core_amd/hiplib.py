@@ -11,7 +11,8 @@ import numpy as np
 from . import vbabi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfabber_vb_hip.so")
+# (FVB_LIB_PATH: an experiment build of the engine, see fabber_core_amd/build.py --variant)
+LIB_PATH = os.environ.get("FVB_LIB_PATH") or os.path.join(_HERE, "lib", "libfabber_vb_hip.so")
 _LIB = None
 
 
@@ -49,6 +50,8 @@ def lib():
         L.fabber_vb_run_device_ex.argtypes = [cfgp, C.c_void_p, outp, C.c_void_p, C.c_int32]
         L.fabber_vb_run_host.restype = C.c_int32
         L.fabber_vb_run_host.argtypes = [cfgp, C.c_void_p, outp, C.c_int32]
+        L.fabber_vb_run_host_multi.restype = C.c_int32
+        L.fabber_vb_run_host_multi.argtypes = [cfgp, C.c_void_p, outp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vbabi.FvbSummary)]
         L.fabber_vb_postproc_device.restype = C.c_int32
         L.fabber_vb_postproc_device.argtypes = [cfgp, C.c_void_p, C.c_void_p, ppp, C.c_void_p]
         L.fabber_vb_postproc_host.restype = C.c_int32
@@ -118,9 +121,11 @@ def _prepare_data(holder, data):
     return data
 
 
-def run_host(holder, data, device=0):
+def run_host(holder, data, device=0, devices=None):
     """Voxelwise VB on the GPU from host arrays (config pointers are host numpy arrays).
-    Returns the same dict of arrays as tests/oracle.py:run."""
+    Returns the same dict of arrays as tests/oracle.py:run. devices: "all" or a list of device indices
+    (fabber_vb_run_host_multi: contiguous voxel blocks, one per entry); the result then also holds
+    `summary` = (sum of F, sum of iterations, bad voxels)."""
     cfg = holder.cfg
     data = _prepare_data(holder, data)
     V = cfg.n_voxels
@@ -136,7 +141,16 @@ def run_host(holder, data, device=0):
     out = vbabi.FvbOutputs()
     for k, a in arrs.items():
         setattr(out, k, a.ctypes.data)
-    _check(lib().fabber_vb_run_host(C.byref(cfg), data.ctypes.data, C.byref(out), device))
+    if devices is None:
+        _check(lib().fabber_vb_run_host(C.byref(cfg), data.ctypes.data, C.byref(out), device))
+    else:
+        summary = vbabi.FvbSummary()
+        if devices == "all":
+            _check(lib().fabber_vb_run_host_multi(C.byref(cfg), data.ctypes.data, C.byref(out), None, 0, C.byref(summary)))
+        else:
+            ids = (C.c_int32 * len(devices))(*devices)
+            _check(lib().fabber_vb_run_host_multi(C.byref(cfg), data.ctypes.data, C.byref(out), ids, len(devices), C.byref(summary)))
+        arrs["summary"] = (summary.sum_free_energy, summary.sum_iterations, summary.bad_voxels)
     arrs["setup_failed"] = (arrs["status"] & 0x100) != 0
     arrs["status"] = arrs["status"] & 0xFF
     return arrs

@@ -78,6 +78,10 @@ class FvbOutputs(C.Structure):
     ]
 
 
+class FvbSummary(C.Structure):
+    _fields_ = [("sum_free_energy", C.c_double), ("sum_iterations", C.c_int64), ("bad_voxels", C.c_int64)]
+
+
 class FvbPostproc(C.Structure):
     _fields_ = [
         ("mean", C.c_void_p),

@@ -218,6 +218,29 @@ int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const f
 /* Same with HOST pointers: uploads, runs, downloads, synchronises. `device` = HIP device index. */
 int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_outputs *out, int32_t device);
 
+/* What the reference's caller sees of a finished voxelwise run besides the images: the global
+ * free energy (sum over the voxels that finished), the iterations executed and the voxels that
+ * stopped on a numerical error (inference_vb.cc:529-544). */
+typedef struct fvb_summary
+{
+    double sum_free_energy; /* 0 unless outputs.free_energy was asked for */
+    int64_t sum_iterations; /* 0 unless outputs.iterations was asked for */
+    int64_t bad_voxels;     /* 0 unless outputs.status was asked for */
+} fvb_summary;
+
+/*
+ * fabber_vb_run_host over several devices of this node. Voxels are independent
+ * (inference_vb.cc:423-571), so the masked-voxel list is cut into n_devices contiguous blocks,
+ * block i runs on HIP device devices[i] - one host thread and one stream per block, the block's
+ * columns of the caller's [row][voxel] images copied straight in and out - and nothing is
+ * exchanged between the blocks; the summary is added up on the host. A device may appear more than
+ * once (two blocks then share it on two streams). devices = NULL: every visible device,
+ * n_devices ignored. Results are those of fabber_vb_run_host, bit for bit, for every block size
+ * that keeps the same kernel (see fabber_vb_kernel_name). summary may be NULL.
+ */
+int32_t fabber_vb_run_host_multi(const fvb_config *cfg, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, fvb_summary *summary);
+
 /* Result images from the packed MVN (device pointers, asynchronous on stream). */
 int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const double *mvn,
     const fvb_postproc *pp, void *stream);

@@ -40,6 +40,10 @@ typedef struct oracle_trace
 int32_t oracle_vb_run(const fvb_config *cfg, const void *data, const fvb_outputs *out,
     int32_t v_begin, int32_t v_end, int32_t halt_bad_voxel, const oracle_trace *trace);
 
+/* Which algorithm restates NEWMAT's .i(): 0 = LU with partial pivoting (default), 1 = the unpivoted
+ * symmetric sweep of the kernels. See inverse() in vb_oracle.cc. Process-wide, not thread-safe. */
+void oracle_set_inverse(int32_t mode);
+
 /* InferenceTechnique::SaveResults / Vb::SaveResults images from a packed MVN. */
 int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double *mvn,
     const fvb_postproc *pp);

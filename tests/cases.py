@@ -195,3 +195,28 @@ def linear_problem(n_voxels, n_times, seed, noise_sd=1.0, **cfg_opts):
     y = X @ theta + rng.normal(0, noise_sd, size=(n_times, n_voxels))
     h = vbabi.build_config(vbabi.MODEL_LINEAR, n_voxels, n_times, design=X, **cfg_opts)
     return h, y.astype(np.float32)
+
+
+def c5_problem(shape, seed=20260105, noise_sd=0.1, n_times=100, dt=0.02, max_iterations=10, sigma=4.0, **cfg_opts):
+    """BASELINE configs[4] (SURVEY 8d "C5 inputs"): the bi-exponential model of config 3 on a full
+    shape[0] x shape[1] x shape[2] grid with a 6-neighbour MRF prior (type M) on amp1; the ground-truth
+    amp1 is a smooth field (white noise, Gaussian-filtered with sigma voxels, rescaled to [0.5, 1]).
+    Returns (holder, coords [3][V], data float32 [T][V], amp1 [V])."""
+    import scipy.ndimage
+    nx, ny, nz = shape
+    rng = np.random.default_rng(seed)
+    field = scipy.ndimage.gaussian_filter(rng.standard_normal((nz, ny, nx)), sigma, mode="nearest")
+    field = 0.5 + 0.5 * (field - field.min()) / max(field.max() - field.min(), 1e-30)
+    coords = vbabi.grid_coords(shape)
+    amp1 = field.reshape(-1).astype(np.float32)  # z slowest, x fastest: the voxel order of grid_coords
+    V = amp1.size
+    t = np.arange(n_times, dtype=np.float64) * dt
+    e1 = np.exp(-1.0 * t).astype(np.float32)
+    e2 = (0.5 * np.exp(-6.0 * t)).astype(np.float32)
+    y = np.empty((n_times, V), dtype=np.float32)
+    for i in range(n_times):  # row by row: 128^3 x 100 floats are 840 MB, no float64 temporaries of that size
+        y[i] = amp1 * e1[i] + e2[i] + rng.standard_normal(V, dtype=np.float32) * np.float32(noise_sd)
+    opts = dict(param_overrides={"amp1": dict(type="M")})
+    opts.update(cfg_opts)
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, n_times, num_exps=2, dt=dt, max_iterations=max_iterations, **opts)
+    return h, coords, y, amp1

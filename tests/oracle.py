@@ -123,6 +123,12 @@ def run_fma(holder, data, **kw):
     return run(holder, data, _lib=lib_fma(), **kw)
 
 
+def set_inverse(mode, _lib=None):
+    """'lu' (default: LAPACK-style LU with partial pivoting) or 'sweep' (the kernels' unpivoted symmetric
+    sweep) as the restatement of NEWMAT's .i(); see inverse() in oracle/vb_oracle.cc."""
+    (_lib or lib()).oracle_set_inverse({"lu": 0, "sweep": 1}[mode])
+
+
 def run_quad(holder, data, **kw):
     """Ground truth: the same statements in binary128 (white noise, voxelwise)."""
     return run(holder, data, _lib=lib_quad(), **kw)

@@ -107,8 +107,10 @@ def test_random_configuration(seed):
     # iterations run here the free energy still shows it at the 1e-6 level (means stay within
     # their 1e-6 bound). Both CPU builds call the same libm, so the measured floor cannot see it.
     tol_f = 2e-5 if h.cfg.model == vbabi.MODEL_EXP else parity.TOL_F
+    # (random problems include ill-conditioned ones: every configuration may use the measured CPU floor,
+    # and the ones that did are listed at the end of the run)
     parity.strict(h, cpu, got, what=desc, cpu2=cpu2, allow_iter_mismatch=max(1, h.cfg.n_voxels // 50) if uses_f else 0,
-                  tol_f=tol_f)
+                  tol_f=tol_f, allow_floor=True)
 
 
 def test_random_cases_are_valid_for_the_oracle():
@@ -174,7 +176,7 @@ def test_random_spatial_configuration(seed):
     for r in (cpu, cpu2):
         r.setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
     tol_f = 2e-5 if h.cfg.model == vbabi.MODEL_EXP else parity.TOL_F
-    parity.strict(h, cpu, got, what=desc, cpu2=cpu2, tol_f=tol_f)
+    parity.strict(h, cpu, got, what=desc, cpu2=cpu2, tol_f=tol_f, allow_floor=True)
 
 
 def test_random_spatial_cases_are_valid_for_the_oracle():

@@ -4,11 +4,16 @@ chaotic on the bi-exponential fit (BASELINE config 3) and merely noisy on the ot
 Two CPU builds of the same oracle source - with and without fused multiply-add contraction,
 i.e. two equally valid compilations of the reference's arithmetic - are compared. Runs on CPU.
 """
+import os
+import sys
+
 import numpy as np
 
 import cases
 import oracle
 import parity
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 
 
 def test_biexponential_fit_is_chaotic_between_two_cpu_builds():
@@ -34,6 +39,29 @@ def test_growth_of_rounding_differences_in_the_first_iterations():
         e_mean, _, _ = parity.voxel_errors(h, oracle.run(h, y), oracle.run_fma(h, y))
         med.append(np.median(e_mean))
     assert med[0] < 1e-6 and med[2] > 1e3 * med[0] and med[2] > 1e-4, med
+
+
+def test_fp64_builds_against_the_binary128_ground_truth():
+    """The same oracle source evaluated in binary128 (tests/golden/make_c3_truth.py) is what the
+    ALGORITHM computes; both fp64 builds are measured against it on 4096 seeded voxels. The chaos is
+    in the first iterations - the median error of the parameter means grows from 2e-7 after one
+    iteration to 4e-2 after five - and then most voxels fall back onto the truth's fixed point: after
+    50 iterations ~74 % of them are within the north star's 1e-4 (median 5e-10) and the rest sit on a
+    different fixed point altogether (error ~10 posterior standard deviations). These are the numbers
+    a GPU implementation is held to (tests/test_hip_parity.py::test_c3_error_against_the_ground_truth)."""
+    truth = parity.load_c3_truth()
+    import make_c3_truth as mt
+    for run in (oracle.run, oracle.run_fma):
+        h, y = mt.problem(truth["n_voxels"])
+        s = parity.truth_stats(h, truth, run(h, y))
+        assert 0.70 < s["within_1e4"] < 0.78 and s["median"] < 1e-9 and s["p90"] > 1.0 and s["failed"] < 3e-3, s
+        med = {}
+        for k, it in enumerate(truth["its"]):
+            if it in (1, 5):
+                hk, _ = mt.problem(truth["n_voxels"])
+                hk.cfg.max_iterations = it
+                med[it] = parity.truth_trace_stats(hk, truth["trace_means"][k], run(hk, y))["median"]
+        assert med[1] < 1e-6 and med[5] > 1e-2, med
 
 
 def test_well_conditioned_models_are_reproducible():

@@ -72,10 +72,26 @@ def main():
                         calib[pat + " " + ctr] = dict(counter=mean(vals), true_bytes=nbytes, bytes_per_count=nbytes / mean(vals))
     out["calibration"] = calib
     res = {}
-    for which in ("fetch", "write", "sq"):
+    for which in ("fetch", "write", "sq", "fp64", "mem"):
         for name, vals in counters(os.path.join(root, which), match).items():
             res[name] = dict(mean_per_launch=mean(vals), launches=len(vals))
     out["counters"] = res
+    # derived: shader clock held during the kernel, executed fp64 FLOP/s, VALU issue utilisation at that clock
+    kt = out["kernel_trace"]
+    g = lambda n: res.get(n, {}).get("mean_per_launch")
+    if kt and g("GRBM_GUI_ACTIVE"):
+        # (the profiled pass's own duration would be the right divisor; the trace pass's is within ~3 %)
+        clock_ghz = g("GRBM_GUI_ACTIVE") / 8 / kt["avg_ns"]
+        d = {"shader_clock_ghz": clock_ghz}
+        if g("SQ_INSTS_VALU_FMA_F64") is not None:
+            flop = (2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")) * 64
+            d["fp64_flop_per_launch"] = flop
+            d["fp64_tflops"] = flop / kt["avg_ns"] / 1e3
+            d["fp64_vector_peak_tflops_at_2p4ghz"] = 78.6
+            d["fp64_frac_of_peak"] = d["fp64_tflops"] / 78.6
+        if g("SQ_INSTS_VALU"):
+            d["valu_issue_utilisation"] = g("SQ_INSTS_VALU") * 4 / (1024 * kt["avg_ns"] * clock_ghz)
+        out["derived"] = d
     print(json.dumps(out, indent=1))
 
 
