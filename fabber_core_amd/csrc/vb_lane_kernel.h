@@ -809,13 +809,17 @@ struct ParkPlan
     static constexpr int PT = P * (P + 1) / 2;
     // rows of 512 B that fit a wave's share of the CU's 160 KB of LDS at lane_waves<P>() waves per SIMD
     static constexpr int BUDGET = lane_waves<P>() >= 3 ? 26 : 38;
+    // Beside the parked state the wave's share holds the rescue row and, if they fit, the 4 P rows of the
+    // perturbed parameter vectors (SweepPark below); those come before Lambda, which only the kernels
+    // with F carry across the pass and only for their save / revert copy.
+    static constexpr int OTHER = 1 + ((PT + 2 * P + 1 + 4 * P <= BUDGET) ? 4 * P : 0);
     static constexpr int SIG = 0;
-    static constexpr bool HAS_LAM = NEEDF && (2 * PT <= BUDGET);
+    static constexpr bool HAS_LAM = false; // (the voxel loop keeps no Lambda across its stages)
     static constexpr int LAM = PT;
     static constexpr int PM = PT + (HAS_LAM ? PT : 0);
-    static constexpr bool HAS_PM = (PM + P <= BUDGET);
+    static constexpr bool HAS_PM = (PM + P + OTHER <= BUDGET);
     static constexpr int PPREC = PM + (HAS_PM ? P : 0);
-    static constexpr bool HAS_PPREC = HAS_PM && (PPREC + P <= BUDGET);
+    static constexpr bool HAS_PPREC = HAS_PM && (PPREC + P + OTHER <= BUDGET);
     static constexpr int ROWS = PPREC + (HAS_PPREC ? P : 0);
 };
 
@@ -1059,6 +1063,143 @@ __device__ __forceinline__ bool calc_free_energy(
     return ok;
 }
 
+// The voxel loop's copy for save / revert (inference_vb.cc:432-434,451-458,516-525): posterior means and
+// covariance with log|det Lambda| (Lambda itself is a temporary of UpdateTheta here), prior, noise.
+// Same row count as save_state (the rows of Lambda stay unused).
+template <int P>
+__device__ __forceinline__ void save_posterior(const KernelArgs &ka, int v, const VoxelState<P> &st, bool logdet_valid)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    double *p = ka.save + v;
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        p[(size_t)(r++) * V] = st.m[i];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        p[(size_t)(r++) * V] = st.Sig[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        p[(size_t)(r++) * V] = st.pm[i];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        p[(size_t)(r++) * V] = st.pprec[i];
+    p[(size_t)(r++) * V] = st.b;
+    p[(size_t)(r++) * V] = st.c;
+    p[(size_t)(r++) * V] = st.logdetLam;
+    p[(size_t)(r++) * V] = logdet_valid ? 1.0 : 0.0;
+}
+
+template <int P>
+__device__ __forceinline__ void restore_posterior(const KernelArgs &ka, int v, VoxelState<P> &st, bool &logdet_valid)
+{
+    constexpr int PT = P * (P + 1) / 2;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    const double *p = ka.save + v;
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.m[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        st.Sig[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.pm[i] = p[(size_t)(r++) * V];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.pprec[i] = p[(size_t)(r++) * V];
+    st.b = p[(size_t)(r++) * V];
+    st.c = p[(size_t)(r++) * V];
+    st.logdetLam = p[(size_t)(r++) * V];
+    logdet_valid = p[(size_t)(r++) * V] != 0.0;
+    st.covValid = true;
+    st.precValid = false;
+}
+
+// calc_free_energy for a loop that evaluates F four times per iteration (inference_vb.cc:468-495): the
+// same sum with the pieces that do not change between two evaluations kept - the noise terms depend on
+// (b, c) only (b changes once per iteration, c after the first noise update never: its lgamma and digamma
+// are kept separately), the prior's log-determinant on the prior precisions only (re-applied once per
+// iteration), lgamma(c0) and log(b0) are constants of the run. fp64 lgamma (seven divisions), digamma
+// and the logarithms are ~1000 of the ~1200 instructions of one evaluation. The terms are added in a
+// different order than noisemodel_white.cc:365-454 does (differences of a few ulp of the largest term).
+template <int P>
+struct FreeEnergyCache
+{
+    double b, c;         // the noise posterior the noise terms were computed for (NaN: none yet)
+    double c_fn;         // the shape lgamma / digamma were computed for
+    double lgamma_c, digamma_c;
+    double noise_terms;
+    double prior_const;  // -lgamma(c0) - c0 log(b0)
+    double prior_logdet; // 1/2 sum_i log|prior precision_i|
+    bool prior_valid;
+    __device__ __forceinline__ void init(const KernelArgs &ka)
+    {
+        b = c = c_fn = __builtin_nan("");
+        prior_valid = false;
+        const double b0 = ka.cfg.noise_prior_b[0], c0 = ka.cfg.noise_prior_c[0];
+        prior_const = -gammaln(c0) - c0 * log(b0);
+    }
+};
+
+template <int P>
+__device__ __forceinline__ bool calc_free_energy_cached(const KernelArgs &ka, VoxelState<P> &st, double kk, double trSA,
+    double Fprior, FreeEnergyCache<P> &fc, bool &logdet_valid, double &F, bool &finite)
+{
+    // log|det Lambda| comes with the covariance from UpdateTheta's inversion; only a posterior that arrived
+    // as a covariance (the initial one) has to be inverted for it, as MVNDist::GetPrecisions would
+    bool ok = true;
+    if (!logdet_valid)
+    {
+        st.precValid = false;
+        ok = ensure_prec<P>(st);
+        logdet_valid = true;
+    }
+    const double nq = (double)ka.n_unmasked;
+    if (!(st.b == fc.b && st.c == fc.c))
+    {
+        const double si = st.b, ci = st.c;
+        if (!(ci == fc.c_fn))
+        {
+            fc.lgamma_c = gammaln(ci);
+            fc.digamma_c = digamma(ci);
+            fc.c_fn = ci;
+        }
+        const double log_b = log(si);
+        const double dg = fc.digamma_c + log_b;
+        const double expectedLogPhiDist = -fc.lgamma_c - ci * log_b - ci + (ci - 1) * dg;
+        fc.noise_terms = -expectedLogPhiDist + dg * (nq * 0.5 + ka.cfg.noise_prior_c[0] - 1) + fc.prior_const
+            - si * ci / ka.cfg.noise_prior_b[0];
+        fc.b = si;
+        fc.c = ci;
+    }
+    if (!fc.prior_valid)
+    {
+        double logdetPrior = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            logdetPrior += log(fabs(st.pprec[i]));
+        fc.prior_logdet = 0.5 * logdetPrior;
+        fc.prior_valid = true;
+    }
+    double quad = 0, trSL0 = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        const double dm = st.m[i] - st.pm[i];
+        quad += dm * st.pprec[i] * dm;
+        trSL0 += st.Sig[tri(i, i)] * st.pprec[i];
+    }
+    const double theta_terms = -(0.5 * st.logdetLam - 0.5 * P * (LOG_2PI + 1)) - 0.5 * quad - 0.5 * trSL0;
+    const double data_terms = -0.5 * st.b * st.c * kk - 0.5 * trSA - 0.5 * nq * LOG_2PI - 0.5 * P * LOG_2PI; // (trace unscaled, :416-417)
+    F = theta_terms + fc.noise_terms + data_terms + fc.prior_logdet;
+    finite = is_finite(F);
+    F += Fprior; // Vb::CalculateF, inference_vb.cc:310
+    return ok;
+}
+
 template <int P>
 __device__ __forceinline__ void save_state(const KernelArgs &ka, int v, const VoxelState<P> &st)
 {
@@ -1263,108 +1404,141 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
     };
     int phase = FIRST;
     int n_lin = 0; // linearisations done so far
+    bool logdet_valid = false; // st.logdetLam belongs to st.Sig (see calc_free_energy_cached)
 
-// CalculateF (inference_vb.cc:302-318) with the given residual terms; a failure ends the voxel's
-// loop exactly where the reference's exception would (F keeps its previous value).
-#define FVB_EVAL_F(KK, TR)                                                                                   \
-    {                                                                                                        \
-        double Fn_;                                                                                          \
-        bool fin_ = true;                                                                                    \
-        if (!calc_free_energy<P>(ka, st, (KK), (TR), Fprior, Fn_, fin_))                                     \
-        {                                                                                                    \
-            status = FVB_BAD_RESULT;                                                                         \
-            break;                                                                                           \
-        }                                                                                                    \
-        if (!fin_)                                                                                           \
-        {                                                                                                    \
-            status = FVB_BAD_FREE_ENERGY;                                                                    \
-            break;                                                                                           \
-        }                                                                                                    \
-        F = Fn_;                                                                                             \
-    }
+    // The iteration as four stages that each end with (at most) ONE evaluation of the free energy, so that
+    // CalculateF (inference_vb.cc:302-318) - lgamma, digamma, logarithms, a few hundred instructions - is in
+    // the kernel once instead of at its four call sites :468, :477, :485, :495 (+ :524 after a revert):
+    //   LINEARISE  ReCentre about the means                F(k = y - g)      "lin"   [skipped the first time]
+    //   PRIORS     save if asked, Prior::ApplyToMVN        F(k = y - g)      "before"
+    //   THETA      UpdateTheta, k'Qk and tr(Sigma J'QJ)    F(k, trace)       "theta"
+    //   NOISE      UpdateNoise                             F(k, trace)       "phi"
+    // A failure ends the voxel's loop exactly where the reference's exception would (F keeps its value).
+    enum
+    {
+        LINEARISE,
+        PRIORS,
+        THETA,
+        NOISE
+    };
+    int stage = LINEARISE;
+    double kk = 0, trSA = 0;    // of the THETA stage, used again by NOISE
+    FreeEnergyCache<P> fcache;
+    if (NEEDF)
+        fcache.init(ka);
     for (;;)
     {
-        park_state<P, NEEDF>(park, st);
-        if (FEED == FEED_STRIDED)
-            status = recentre<Model, P>(ka, ma, v, st.m, mo, n_lin < ka.precise_passes);
-        else
-            status = recentre_tiles<Model, P, RAW>(ka, ma, lane_tile, st.m, mo, n_lin < ka.precise_passes, sweep_park);
-        n_lin = (phase == REVERTED) ? n_lin : n_lin + 1;
-        unpark_state<P, NEEDF>(park, st);
-        if (status != FVB_OK)
+        bool want_f = NEEDF;
+        double f_kk, f_tr;
+        if (stage == LINEARISE)
         {
-            setup_failed = (phase == FIRST);
-            break;
+            park_state<P, NEEDF>(park, st);
+            if (FEED == FEED_STRIDED)
+                status = recentre<Model, P>(ka, ma, v, st.m, mo, n_lin < ka.precise_passes);
+            else
+                status = recentre_tiles<Model, P, RAW>(ka, ma, lane_tile, st.m, mo, n_lin < ka.precise_passes, sweep_park);
+            n_lin = (phase == REVERTED) ? n_lin : n_lin + 1;
+            unpark_state<P, NEEDF>(park, st);
+            if (status != FVB_OK)
+            {
+                setup_failed = (phase == FIRST);
+                break;
+            }
+            if (phase == FIRST)
+            {
+                if (use_save)
+                    save_posterior<P>(ka, v, st, logdet_valid); // :432-434
+                want_f = false;
+            }
         }
-        if (phase == FIRST)
+        else if (stage == PRIORS)
         {
-            if (use_save)
-                save_state<P>(ka, v, st); // :432-434
+            if (use_save && conv_need_save(conv)) // :451-458
+                save_posterior<P>(ka, v, st, logdet_valid);
+            if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
+            {
+                status = FVB_BAD_RESULT;
+                break;
+            }
+            fcache.prior_valid = false; // (the prior precisions were rewritten)
+        }
+        else if (stage == THETA)
+        {
+            if (!update_theta<P>(st, mo, conv_lm_alpha(conv)) || !ensure_cov<P>(st)) // :470
+            {
+                status = FVB_BAD_RESULT;
+                break;
+            }
+            st.precValid = false; // Lambda is not kept: the covariance and log|det Lambda| are
+            logdet_valid = true;
+            if (FEED == FEED_STRIDED)
+                residual_and_trace<Model, P, NEEDF>(ka, ma, v, st, mo, kk, trSA, park, rescue_row);
+            else
+                residual_and_trace_adaptive<Model, P, NEEDF, RAW, SWEEP_PARKED>(ka, ma, v, st, mo, kk, trSA, park, rescue_row, wave_tile, sweep_park);
         }
         else
         {
-            if (NEEDF) // "lin" :495, or F of the restored state :524
+            update_noise<P>(ka, st, kk, trSA); // :479
+        }
+        if (want_f)
+        {
+            if (stage == LINEARISE || stage == PRIORS) // the centre is the current mean, so k = y - g
             {
                 if (!ensure_cov<P>(st))
                 {
                     status = FVB_BAD_RESULT;
                     break;
                 }
-                FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
+                f_kk = mo.s;
+                f_tr = trace_SA<P>(st, mo);
             }
-            if (phase == REVERTED)
-                break;
-            if (ka.out.f_history && hist_len < ka.cfg.f_history_rows) // :496-497
-                ka.out.f_history[(size_t)hist_len * V + v] = F;
-            hist_len++;
-            ++it;
-            if (conv_test(conv, F)) // :500
+            else
             {
-                if (use_save && conv_need_save(conv)) // :506-513
-                    save_state<P>(ka, v, st);
-                if (use_save && conv_need_revert(conv)) // :516-525
-                {
-                    restore_state<P>(ka, v, st);
-                    phase = REVERTED;
-                    continue;
-                }
-                break;
+                f_kk = kk;
+                f_tr = trSA;
             }
-        }
-        phase = ITERATING;
-        if (use_save && conv_need_save(conv)) // :451-458
-            save_state<P>(ka, v, st);
-        if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
-        {
-            status = FVB_BAD_RESULT;
-            break;
-        }
-        if (NEEDF) // "before" :468 - the centre is the current mean, so k = y - g
-        {
-            if (!ensure_cov<P>(st))
+            double Fn;
+            bool fin = true;
+            if (!calc_free_energy_cached<P>(ka, st, f_kk, f_tr, Fprior, fcache, logdet_valid, Fn, fin))
             {
                 status = FVB_BAD_RESULT;
                 break;
             }
-            FVB_EVAL_F(mo.s, trace_SA<P>(st, mo))
+            if (!fin)
+            {
+                status = FVB_BAD_FREE_ENERGY;
+                break;
+            }
+            F = Fn;
         }
-        if (!update_theta<P>(st, mo, conv_lm_alpha(conv)) || !ensure_cov<P>(st)) // :470
+        if (stage == LINEARISE)
         {
-            status = FVB_BAD_RESULT;
-            break;
+            if (phase == REVERTED) // :516-525 done
+                break;
+            if (phase == ITERATING)
+            {
+                if (ka.out.f_history && hist_len < ka.cfg.f_history_rows) // :496-497
+                    ka.out.f_history[(size_t)hist_len * V + v] = F;
+                hist_len++;
+                ++it;
+                if (conv_test(conv, F)) // :500
+                {
+                    if (use_save && conv_need_save(conv)) // :506-513
+                        save_posterior<P>(ka, v, st, logdet_valid);
+                    if (use_save && conv_need_revert(conv)) // :516-525
+                    {
+                        restore_posterior<P>(ka, v, st, logdet_valid);
+                        fcache.prior_valid = false;
+                        phase = REVERTED;
+                        continue; // LINEARISE again, about the restored means
+                    }
+                    break;
+                }
+            }
+            phase = ITERATING;
         }
-        double kk, trSA;
-        if (FEED == FEED_STRIDED)
-            residual_and_trace<Model, P, NEEDF>(ka, ma, v, st, mo, kk, trSA, park, rescue_row);
-        else
-            residual_and_trace_adaptive<Model, P, NEEDF, RAW, SWEEP_PARKED>(ka, ma, v, st, mo, kk, trSA, park, rescue_row, wave_tile, sweep_park);
-        if (NEEDF) // "theta" :477
-            FVB_EVAL_F(kk, trSA)
-        update_noise<P>(ka, st, kk, trSA); // :479
-        if (NEEDF) // "phi" :485
-            FVB_EVAL_F(kk, trSA)
+        stage = (stage + 1) & 3;
     }
-#undef FVB_EVAL_F
 
     // ---- result MVN: MVNDist(fwd_post, noise.OutputAsMVN()) packed as MVNDist::Save does
     // (inference_vb.cc:549-550; dist_mvn.cc:57-100,410-429; noisemodel_white.cc:55-68) ----
