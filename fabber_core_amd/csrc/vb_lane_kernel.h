@@ -539,6 +539,33 @@ __device__ __forceinline__ bool apply_priors(const KernelArgs &ka, int v, int it
     return ok;
 }
 
+// eq (20), m = Sigma (phi J'Q(y - g + J m_l) + Lambda0 mu0), with the order of its operations FIXED
+// (explicit fused multiply-adds): the spatial sweep evaluates the one entry that depends on a voxel's
+// neighbours in a kernel of its own (vb_spatial.h) and must land on the same bits as update_theta.
+//   base_i = phi (u_i + sum_j A_ij ml_j)      rhs_i = fma(prec0_i, mu0_i, base_i)     m_i = sum_j Sigma_ij rhs_j
+template <int P>
+__device__ __forceinline__ double theta_rhs_base(double phibar, const Moments<P> &mo, int i)
+{
+    double aml = 0;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        aml = __builtin_fma(mo.A[tri(i, j)], mo.ml[j], aml);
+    return phibar * (mo.u[i] + aml);
+}
+__device__ __forceinline__ double theta_rhs(double base, double prior_prec, double prior_mean)
+{
+    return __builtin_fma(prior_prec, prior_mean, base);
+}
+template <int P>
+__device__ __forceinline__ double theta_mean(const double *Sig, const double (&rhs)[P], int i)
+{
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        s = __builtin_fma(Sig[tri(i, j)], rhs[j], s);
+    return s;
+}
+
 // WhiteNoiseModel::UpdateTheta (noisemodel_white.cc:275-363), one phi
 template <int P>
 __device__ __forceinline__ bool update_theta(VoxelState<P> &st, const Moments<P> &mo, double alpha)
@@ -557,24 +584,12 @@ __device__ __forceinline__ bool update_theta(VoxelState<P> &st, const Moments<P>
         double rhs[P];
 #pragma unroll
         for (int i = 0; i < P; i++)
-        {
-            double aml = 0;
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                aml += mo.A[tri(i, j)] * mo.ml[j];
-            rhs[i] = phibar * (mo.u[i] + aml) + st.pprec[i] * st.pm[i];
-        }
+            rhs[i] = theta_rhs(theta_rhs_base<P>(phibar, mo, i), st.pprec[i], st.pm[i]);
         if (!ensure_cov<P>(st))
             return false;
 #pragma unroll
         for (int i = 0; i < P; i++)
-        {
-            double s = 0;
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                s += st.Sig[tri(i, j)] * rhs[j];
-            st.m[i] = s; // eq (20)
-        }
+            st.m[i] = theta_mean<P>(st.Sig, rhs, i); // eq (20)
     }
     else
     {

@@ -63,6 +63,29 @@ struct SpatialArgs
     int32_t owned_begin, owned_end;
     int32_t n_voxels_global; // the V of h_K = V/2 + q2 (priors.cc:321)
     double *ak_sums;         // [P][2] (trace_term, term2): this slab's, then the all-reduced ones
+    // ---- the split first sweep (SweepPlan below); NULL / 0 when the per-level launches are used ----
+    const int32_t *pos_of;   // [V] position of a voxel in the level-major numbering
+    int32_t n_pos;           // positions, every level padded to a multiple of 16
+    int32_t n_spatial;       // spatial parameters ...
+    int32_t spatial_param[FVB_MAX_PARAMS]; // ... and which they are
+    double *sw_x;            // [n_spatial][n_pos] means of the spatial parameters, swept in place
+    double *sw_pm;           // [n_spatial][n_pos] their prior means as the sweep left them
+    double *sw_rhs0;         // [P][n_pos] eq (20) right-hand side: complete where it needs no neighbour, else its base
+    double *sw_pprec;        // [n_spatial][n_pos] prior precision of the spatial parameter
+    double *sw_q;            // [n_spatial][n_pos] (1 / prior precision) x spatial precision
+    double *sw_rec;          // [n_spatial][n_pos] 1 / number of live neighbours (types M, m)
+    double *sw_sig;          // [n_spatial][P][n_pos] the spatial parameters' rows of Sigma
+    int32_t *sw_npos;        // [6][n_pos] positions of the live first neighbours, -1 = none
+    int32_t *sw_alive;       // [n_pos] 1 = the voxel takes part in the sweep
+    const int32_t *sw_level_pos;   // [n_levels] first position of a level
+    const int32_t *sw_level_count; // [n_levels] voxels in it
+    int32_t n_levels;
+    unsigned long long *sw_gran; // [n_spatial][n_pos][2] the means again as two self-validating 8-byte granules
+                                 // {low / high half of the double, serial number of the sweep that wrote it}
+    uint32_t sw_serial;      // this sweep's serial number (1, 2, ...; the buffer starts zeroed)
+    uint32_t *sw_counter;    // (unused by the data-flow sweep; kept for the barrier variant)
+    int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the
+                             // sweep, a barrier timed out): the run is repeated with the per-level launches
 };
 
 #if defined(__HIPCC__)
@@ -522,8 +545,403 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
     sp_store_theta<P>(sa, v, st);
 }
 
+// =====================================================================================================
+// The first sweep, split (spatial prior types M and m). Per level the per-level launches above pay one
+// kernel boundary and one voxel's whole dependent chain - state, neighbour ids, neighbour means, the
+// P x P inversion, the stores - 382 times per iteration at 128^3 (5.2 of 6.2 ms). But of all that only
+// ONE number per spatial parameter really waits for the neighbours: the prior mean
+//        mu0_k = (1 / prec0_k) s_k mean(neighbours' current means of parameter k)       (priors.cc:441-482)
+// The prior PRECISION s_k = a_K (nn + 1e-8) depends on the neighbour COUNT only, so Lambda (eq 19), its
+// inverse Sigma and every entry of eq (20)'s right-hand side except mu0_k's are known for all voxels at
+// once. The sweep that has to respect the reference's voxel order shrinks to
+//        m_k(v) = sum_j Sigma_kj rhs_j,   rhs_k = fma(prec0_k, mu0_k, base_k)
+// a dozen multiply-adds per voxel on values laid out level-major. Three steps per iteration:
+//   vb_spatial_prep_kernel   all voxels in parallel: priors, Lambda, Sigma, right-hand sides -> sweep records
+//   vb_spatial_sweep_kernel  ONE launch: a few workgroups walk the levels in order with a counter barrier
+//                            between levels (means handed over with sc1 stores / loads, MI355X_MICROARCH.md
+//                            "Valid forms", row 1) and update the spatial parameters' means in place
+//   vb_spatial_noise_kernel  (FAST) first completes the other means from the sweep's result - the same
+//                            theta_rhs / theta_mean sequence update_theta runs, so the posterior is the
+//                            per-level kernels' bit for bit - then carries on with the second sweep
+// A voxel that FAILS during the first sweep (singular Lambda, non-finite F) changes its later neighbours'
+// lists in the reference (Vb::IgnoreVoxel); the split sweep does not model that: it raises sw_flags[0] and
+// the driver repeats the whole run with the per-level launches (tests/test_spatial.py forces both).
+// =====================================================================================================
+__device__ __forceinline__ double load_sc1(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_sc1(double *p, double x)
+{
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A voxel that drops out in prep (the run is going to be repeated): hand its old means to the sweep with THIS
+// sweep's serial number, so that no neighbour waits for it.
+__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos)
+{
+    const size_t NP = (size_t)sa.n_pos;
+    for (int s = 0; s < sa.n_spatial; s++)
+    {
+        unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
+        const unsigned long long now = (unsigned long long)sa.sw_serial << 32;
+        g[0] = now | (g[0] & 0xffffffffull);
+        g[1] = now | (g[1] & 0xffffffffull);
+    }
+}
+
+template <int P, bool NEEDF>
+__global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *__restrict__ sap, int it)
+{
+    typedef SpLayout<P> L;
+    const SpatialArgs &sa = *sap;
+    const KernelArgs &ka = sa.ka;
+    const int v = sa.owned_begin + blockIdx.x * 64 + threadIdx.x;
+    if (v >= sa.owned_end)
+        return;
+    const size_t V = (size_t)ka.cfg.n_voxels;
+    const size_t NP = (size_t)sa.n_pos;
+    const int pos = sa.pos_of[v];
+    const bool ignored = sa.status[v] != 0;
+    if (ignored)
+        sa.sw_alive[pos] = 0;
+    if (ignored && v != sa.owned_end - 1) // (the last voxel's priors are observable through its F term)
+        return;
+    VoxelState<P> st;
+    Moments<P> mo;
+    sp_load<P>(sa, v, st, mo);
+    const int dims = sa.spatial_dims;
+    int n1[6];
+    bool live1[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+    {
+        const int u = sa.nn[(size_t)v * 6 + a];
+        n1[a] = (u < 0) ? v : u;
+        live1[a] = (u >= 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+        live1[a] = live1[a] && (sa.status[n1[a]] == 0);
+    int nn_live = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+        nn_live += live1[a] ? 1 : 0;
+    double Fprior = 0;
+    int si = 0; // index among the spatial parameters
+#pragma unroll
+    for (int k = 0; k < P; k++)
+    {
+        const int type = ka.cfg.prior_type[k];
+        if (is_spatial_type(type)) // SpatialPrior::ApplyToMVN (priors.cc:362-482), types M and m
+        {
+            const int nn = (type == FVB_PRIOR_SPATIAL_m) ? 2 * dims : nn_live;
+            const double aK = sa.aK[k];
+            const double spatial_prec = (type == FVB_PRIOR_SPATIAL_M) ? aK * (nn + 1e-8) : aK * nn;
+            st.pprec[k] = (type == FVB_PRIOR_SPATIAL_m) ? spatial_prec : ka.cfg.prior_prec[k] + spatial_prec;
+            const double pcov = 1.0 / st.pprec[k];
+            if (!ignored)
+            {
+                sa.sw_pprec[si * NP + pos] = st.pprec[k];
+                sa.sw_q[si * NP + pos] = pcov * spatial_prec;
+                sa.sw_rec[si * NP + pos] = 1 / double(nn);
+                sa.sw_x[si * NP + pos] = st.m[k];
+                // the mean as the sweep's neighbours read it: a value of the PREVIOUS sweep
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(st.m[k]);
+                const unsigned long long old = (unsigned long long)(sa.sw_serial - 1) << 32;
+                sa.sw_gran[((size_t)si * NP + pos) * 2] = old | (bits & 0xffffffffull);
+                sa.sw_gran[((size_t)si * NP + pos) * 2 + 1] = old | (bits >> 32);
+            }
+            si++;
+        }
+        else if (type == FVB_PRIOR_ARD) // priors.cc:150-181
+        {
+            const double new_cov = st.m[k] * st.m[k] + st.Sig[tri(k, k)];
+            if (it == 0)
+            {
+                st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
+                st.pm[k] = ka.cfg.prior_mean[k];
+            }
+            else
+                st.pprec[k] = 1.0 / new_cov;
+            const double bb = 2 / new_cov;
+            Fprior += -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
+        }
+        else if (type == FVB_PRIOR_IMAGE)
+        {
+            st.pm[k] = ka.cfg.image_prior[k][v];
+            st.pprec[k] = ka.cfg.prior_prec[k];
+        }
+        else
+        {
+            st.pm[k] = ka.cfg.prior_mean[k];
+            st.pprec[k] = ka.cfg.prior_prec[k];
+        }
+    }
+    if (v == sa.owned_end - 1)
+        *sa.fprior_last = Fprior;
+    if (ignored)
+        return;
+    if (NEEDF)
+    {
+        // CalculateF "before" (:643) with the old posterior and the new priors. Only its FAILURE is observable
+        // (a non-finite F stops the voxel before its means are updated); the one term that needs the spatial
+        // prior means, (m - mu0)' Lambda0 (m - mu0), is checked where they are known (noise kernel).
+        VoxelState<P> tmp = st;
+        int sk = 0;
+#pragma unroll
+        for (int k = 0; k < P; k++)
+            if (is_spatial_type(ka.cfg.prior_type[k]))
+                tmp.pm[k] = tmp.m[k];
+        double F0;
+        bool finite0 = true;
+        if (!calc_free_energy<P>(ka, tmp, mo.s, trace_SA<P>(tmp, mo), Fprior, F0, finite0) || !finite0)
+        {
+            sa.sw_flags[0] = 1;
+            sa.sw_alive[pos] = 0;
+            sweep_release(sa, pos);
+            return;
+        }
+        (void)sk;
+    }
+    // eq (19) and its inverse, exactly update_theta's; the means follow in the sweep and in the noise kernel
+    const double phibar = st.b * st.c;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            st.Lam[tri(i, j)] = phibar * mo.A[tri(i, j)] + ((i == j) ? st.pprec[i] : 0.0);
+    st.precValid = true;
+    st.covValid = false;
+    if (!ensure_cov<P>(st))
+    {
+        sa.sw_flags[0] = 1; // this voxel fails in the first sweep: not modelled here
+        sa.sw_alive[pos] = 0;
+        sweep_release(sa, pos);
+        return;
+    }
+    si = 0;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+    {
+        const double base = theta_rhs_base<P>(phibar, mo, k);
+        if (is_spatial_type(ka.cfg.prior_type[k]))
+        {
+            sa.sw_rhs0[k * NP + pos] = base;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                sa.sw_sig[((size_t)si * P + j) * NP + pos] = st.Sig[tri(k, j)];
+            si++;
+        }
+        else
+            sa.sw_rhs0[k * NP + pos] = theta_rhs(base, st.pprec[k], st.pm[k]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+        sa.sw_npos[a * NP + pos] = live1[a] ? sa.pos_of[n1[a]] : -1;
+    sa.sw_alive[pos] = 1;
+    // the posterior's new covariance and the priors are final here (the state's means stay the OLD ones
+    // until the noise kernel has seen them: F "before" is evaluated with them)
+    {
+        double *p = sa.state + v;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            p[(size_t)(L::PM + i) * V] = st.pm[i];
+            p[(size_t)(L::PPREC + i) * V] = st.pprec[i];
+        }
+#pragma unroll
+        for (int i = 0; i < L::PT; i++)
+            p[(size_t)(L::SIG + i) * V] = st.Sig[i];
+        p[(size_t)L::LOGDET * V] = st.logdetLam;
+    }
+}
+
+// What a sweep step needs of one voxel besides its neighbours' means: read ahead of the level barrier.
+template <int P>
+struct SweepRecord
+{
+    int alive;
+    int np[6];
+    double rhs0[P];
+    double pprec[P], q[P], rec[P]; // per spatial parameter (at most P of them)
+    double sig[P][P];              // [spatial parameter][j]
+    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
+    {
+        const size_t NP = (size_t)sa.n_pos;
+        alive = (pos >= 0) ? sa.sw_alive[pos] : 0;
+        if (!alive)
+            return;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+            np[a] = sa.sw_npos[a * NP + pos];
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            rhs0[j] = sa.sw_rhs0[j * NP + pos];
+#pragma unroll
+        for (int s = 0; s < P; s++)
+            if (s < ns)
+            {
+                pprec[s] = sa.sw_pprec[s * NP + pos];
+                q[s] = sa.sw_q[s * NP + pos];
+                rec[s] = sa.sw_rec[s * NP + pos];
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    sig[s][j] = sa.sw_sig[((size_t)s * P + j) * NP + pos];
+            }
+    }
+};
+
+// The step of (up to) NV voxels of one level together: prior means of the spatial parameters from the
+// neighbours' CURRENT means, then eq (20). level_begin = first position of the level: neighbours before it
+// were (or are being) updated in THIS sweep and are waited for - their granules must carry this sweep's
+// serial number -, neighbours after it still hold the previous sweep's means. All voxels of the call poll
+// in the same loop: one memory round trip per attempt, not one per voxel.
+template <int P, int NV>
+__device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRecord<P> (&r)[NV], const int (&pos)[NV], int ns,
+    int level_begin)
+{
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+    double rhs[NV][P];
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            rhs[i][j] = r[i].rhs0[j];
+#pragma unroll
+    for (int s = 0; s < P; s++)
+        if (s < ns)
+        {
+            const unsigned long long *g = sa.sw_gran + (size_t)s * NP * 2;
+            unsigned long long lo[NV][6], hi[NV][6];
+            int spins = 0;
+            for (;;)
+            {
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+                    {
+                        const size_t at = (size_t)((!r[i].alive || r[i].np[a] < 0) ? 0 : r[i].np[a]) * 2;
+                        lo[i][a] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[i][a] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                bool ready = true;
+#pragma unroll
+                for (int i = 0; i < NV; i++)
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+                        if (r[i].alive && r[i].np[a] >= 0 && r[i].np[a] < level_begin)
+                            ready = ready && ((lo[i][a] >> 32) == serial) && ((hi[i][a] >> 32) == serial);
+#ifdef FVB_SWEEP_STATS
+                atomicAdd((unsigned long long *)(sa.sw_flags + 4), 1ull); // poll attempts
+#endif
+                if (ready)
+                    break;
+                if (++spins > (1 << 22)) // never (every wave of the grid is resident); the run is repeated
+                {
+                    sa.sw_flags[0] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+            {
+                if (!r[i].alive)
+                    continue;
+                double contrib = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+                    if (r[i].np[a] >= 0)
+                        contrib += __longlong_as_double((long long)((hi[i][a] << 32) | (lo[i][a] & 0xffffffffull)));
+                const double spatial_mean = contrib * r[i].rec[s];
+                const double pm = r[i].q[s] * spatial_mean;
+                sa.sw_pm[s * NP + pos[i]] = pm;
+                const int k = sa.spatial_param[s];
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    if (j == k)
+                        rhs[i][j] = theta_rhs(rhs[i][j], r[i].pprec[s], pm);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+    {
+        if (!r[i].alive)
+            continue;
+#pragma unroll
+        for (int s = 0; s < P; s++)
+            if (s < ns)
+            {
+                double m = 0;
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    m = __builtin_fma(r[i].sig[s][j], rhs[i][j], m);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+                unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos[i]) * 2;
+                __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sa.sw_x[s * NP + pos[i]] = m; // for the kernels after this one
+            }
+    }
+}
+
+// The ordered part: ONE launch, gridDim.x workgroups of 256 lanes, every wave resident. Each lane walks the
+// levels in order with (up to) two voxels per level; nothing synchronises the grid: a voxel waits for exactly
+// the neighbours it needs - those of the previous level - by polling their means, which travel as 8-byte
+// granules {half of the double, serial number of the sweep} written and read with device-scope (sc1)
+// accesses: a granule is valid or not by itself, no flag, no fence, no barrier (MI355X_MICROARCH.md
+// "handoff-1to1": ~1 us per hop). Every wave advances through the levels in the same order and level 0 waits
+// for nobody, so the grid cannot lock up as long as it is resident (64 workgroups at most on 256 CUs); a poll
+// that does not end raises sw_flags[0] and the run is repeated with the per-level launches. The records of the
+// NEXT level's voxels (everything that does not wait for a neighbour) are requested as soon as the current
+// level's results have left; a level with more than 512 x gridDim.x voxels takes the rest one by one.
+template <int P>
+__global__ __launch_bounds__(256) void vb_spatial_sweep_kernel(const SpatialArgs *__restrict__ sap)
+{
+    const SpatialArgs &sa = *sap;
+    const int ns = sa.n_spatial;
+    const int stride = gridDim.x * 256;
+    const int lane0 = blockIdx.x * 256 + threadIdx.x;
+    SweepRecord<P> r[2];
+    int begin = sa.sw_level_pos[0], count = sa.sw_level_count[0];
+    r[0].load(sa, lane0 < count ? begin + lane0 : -1, ns);
+    r[1].load(sa, lane0 + stride < count ? begin + lane0 + stride : -1, ns);
+    for (int l = 0; l < sa.n_levels; l++)
+    {
+        const int pos[2] = { begin + lane0, begin + lane0 + stride };
+#ifdef FVB_SWEEP_STATS
+        const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
+#endif
+        sweep_step<P, 2>(sa, r, pos, ns, begin);
+#ifdef FVB_SWEEP_STATS
+        if (lane0 == 0)
+            atomicAdd((unsigned long long *)(sa.sw_flags + 6), __builtin_amdgcn_s_memrealtime() - t_a); // 100 MHz ticks in steps, lane 0
+#endif
+        for (int i = lane0 + 2 * stride; i < count; i += stride) // (huge levels only)
+        {
+            SweepRecord<P> one[1];
+            one[0].load(sa, begin + i, ns);
+            const int p1[1] = { begin + i };
+            sweep_step<P, 1>(sa, one, p1, ns, begin);
+        }
+        // The next level's records, requested AFTER this level's results have left: their latency overlaps the
+        // wait for the next level's neighbours (loads return in order: asked for earlier, they would sit in
+        // front of the polls).
+        if (l + 1 < sa.n_levels)
+        {
+            begin = sa.sw_level_pos[l + 1];
+            count = sa.sw_level_count[l + 1];
+            r[0].load(sa, lane0 < count ? begin + lane0 : -1, ns);
+            r[1].load(sa, lane0 + stride < count ? begin + lane0 + stride : -1, ns);
+        }
+    }
+}
+
 // ---- second sweep: UpdateNoise, ReCentre, F (inference_vb.cc:674-722), all voxels -------------
-template <class Model, int P, bool NEEDF>
+template <class Model, int P, bool NEEDF, bool FAST = false>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(const SpatialArgs sa)
 {
     const KernelArgs &ka = sa.ka;
@@ -539,6 +957,61 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
     VoxelState<P> st;
     Moments<P> mo;
     sp_load<P>(sa, v, st, mo);
+    if (FAST)
+    {
+        // The rest of UpdateTheta after the split first sweep: the state holds this iteration's priors,
+        // Sigma and log|det Lambda| (prep) and still the OLD means; the sweep left the spatial parameters'
+        // new means and prior means at the voxel's level-major position.
+        typedef SpLayout<P> L;
+        const size_t V = (size_t)ka.cfg.n_voxels, NP = (size_t)sa.n_pos;
+        const int pos = sa.pos_of[v];
+        if (!sa.sw_alive[pos])
+            return; // failed in prep: the run is being repeated anyway
+        const double phibar = st.b * st.c;
+        double m_new[P], rhs[P];
+        int si = 0;
+#pragma unroll
+        for (int k = 0; k < P; k++)
+            if (is_spatial_type(ka.cfg.prior_type[k]))
+            {
+                st.pm[k] = sa.sw_pm[si * NP + pos];
+                m_new[k] = sa.sw_x[si * NP + pos];
+                if (NEEDF) // F "before" (:643) would see this prior mean next to the old posterior mean
+                {
+                    const double dm = st.m[k] - st.pm[k];
+                    if (!is_finite(dm * st.pprec[k] * dm))
+                        sa.sw_flags[0] = 1;
+                }
+                si++;
+            }
+#pragma unroll
+        for (int k = 0; k < P; k++)
+            rhs[k] = theta_rhs(theta_rhs_base<P>(phibar, mo, k), st.pprec[k], st.pm[k]);
+#pragma unroll
+        for (int k = 0; k < P; k++)
+            if (!is_spatial_type(ka.cfg.prior_type[k]))
+                m_new[k] = theta_mean<P>(st.Sig, rhs, k);
+#pragma unroll
+        for (int k = 0; k < P; k++)
+            st.m[k] = m_new[k];
+        if (NEEDF) // F "theta" (:651): its value is overwritten, its failure would have stopped the voxel
+        {
+            double kk0, tr0, F0;
+            bool lost0, finite0 = true;
+            st.precValid = true; // log|det Lambda| came with Sigma
+            residual_terms<P>(st, mo, 0.0, kk0, tr0, lost0);
+            if (!calc_free_energy<P>(ka, st, kk0, tr0, 0.0, F0, finite0) || !finite0)
+                sa.sw_flags[0] = 1;
+            st.precValid = false;
+        }
+        double *p = sa.state + v;
+#pragma unroll
+        for (int k = 0; k < P; k++)
+        {
+            p[(size_t)(L::M + k) * V] = st.m[k];
+            p[(size_t)(L::PM + k) * V] = st.pm[k];
+        }
+    }
     double kk, trSA;
     residual_and_trace<Model, P>(ka, ma, v, st, mo, kk, trSA);
     update_noise<P>(ka, st, kk, trSA);
@@ -604,6 +1077,8 @@ __global__ __launch_bounds__(256) void vb_spatial_pack_kernel(const SpatialArgs 
 // Kernel table for one (model, P)
 typedef void (*SpatialKernelFn)(const SpatialArgs);
 typedef void (*SpatialThetaFn)(const SpatialArgs *, int, int, int);
+typedef void (*SpatialPrepFn)(const SpatialArgs *, int);
+typedef void (*SpatialSweepFn)(const SpatialArgs *);
 struct SpatialKernels
 {
     SpatialKernelFn setup, ak_partial, ak_reduce, ak_final;
@@ -611,6 +1086,10 @@ struct SpatialKernels
     SpatialKernelFn noise, pack;
     int state_rows;
     const char *name;
+    // the split first sweep
+    SpatialPrepFn prep;
+    SpatialSweepFn sweep;
+    SpatialKernelFn noise_fast;
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
@@ -624,6 +1103,10 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
                    : (SpatialThetaFn)vb_spatial_theta_kernel<PP, false>,                                     \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true>                           \
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false>,                         \
-            vb_spatial_pack_kernel<PP>, SpLayout<PP>::ROWS, "spatial<" TAG "," #PP ">" };
+            vb_spatial_pack_kernel<PP>, SpLayout<PP>::ROWS, "spatial<" TAG "," #PP ">",                      \
+            need_f ? (SpatialPrepFn)vb_spatial_prep_kernel<PP, true> : (SpatialPrepFn)vb_spatial_prep_kernel<PP, false>, \
+            vb_spatial_sweep_kernel<PP>,                                                                     \
+            need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true, true>                     \
+                   : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true> };
 
 } // namespace fvb

@@ -321,6 +321,12 @@ struct fvb_spatial_run
     std::vector<int32_t> level_begin;
     DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums;
     double t_geometry_ms = 0, t_neighbours_ms = 0;
+    // the split first sweep (vb_spatial.h): whole-volume runs with first-neighbour priors (types M, m)
+    bool allow_fast = false, fast = false;
+    std::vector<int32_t> level_begin_counts; // voxels per level
+    DevMem d_pos_of, d_level_pos, d_level_count, d_sw_f64, d_sw_i32, d_sw_sync, d_sw_gran;
+    int sweep_fast(int it);
+    int fast_failed(bool &failed);
 
     int open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out, hipStream_t stream_);
     int ak_sums(double *host_sums);
@@ -486,6 +492,35 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     t_geometry_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 
+    // ---- level-major numbering for the split first sweep ----
+    int n_spatial = 0, spatial_param[FVB_MAX_PARAMS] = { 0 };
+    for (int kk = 0; kk < P; kk++)
+        if (cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M)
+            spatial_param[n_spatial++] = kk;
+    fast = allow_fast && has_spatial && !second_neighbours && owned_begin == 0 && owned_end == V && n_owned > 0
+        && !getenv("FVB_SPATIAL_PER_LEVEL");
+    std::vector<int32_t> pos_of, level_pos, level_count;
+    int n_pos = 0;
+    if (fast)
+    {
+        // every level starts on a multiple of 16 positions: a wave's 64 consecutive doubles are whole 128-byte lines
+        const size_t nl = level_begin.size() - 1;
+        level_pos.resize(nl);
+        level_count.resize(nl);
+        pos_of.assign((size_t)V, 0);
+        for (size_t l = 0; l < nl; l++)
+        {
+            n_pos = (n_pos + 15) / 16 * 16;
+            level_pos[l] = n_pos;
+            level_count[l] = level_begin[l + 1] - level_begin[l];
+            for (int i = level_begin[l]; i < level_begin[l + 1]; i++)
+                pos_of[(size_t)order[i]] = n_pos + (i - level_begin[l]);
+            n_pos += level_count[l];
+        }
+        n_pos = (n_pos + 15) / 16 * 16;
+        level_begin_counts = level_count;
+    }
+
     // ---- device memory ----
     const int n_blocks = std::max(1, std::min(1024, (n_owned + 255) / 256));
     FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V));
@@ -528,6 +563,48 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     sa.owned_begin = owned_begin;
     sa.owned_end = owned_end;
     sa.n_voxels_global = sp.n_voxels_global > 0 ? sp.n_voxels_global : V;
+    if (fast)
+    {
+        const size_t NP = (size_t)n_pos, ns = (size_t)n_spatial;
+        FVB_HIP_CHECK(d_pos_of.alloc(sizeof(int32_t) * (size_t)V));
+        FVB_HIP_CHECK(d_level_pos.alloc(sizeof(int32_t) * level_pos.size()));
+        FVB_HIP_CHECK(d_level_count.alloc(sizeof(int32_t) * level_count.size()));
+        FVB_HIP_CHECK(hipMemcpyAsync(d_pos_of.p, pos_of.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipMemcpyAsync(d_level_pos.p, level_pos.data(), sizeof(int32_t) * level_pos.size(), hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipMemcpyAsync(d_level_count.p, level_count.data(), sizeof(int32_t) * level_count.size(), hipMemcpyHostToDevice, stream));
+        // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]
+        const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P) * NP;
+        FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64));
+        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * 7 * NP)); // npos [6][NP], alive [NP]
+        FVB_HIP_CHECK(d_sw_sync.alloc(64));                      // counter, flags[2]
+        FVB_HIP_CHECK(d_sw_gran.alloc(sizeof(unsigned long long) * 2 * ns * NP));
+        FVB_HIP_CHECK(hipMemsetAsync(d_sw_gran.p, 0, sizeof(unsigned long long) * 2 * ns * NP, stream));
+        sa.sw_gran = (unsigned long long *)d_sw_gran.p;
+        sa.sw_serial = 0;
+        FVB_HIP_CHECK(hipMemsetAsync(d_sw_i32.p, 0, sizeof(int32_t) * 7 * NP, stream));
+        FVB_HIP_CHECK(hipMemsetAsync(d_sw_f64.p, 0, sizeof(double) * n_f64, stream));
+        FVB_HIP_CHECK(hipMemsetAsync(d_sw_sync.p, 0, 64, stream));
+        double *f = (double *)d_sw_f64.p;
+        sa.sw_x = f;
+        sa.sw_pm = f + ns * NP;
+        sa.sw_pprec = f + 2 * ns * NP;
+        sa.sw_q = f + 3 * ns * NP;
+        sa.sw_rec = f + 4 * ns * NP;
+        sa.sw_rhs0 = f + 5 * ns * NP;
+        sa.sw_sig = f + (5 * ns + (size_t)P) * NP;
+        sa.sw_npos = (int32_t *)d_sw_i32.p;
+        sa.sw_alive = (int32_t *)d_sw_i32.p + 6 * NP;
+        sa.sw_counter = (uint32_t *)d_sw_sync.p;
+        sa.sw_flags = (int32_t *)d_sw_sync.p + 4;
+        sa.pos_of = (const int32_t *)d_pos_of.p;
+        sa.n_pos = n_pos;
+        sa.n_spatial = n_spatial;
+        for (int i = 0; i < n_spatial; i++)
+            sa.spatial_param[i] = spatial_param[i];
+        sa.sw_level_pos = (const int32_t *)d_level_pos.p;
+        sa.sw_level_count = (const int32_t *)d_level_count.p;
+        sa.n_levels = (int32_t)level_pos.size();
+    }
     // number of unmasked timepoints: phi_index is a device pointer here, read it back once
     int n_unmasked = cfg.n_times;
     if (cfg.phi_index)
@@ -592,6 +669,42 @@ int fvb_spatial_run::sweep(int it)
     return 0;
 }
 
+// One iteration's first and second sweep with the split first sweep (see vb_spatial.h)
+int fvb_spatial_run::sweep_fast(int it)
+{
+    sa.it = it;
+    sa.sw_serial++; // (this sweep's number; the kernels read it from the device copy of the arguments)
+    SpatialArgs *sap = (SpatialArgs *)d_sa.p;
+    FVB_HIP_CHECK(hipMemcpyAsync(&sap->sw_serial, &sa.sw_serial, sizeof(sa.sw_serial), hipMemcpyHostToDevice, stream));
+    const int n_owned = owned_end - owned_begin;
+    hipLaunchKernelGGL(k.prep, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sap, it);
+    // few workgroups, all resident at once on any MI355X (256 CUs): the level barrier is a counter
+    const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
+    const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane
+    hipLaunchKernelGGL(k.sweep, dim3(nwg), dim3(256), 0, stream, sap);
+    hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fvb_spatial_run::fast_failed(bool &failed)
+{
+    failed = false;
+    if (!fast)
+        return 0;
+    int32_t flag = 0;
+    FVB_HIP_CHECK(hipMemcpyAsync(&flag, sa.sw_flags, sizeof(flag), hipMemcpyDeviceToHost, stream));
+    FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    failed = flag != 0;
+    if (getenv("FVB_SWEEP_STATS"))
+    {
+        unsigned long long st[2] = { 0, 0 };
+        FVB_HIP_CHECK(hipMemcpy(st, sa.sw_flags + 4, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[fvb spatial] sweep statistics: %llu poll attempts by all lanes, %.3f ms inside the steps (lane 0, all sweeps)\n", st[0], st[1] / 1e5);
+    }
+    return 0;
+}
+
 int fvb_spatial_run::copy_means(int v_begin, int v_count, double *host_means, int32_t *host_status, bool to_device)
 {
     if (v_begin < 0 || v_count < 0 || v_begin + v_count > V)
@@ -632,7 +745,7 @@ int fvb_spatial_run::finish()
 namespace
 {
 int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data, const fvb_outputs *d_out,
-    hipStream_t stream, void (*progress_cb)(int, int))
+    hipStream_t stream, void (*progress_cb)(int, int), bool allow_fast = true)
 {
     const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -641,6 +754,7 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
     };
     const auto t_start = now();
     fvb_spatial_run run;
+    run.allow_fast = allow_fast;
     int rc = run.open(cfg, sp, d_data, d_out, stream);
     if (rc)
         return rc;
@@ -654,8 +768,20 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
             if ((rc = run.ak_sums(nullptr)) != 0 || (rc = run.set_ak_sums(nullptr)) != 0)
                 return rc;
         }
-        if ((rc = run.sweep(it)) != 0)
+        if ((rc = (run.fast ? run.sweep_fast(it) : run.sweep(it))) != 0)
             return rc;
+    }
+    bool failed = false;
+    if ((rc = run.fast_failed(failed)) != 0)
+        return rc;
+    if (failed)
+    {
+        // a voxel failed DURING a first sweep (or the sweep's barrier gave up): the split sweep does not
+        // reproduce what that does to the voxels after it. Nothing has been written to the outputs that the
+        // repeat does not overwrite: do the run again with the per-level launches.
+        if (timing || getenv("FVB_SPATIAL_VERBOSE"))
+            fprintf(stderr, "[fvb spatial] split first sweep abandoned, repeating the run with per-level launches\n");
+        return run_spatial(cfg, sp, d_data, d_out, stream, nullptr, false);
     }
     const auto t_enq = now();
     if ((rc = run.finish()) != 0)

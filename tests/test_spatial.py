@@ -372,3 +372,51 @@ def test_level_order_built_by_several_host_threads_is_the_same(monkeypatch):
         monkeypatch.setenv("FVB_SPATIAL_HOST_THREADS", n)
         many = hiplib.run_spatial_host(h, sp, y)
         assert np.array_equal(one["mvn"], many["mvn"]) and np.array_equal(one["status"], many["status"])
+
+
+@gpu
+@pytest.mark.parametrize("case", ["M exp", "m exp masked", "two spatial + ARD + F", "M + image prior, dims 2, speed", "failing voxel with F",
+                                  "NaN cascade without F"])
+def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch):
+    """Whole-volume runs with first-neighbour priors (types M, m) take the split first sweep (vb_spatial.h:
+    one parallel launch for everything that does not wait for a neighbour, ONE persistent launch that walks
+    the levels for the spatial parameters' means, the rest inside the second sweep's kernel); the per-level
+    launches stay for types P / p, for slabs, and as the fallback when a voxel fails during a sweep.
+    Both evaluate eq (19)-(20) with the same operation sequence: every output must be identical."""
+    rng = np.random.default_rng(41)
+    sp_kw = {}
+    if case == "M exp":
+        mask, coords = masked_volume((13, 11, 9), seed=31, keep=1.0)
+        _, y = smooth_exp_data(coords, 40, 0.04, seed=32)
+        h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 40, num_exps=1, dt=0.04, max_iterations=7, param_overrides={"amp1": dict(type="M")})
+    elif case == "m exp masked":
+        mask, coords = masked_volume((12, 10, 8), seed=33, keep=0.8)
+        _, y = smooth_exp_data(coords, 40, 0.04, seed=34)
+        h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 40, num_exps=1, dt=0.04, max_iterations=6, param_overrides={"r1": dict(type="m")})
+    elif case in ("two spatial + ARD + F", "M + image prior, dims 2, speed"):
+        mask, coords = masked_volume((10, 8, 6), seed=5)
+        V = coords.shape[1]
+        t = np.arange(1, 21.0)
+        c0 = 2.0 + np.sin(coords[0] / 2.0)
+        y = c0[None, :] + 0.3 * t[:, None] + 0.01 * t[:, None] ** 2 + rng.normal(0, 0.2, (20, V))
+        if case.startswith("two"):
+            h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6, need_f=True,
+                                   param_overrides={"c0": dict(type="M"), "c1": dict(type="A"), "c2": dict(type="m")})
+            sp_kw = dict(update_first_iter=True)
+        else:
+            img = rng.normal(0.3, 0.05, V)
+            h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6,
+                                   param_overrides={"c0": dict(type="M"), "c1": dict(type="I", prec=4.0)}, image_priors={"c1": img})
+            sp_kw = dict(spatial_dims=2, spatial_speed=1.5, q1=5.0, q2=2.0)
+    elif case == "failing voxel with F":
+        h, sp0, y, bad = failing_voxel_problem("M")
+        coords = sp0.coords
+    else:
+        h, sp0, y, bad = failing_voxel_problem("M", need_f=False)
+        coords = sp0.coords
+    sp = vbabi.SpatialHolder(coords, **sp_kw)
+    split = hiplib.run_spatial_host(h, sp, y)
+    monkeypatch.setenv("FVB_SPATIAL_PER_LEVEL", "1")
+    per_level = hiplib.run_spatial_host(h, sp, y)
+    for k in ("mvn", "status", "iterations", "free_energy"):
+        assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, k)
