@@ -307,22 +307,23 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
     }
 }
 
-// this slab's sums: the per-block partials added in block order (deterministic)
+// this slab's sums: the per-block partials added in a fixed order (deterministic): one 64-lane wave per
+// (parameter, sum), lane l adds blocks l, l + 64, ... in order, then a butterfly over the lanes
 template <int P>
-__global__ void vb_spatial_ak_reduce_kernel(const SpatialArgs sa)
+__global__ __launch_bounds__(64) void vb_spatial_ak_reduce_kernel(const SpatialArgs sa)
 {
-    const int k = threadIdx.x;
+    const int k = blockIdx.x >> 1, which = blockIdx.x & 1;
     if (k >= P)
         return;
-    double trace_term = 0, term2 = 0;
+    double acc = 0;
     if (is_spatial_type(sa.ka.cfg.prior_type[k]))
-        for (int b = 0; b < sa.n_blocks; b++)
-        {
-            trace_term += sa.partials[((size_t)b * P + k) * 2 + 0];
-            term2 += sa.partials[((size_t)b * P + k) * 2 + 1];
-        }
-    sa.ak_sums[2 * k + 0] = trace_term;
-    sa.ak_sums[2 * k + 1] = term2;
+        for (int b = threadIdx.x; b < sa.n_blocks; b += 64)
+            acc += sa.partials[((size_t)b * P + k) * 2 + which];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        acc += __shfl_xor(acc, off);
+    if (threadIdx.x == 0)
+        sa.ak_sums[2 * k + which] = acc;
 }
 
 template <int P>
@@ -578,20 +579,20 @@ __device__ __forceinline__ void store_sc1(double *p, double x)
 
 // A voxel that drops out in prep (the run is going to be repeated): hand its old means to the sweep with THIS
 // sweep's serial number, so that no neighbour waits for it.
-__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos)
+__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, uint32_t serial)
 {
     const size_t NP = (size_t)sa.n_pos;
     for (int s = 0; s < sa.n_spatial; s++)
     {
         unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
-        const unsigned long long now = (unsigned long long)sa.sw_serial << 32;
+        const unsigned long long now = (unsigned long long)serial << 32;
         g[0] = now | (g[0] & 0xffffffffull);
         g[1] = now | (g[1] & 0xffffffffull);
     }
 }
 
 template <int P, bool NEEDF>
-__global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *__restrict__ sap, int it)
+__global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *__restrict__ sap, int it, uint32_t serial)
 {
     typedef SpLayout<P> L;
     const SpatialArgs &sa = *sap;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
                 sa.sw_x[si * NP + pos] = st.m[k];
                 // the mean as the sweep's neighbours read it: a value of the PREVIOUS sweep
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(st.m[k]);
-                const unsigned long long old = (unsigned long long)(sa.sw_serial - 1) << 32;
+                const unsigned long long old = (unsigned long long)(serial - 1) << 32;
                 sa.sw_gran[((size_t)si * NP + pos) * 2] = old | (bits & 0xffffffffull);
                 sa.sw_gran[((size_t)si * NP + pos) * 2 + 1] = old | (bits >> 32);
             }
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         {
             sa.sw_flags[0] = 1;
             sa.sw_alive[pos] = 0;
-            sweep_release(sa, pos);
+            sweep_release(sa, pos, serial);
             return;
         }
         (void)sk;
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     {
         sa.sw_flags[0] = 1; // this voxel fails in the first sweep: not modelled here
         sa.sw_alive[pos] = 0;
-        sweep_release(sa, pos);
+        sweep_release(sa, pos, serial);
         return;
     }
     si = 0;
@@ -758,20 +759,22 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
 }
 
 // What a sweep step needs of one voxel besides its neighbours' means: read ahead of the level barrier.
-template <int P>
+template <int P, int NS>
 struct SweepRecord
 {
     int alive;
     int np[6];
     double rhs0[P];
-    double pprec[P], q[P], rec[P]; // per spatial parameter (at most P of them)
-    double sig[P][P];              // [spatial parameter][j]
+    double pprec[NS], q[NS], rec[NS]; // per spatial parameter (NS = the most the kernel is built for)
+    double sig[NS][P];                // [spatial parameter][j]
     __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
     {
+        // every load unconditional (a lane without a voxel reads position 0 and ignores it): a load that had to
+        // wait for the `alive` word first would cost the step a second memory round trip
         const size_t NP = (size_t)sa.n_pos;
-        alive = (pos >= 0) ? sa.sw_alive[pos] : 0;
-        if (!alive)
-            return;
+        const bool have = pos >= 0;
+        pos = have ? pos : 0;
+        const int alive_word = sa.sw_alive[pos];
 #pragma unroll
         for (int a = 0; a < 6; a++)
             np[a] = sa.sw_npos[a * NP + pos];
@@ -779,7 +782,7 @@ struct SweepRecord
         for (int j = 0; j < P; j++)
             rhs0[j] = sa.sw_rhs0[j * NP + pos];
 #pragma unroll
-        for (int s = 0; s < P; s++)
+        for (int s = 0; s < NS; s++)
             if (s < ns)
             {
                 pprec[s] = sa.sw_pprec[s * NP + pos];
@@ -789,6 +792,7 @@ struct SweepRecord
                 for (int j = 0; j < P; j++)
                     sig[s][j] = sa.sw_sig[((size_t)s * P + j) * NP + pos];
             }
+        alive = have ? alive_word : 0;
     }
 };
 
@@ -797,9 +801,13 @@ struct SweepRecord
 // were (or are being) updated in THIS sweep and are waited for - their granules must carry this sweep's
 // serial number -, neighbours after it still hold the previous sweep's means. All voxels of the call poll
 // in the same loop: one memory round trip per attempt, not one per voxel.
-template <int P, int NV>
-__device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRecord<P> (&r)[NV], const int (&pos)[NV], int ns,
-    int level_begin)
+// next / next_pos: the records to fetch for the following level (or NULL). They are requested right after the
+// first poll's loads have been issued and before their results are used: younger than the poll's loads, they
+// are not waited for with them (s_waitcnt vmcnt(N) leaves the N youngest outstanding), and by the next level's
+// poll they are old enough to be back.
+template <int P, int NS, int NV>
+__device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRecord<P, NS> (&r)[NV], const int (&pos)[NV], int ns,
+    int level_begin, SweepRecord<P, NS> *next = nullptr, const int *next_pos = nullptr)
 {
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
@@ -810,7 +818,7 @@ __device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRec
         for (int j = 0; j < P; j++)
             rhs[i][j] = r[i].rhs0[j];
 #pragma unroll
-    for (int s = 0; s < P; s++)
+    for (int s = 0; s < NS; s++)
         if (s < ns)
         {
             const unsigned long long *g = sa.sw_gran + (size_t)s * NP * 2;
@@ -827,6 +835,12 @@ __device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRec
                         lo[i][a] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         hi[i][a] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                if (next && s == 0 && spins == 0)
+                {
+#pragma unroll
+                    for (int i = 0; i < NV; i++)
+                        next[i].load(sa, next_pos[i], ns);
+                }
                 bool ready = true;
 #pragma unroll
                 for (int i = 0; i < NV; i++)
@@ -872,7 +886,7 @@ __device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRec
         if (!r[i].alive)
             continue;
 #pragma unroll
-        for (int s = 0; s < P; s++)
+        for (int s = 0; s < NS; s++)
             if (s < ns)
             {
                 double m = 0;
@@ -898,45 +912,41 @@ __device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRec
 // that does not end raises sw_flags[0] and the run is repeated with the per-level launches. The records of the
 // NEXT level's voxels (everything that does not wait for a neighbour) are requested as soon as the current
 // level's results have left; a level with more than 512 x gridDim.x voxels takes the rest one by one.
-template <int P>
-__global__ __launch_bounds__(256) void vb_spatial_sweep_kernel(const SpatialArgs *__restrict__ sap)
+template <int P, int NS>
+__global__ __launch_bounds__(256) void vb_spatial_sweep_kernel(const SpatialArgs sa)
 {
-    const SpatialArgs &sa = *sap;
     const int ns = sa.n_spatial;
+    const int nl = sa.n_levels;
     const int stride = gridDim.x * 256;
     const int lane0 = blockIdx.x * 256 + threadIdx.x;
-    SweepRecord<P> r[2];
-    int begin = sa.sw_level_pos[0], count = sa.sw_level_count[0];
+    extern __shared__ int s_tab[]; // [2][n_levels]: first position, voxel count (no dependent global load per level)
+    for (int i = threadIdx.x; i < nl; i += 256)
+    {
+        s_tab[i] = sa.sw_level_pos[i];
+        s_tab[nl + i] = sa.sw_level_count[i];
+    }
+    __syncthreads();
+    SweepRecord<P, NS> r[2], nx[2];
+    int begin = s_tab[0], count = s_tab[nl];
     r[0].load(sa, lane0 < count ? begin + lane0 : -1, ns);
     r[1].load(sa, lane0 + stride < count ? begin + lane0 + stride : -1, ns);
-    for (int l = 0; l < sa.n_levels; l++)
+    for (int l = 0; l < nl; l++)
     {
         const int pos[2] = { begin + lane0, begin + lane0 + stride };
-#ifdef FVB_SWEEP_STATS
-        const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
-#endif
-        sweep_step<P, 2>(sa, r, pos, ns, begin);
-#ifdef FVB_SWEEP_STATS
-        if (lane0 == 0)
-            atomicAdd((unsigned long long *)(sa.sw_flags + 6), __builtin_amdgcn_s_memrealtime() - t_a); // 100 MHz ticks in steps, lane 0
-#endif
+        const int nbegin = (l + 1 < nl) ? s_tab[l + 1] : 0, ncount = (l + 1 < nl) ? s_tab[nl + l + 1] : 0;
+        const int npos[2] = { lane0 < ncount ? nbegin + lane0 : -1, lane0 + stride < ncount ? nbegin + lane0 + stride : -1 };
+        sweep_step<P, NS, 2>(sa, r, pos, ns, begin, nx, npos);
         for (int i = lane0 + 2 * stride; i < count; i += stride) // (huge levels only)
         {
-            SweepRecord<P> one[1];
+            SweepRecord<P, NS> one[1];
             one[0].load(sa, begin + i, ns);
             const int p1[1] = { begin + i };
-            sweep_step<P, 1>(sa, one, p1, ns, begin);
+            sweep_step<P, NS, 1>(sa, one, p1, ns, begin);
         }
-        // The next level's records, requested AFTER this level's results have left: their latency overlaps the
-        // wait for the next level's neighbours (loads return in order: asked for earlier, they would sit in
-        // front of the polls).
-        if (l + 1 < sa.n_levels)
-        {
-            begin = sa.sw_level_pos[l + 1];
-            count = sa.sw_level_count[l + 1];
-            r[0].load(sa, lane0 < count ? begin + lane0 : -1, ns);
-            r[1].load(sa, lane0 + stride < count ? begin + lane0 + stride : -1, ns);
-        }
+        r[0] = nx[0];
+        r[1] = nx[1];
+        begin = nbegin;
+        count = ncount;
     }
 }
 
@@ -1077,8 +1087,8 @@ __global__ __launch_bounds__(256) void vb_spatial_pack_kernel(const SpatialArgs 
 // Kernel table for one (model, P)
 typedef void (*SpatialKernelFn)(const SpatialArgs);
 typedef void (*SpatialThetaFn)(const SpatialArgs *, int, int, int);
-typedef void (*SpatialPrepFn)(const SpatialArgs *, int);
-typedef void (*SpatialSweepFn)(const SpatialArgs *);
+typedef void (*SpatialPrepFn)(const SpatialArgs *, int, uint32_t);
+typedef void (*SpatialSweepFn)(const SpatialArgs);
 struct SpatialKernels
 {
     SpatialKernelFn setup, ak_partial, ak_reduce, ak_final;
@@ -1088,7 +1098,7 @@ struct SpatialKernels
     const char *name;
     // the split first sweep
     SpatialPrepFn prep;
-    SpatialSweepFn sweep;
+    SpatialSweepFn sweep[3]; // built for 1, 2 and up to P spatial parameters (what a lane keeps in registers grows with it)
     SpatialKernelFn noise_fast;
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
@@ -1105,7 +1115,8 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false>,                         \
             vb_spatial_pack_kernel<PP>, SpLayout<PP>::ROWS, "spatial<" TAG "," #PP ">",                      \
             need_f ? (SpatialPrepFn)vb_spatial_prep_kernel<PP, true> : (SpatialPrepFn)vb_spatial_prep_kernel<PP, false>, \
-            vb_spatial_sweep_kernel<PP>,                                                                     \
+            { vb_spatial_sweep_kernel<PP, 1>, vb_spatial_sweep_kernel<PP, (PP < 2 ? PP : 2)>,                  \
+                vb_spatial_sweep_kernel<PP, PP> },                                                           \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true, true>                     \
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true> };
 

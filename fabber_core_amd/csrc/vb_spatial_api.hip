@@ -498,7 +498,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         if (cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M)
             spatial_param[n_spatial++] = kk;
     fast = allow_fast && has_spatial && !second_neighbours && owned_begin == 0 && owned_end == V && n_owned > 0
-        && !getenv("FVB_SPATIAL_PER_LEVEL");
+        && !getenv("FVB_SPATIAL_PER_LEVEL") && level_begin.size() <= 6000; // (the sweep keeps the level table in LDS)
     std::vector<int32_t> pos_of, level_pos, level_count;
     int n_pos = 0;
     if (fast)
@@ -632,7 +632,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
 int fvb_spatial_run::ak_sums(double *host_sums)
 {
     hipLaunchKernelGGL(k.ak_partial, dim3(sa.n_blocks), dim3(256), 0, stream, sa);
-    hipLaunchKernelGGL(k.ak_reduce, dim3(1), dim3(64), 0, stream, sa);
+    hipLaunchKernelGGL(k.ak_reduce, dim3(2 * P), dim3(64), 0, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     if (host_sums)
     {
@@ -673,15 +673,13 @@ int fvb_spatial_run::sweep(int it)
 int fvb_spatial_run::sweep_fast(int it)
 {
     sa.it = it;
-    sa.sw_serial++; // (this sweep's number; the kernels read it from the device copy of the arguments)
-    SpatialArgs *sap = (SpatialArgs *)d_sa.p;
-    FVB_HIP_CHECK(hipMemcpyAsync(&sap->sw_serial, &sa.sw_serial, sizeof(sa.sw_serial), hipMemcpyHostToDevice, stream));
+    sa.sw_serial++; // this sweep's number
     const int n_owned = owned_end - owned_begin;
-    hipLaunchKernelGGL(k.prep, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sap, it);
+    hipLaunchKernelGGL(k.prep, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
     // few workgroups, all resident at once on any MI355X (256 CUs): the level barrier is a counter
     const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
     const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane
-    hipLaunchKernelGGL(k.sweep, dim3(nwg), dim3(256), 0, stream, sap);
+    hipLaunchKernelGGL(k.sweep[sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2)], dim3(nwg), dim3(256), 2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
     hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
