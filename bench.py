@@ -193,6 +193,41 @@ def bench_spatial(args, world, rank, device):
     return result
 
 
+def bench_single_process(args):
+    """--single-process: N devices driven by ONE process through the C ABI's own sharding
+    (fabber_vb_run_host_multi: contiguous voxel blocks, one host thread + stream per device, nothing
+    exchanged). Host buffers in, host buffers out, so the figure INCLUDES the PCIe transfers: it is the
+    rate a fabber_dorun caller with devices=all sees, not the device-resident headline."""
+    from fabber_core_amd import hiplib
+    w = WORKLOADS[args.workload]
+    if w.get("kind") == "spatial":
+        raise SystemExit("--single-process shards voxelwise VB; spatial VB runs on one device")
+    n = args.gpus
+    visible = hiplib.device_count()
+    if visible < n:
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (n, visible))
+    V = (args.voxels or w["voxels"]) * n
+    holder, y = make_problem(w, V, 20260103, bool(args.need_f))
+    devices = list(range(n))
+    for _ in range(args.warmup):
+        hiplib.run_host(holder, y, devices=devices)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = hiplib.run_host(holder, y, devices=devices)
+    elapsed = time.perf_counter() - t0
+    s_f, s_it, bad = res["summary"]
+    result = {"metric": "voxels/sec to VB convergence", "value": V * args.steps / elapsed, "unit": "voxels/s", "n_gpus": n,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": w["desc"], "voxels_per_gpu": V // n, "total_voxels": V, "timepoints": w["T"],
+                         "params": holder.cfg.n_params, "iterations": w["its"], "need_f": bool(args.need_f),
+                         "parallelism": "one process, fabber_vb_run_host_multi over %d device(s), host buffers (PCIe-inclusive)" % n,
+                         "input_dtype": "f32", "mean_iterations": s_it / V, "bad_voxels": int(bad)},
+              "roofline": None, "cpu_baseline": None}
+    print(json.dumps(result), flush=True)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,7 +242,26 @@ def main():
     ap.add_argument("--residual", default="auto", choices=["auto", "exact", "moments"],
                     help="how k'Qk is obtained (fabber_vb_set_residual_mode); default adaptive")
     ap.add_argument("--residual-tol", type=float, default=None)
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N: one process, the C++ engine's own sharding (fabber_vb_run_host_multi, host buffers: "
+                         "the rate includes the PCIe transfers and is reported as such)")
     args = ap.parse_args()
+
+    if args.single_process:
+        return bench_single_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: start the ranks here, BEFORE anything in this process touches the GPU
+        # (a process that has initialised HIP must not exec another program), and relay rank 0's line.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        child = subprocess.run(cmd, env=env)
+        raise SystemExit(child.returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

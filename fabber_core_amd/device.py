@@ -19,14 +19,21 @@ class DeviceProblem:
         self.holder = holder
         cfg = holder.cfg
         self.device = torch.device(device)
-        data = np.ascontiguousarray(data)
-        if data.dtype != np.float64:
-            data = np.ascontiguousarray(data, dtype=np.float32)
-        assert data.shape == (cfg.n_times, cfg.n_voxels)
-        self.data = torch.from_numpy(data).to(self.device)
+        if isinstance(data, torch.Tensor):  # a series that was generated on the device (full-size tests)
+            assert data.is_cuda and data.is_contiguous() and data.dtype in (torch.float32, torch.float64)
+            assert tuple(data.shape) == (cfg.n_times, cfg.n_voxels)
+            self.data = data
+            is_f64 = data.dtype == torch.float64
+        else:
+            data = np.ascontiguousarray(data)
+            if data.dtype != np.float64:
+                data = np.ascontiguousarray(data, dtype=np.float32)
+            assert data.shape == (cfg.n_times, cfg.n_voxels)
+            self.data = torch.from_numpy(data).to(self.device)
+            is_f64 = data.dtype == np.float64
         # device copy of the config: same scalars, pointer members replaced by device tensors
         self.cfg = vbabi.FvbConfig.from_buffer_copy(cfg)
-        self.cfg.data_f64 = 1 if data.dtype == np.float64 else 0
+        self.cfg.data_f64 = 1 if is_f64 else 0
         self._keep = {}
         for name, arr in holder.keep.items():
             t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
