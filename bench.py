@@ -76,31 +76,17 @@ def make_problem(w, V, seed, need_f):
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the 157.3 TF fp32 vector peak)
-EXP_FLOP_EQ = 25.0             # flop-equivalents charged per fp64 exp()
 N_SIMDS = 256 * 4              # MI355X: 256 CUs x 4 SIMDs
-CLOCK_GHZ = 2.4
 
 
-def flops_per_voxel_iteration(P, T, w):
-    """(2P+1) E_m + 2TP + P(P+1)T + 6TP + 6T + 2P^3 + 6P^2 with
-    E_m = 3 T N_e flops + T N_e exp() for the exponential model, 2 T P for the polynomial and
-    the linear model (the algorithm's count: what the reference executes per voxel-iteration, not
-    what the kernel executes after sharing work between the 2P+1 evaluations)."""
-    if w.get("kind", "exp") == "exp":
-        e_m = 3 * T * w["num_exps"] + T * w["num_exps"] * EXP_FLOP_EQ
-    else:
-        e_m = 2 * T * P
-    return (2 * P + 1) * e_m + 2 * T * P + P * (P + 1) * T + 6 * T * P + 6 * T + 2 * P ** 3 + 6 * P ** 2
-
-
-def pmc_traffic(workload, V, kernel, args):
-    """HBM bytes per launch of the VB kernel from the PMC passes committed under profiles/
-    (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes of this very
-    command, scaled by the bytes-per-count measured with tools/pmc_calib on the kernels' own access
-    widths). Counters cannot be read from inside the timed run, so the figure is attached only when
-    the committed profile is of the same workload, size, kernel and default engine settings."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_%s.json" % workload)
-    if not os.path.exists(path) or V != WORKLOADS[workload]["voxels"] or args.need_f or args.variant != "auto" \
+def pmc_profile(workload, V, kernel, args, kernel_ms):
+    """What the PMC passes committed under profiles/ say about the VB kernel (tools/pmc_passes.sh: FETCH_SIZE and
+    WRITE_SIZE in separate rocprofv3 --pmc passes of this very command, scaled by the bytes-per-count measured with
+    tools/pmc_calib on the kernels' own access widths; the fp64 instruction counters and GRBM_GUI_ACTIVE in a third).
+    Counters cannot be read from inside the timed run, so the figures are attached only when the committed profile
+    is of the same workload, size, kernel and default engine settings; rates use the LIVE kernel time."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
+    if not os.path.exists(path) or V != WORKLOADS[workload]["voxels"] or args.variant != "auto" \
             or args.residual != "auto" or args.residual_tol is not None:
         return {"traffic": None}
     prof = json.load(open(path))
@@ -108,21 +94,29 @@ def pmc_traffic(workload, V, kernel, args):
     tag = kernel[kernel.find("<") + 1:].rstrip(">").split(",")  # e.g. lane<exp,4> / lane_ar1<linear,4> -> ["exp", "4"]
     if len(tag) < 2 or ("%sModel<%s>" % (tag[0].capitalize(), tag[1])) not in name:
         return {"traffic": None}
-    cal, ctr = prof["calibration"], prof["counters"]
+    cal, ctr, der = prof["calibration"], prof["counters"], prof.get("derived", {})
     fetch = ctr["FETCH_SIZE"]["mean_per_launch"] * cal["read_rows<float> FETCH_SIZE"]["bytes_per_count"]
     write = ctr["WRITE_SIZE"]["mean_per_launch"] * cal["write_rows<double> WRITE_SIZE"]["bytes_per_count"]
+    out = {"traffic": fetch + write,
+           "traffic_detail": {"fetch_bytes": fetch, "write_bytes": write, "source": os.path.relpath(path, ROOT),
+                              "profiled_kernel_ms": prof["kernel_trace"]["avg_ns"] / 1e6,
+                              "note": "the series is re-read on every pass (51 passes; at this size it does not stay in L2), "
+                                      "the tiled copy is written and read once more, plus what is left of register spills"}}
+    clock = der.get("shader_clock_ghz")
     valu = ctr.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
-    issue = None
-    if valu:
-        # one VALU instruction of a 64-lane wave occupies its SIMD's 16-lane pipe for 4 cycles
-        issue = {"valu_wave_instructions": valu, "simds": N_SIMDS, "clock_ghz": CLOCK_GHZ,
-                 "utilisation": valu * 4 / (N_SIMDS * prof["kernel_trace"]["avg_ns"] * CLOCK_GHZ),
-                 "wait_any_over_wave_cycles": ctr["SQ_WAIT_ANY"]["mean_per_launch"] / ctr["SQ_WAVE_CYCLES"]["mean_per_launch"]}
-    return {"traffic": fetch + write, "valu_issue": issue,
-            "traffic_detail": {"fetch_bytes": fetch, "write_bytes": write, "source": os.path.relpath(path, ROOT),
-                               "profiled_kernel_ms": prof["kernel_trace"]["avg_ns"] / 1e6,
-                               "note": "includes the per-iteration re-read of the series (it does not stay in the "
-                                       "Infinity Cache at this size) and register spill traffic; see DESIGN.md"}}
+    if valu and clock:
+        # one fp64 VALU instruction of a 64-lane wave occupies its SIMD's 16-lane pipe for 4 cycles
+        out["valu_issue"] = {"valu_wave_instructions": valu, "simds": N_SIMDS, "shader_clock_ghz_measured": clock,
+                             "clock_source": "GRBM_GUI_ACTIVE / 8 / kernel time of the profiled launch",
+                             "utilisation": valu * 4 / (N_SIMDS * prof["kernel_trace"]["avg_ns"] * clock),
+                             "wait_any_over_wave_cycles": ctr["SQ_WAIT_ANY"]["mean_per_launch"] / ctr["SQ_WAVE_CYCLES"]["mean_per_launch"]}
+    if der.get("fp64_flop_per_launch"):
+        flop = der["fp64_flop_per_launch"]
+        out["fp64_executed"] = {"flop_per_launch": flop, "achieved": flop / (kernel_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                "vector_peak_at_2p4ghz": FP64_VALU_PEAK_TFLOPS,
+                                "frac": flop / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                "counted": "(2 x SQ_INSTS_VALU_FMA_F64 + ADD_F64 + MUL_F64) x 64 lanes, executed"}
+    return out
 
 
 def bench_spatial(args, world, rank, device):
@@ -345,20 +339,16 @@ def main():
         rows = holder.n_mvn_rows
         alg_bytes = (4 * T + 4 * rows) * V
         mean_its = summ[1] / (V * world)
-        flops = flops_per_voxel_iteration(P, T, w) * mean_its * V
         roofline = {
             "bound": "hbm", "kernel": prob.kernel,
             "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-            "note": "the kernel is bound by fp64 VALU issue, not by HBM: see valu_issue (executed instructions, from "
-                    "the committed PMC profile) and fp64_algorithmic (the reference's operation count per second; it can "
-                    "exceed the vector peak because the kernel shares work between the 2P+1 model evaluations)",
-            "fp64_algorithmic": {"achieved": flops / (k_ms * 1e-3) / 1e12, "vector_peak": FP64_VALU_PEAK_TFLOPS,
-                                 "unit": "TFLOP-eq/s", "flop_eq_per_voxel_iteration": flops_per_voxel_iteration(P, T, w),
-                                 "exp_flop_eq": EXP_FLOP_EQ},
+            "note": "the kernel is bound by fp64 VALU issue, not by HBM: see valu_issue (executed instructions and the shader "
+                    "clock measured during the kernel, from the committed PMC profile) and fp64_executed (executed fp64 "
+                    "FLOP/s against the 78.6 TFLOP/s vector peak)",
         }
-        roofline.update(pmc_traffic(args.workload, V, prob.kernel, args))
+        roofline.update(pmc_profile(args.workload, V, prob.kernel, args, k_ms))
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             import oracle
@@ -390,6 +380,25 @@ def main():
             floor = parity.population_stats(hf, ref_f, oracle.run_fma(hf, yf))
             stats = parity.population_stats(hs, ref, gpu)
             tolist = lambda d: {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in d.items()}
+            truth = None
+            if args.workload == "c3" and not args.need_f:
+                # the fit is chaotic per voxel: every fp64 implementation is measured against the binary128
+                # evaluation of the reference algorithm on the committed 4096-voxel sample (tests/golden/)
+                sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+                import make_c3_truth as mt
+                from fabber_core_amd import hiplib as _hl
+                tr = parity.load_c3_truth()
+                ht, yt = mt.problem(tr["n_voxels"])
+                _hl.set_variant("lane")
+                try:
+                    g_t = _hl.run_host(ht, yt)
+                finally:
+                    _hl.set_variant(args.variant)
+                truth = {"sample": "tests/golden/c3_truth_binary128.npz: %d voxels of this workload" % tr["n_voxels"],
+                         "error_definition": "per voxel max over parameters + noise of |mean - truth| / max(|truth|, posterior sd); "
+                                             "*_rel: |mean - truth| / max(|truth|, 1e-12) over the model parameters (SURVEY 8d)",
+                         "gpu": parity.truth_stats(ht, tr, g_t), "cpu": parity.truth_stats(ht, tr, oracle.run(ht, yt)),
+                         "cpu_fma_build": parity.truth_stats(ht, tr, oracle.run_fma(ht, yt))}
             cpu = {"value": ns / cpu_s, "unit": "voxels/s", "cores": 1, "kind": "port",
                    "sample": "first %d voxels of rank 0's shard, same model/iterations, oracle/liboracle.so single thread, %.1f s" % (ns, cpu_s),
                    "host_cpus": os.cpu_count(),
@@ -397,7 +406,8 @@ def main():
                                  "gpu_over_cpu": (V / (k_ms * 1e-3)) / (ns / cpu_all_s)},
                    "gpu_over_cpu_single_thread": (V / (k_ms * 1e-3)) / (ns / cpu_s),
                    "posterior_mean_error_definition": "max over parameters+noise of |d mean| / max(|mean|, posterior sd), per voxel",
-                   "gpu_vs_cpu": tolist(stats), "cpu_vs_cpu_fma_build_floor": tolist(floor)}
+                   "gpu_vs_cpu": tolist(stats), "cpu_vs_cpu_fma_build_floor": tolist(floor),
+                   "against_binary128_ground_truth": truth}
         result = {
             "metric": "voxels/sec to VB convergence", "value": value, "unit": "voxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

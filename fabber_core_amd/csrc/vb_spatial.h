@@ -48,7 +48,8 @@ struct SpatialArgs
     const int32_t *nn;      // [V][6] first neighbours (0-based, -1 = none), reference order
     const int32_t *order;   // voxel ids sorted by level
     double *aK;             // [P] smoothing precision per (spatial) parameter
-    double *partials;       // [n_blocks][P][2] reduction scratch
+    double *partials;       // [n_blocks][P][2] reduction scratch: one entry per SEGMENT of the voxel list
+    const int32_t *seg_start; // [n_blocks + 1] first voxel of each segment: a z-plane, cut every 4096 voxels
     double *fprior_last;    // F contribution of the priors of the LAST voxel of the first sweep
     int32_t *status;        // [V]
     int32_t spatial_dims;
@@ -258,7 +259,10 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
         if (!is_spatial_type(type))
             continue;
         double trace_term = 0, term2 = 0;
-        for (int v = sa.owned_begin + blockIdx.x * 256 + threadIdx.x; v < sa.owned_end; v += gridDim.x * 256)
+        // one block per segment (a z-plane of the owned voxels, cut every 4096 voxels from the plane's first):
+        // the partial sum of a segment does not depend on how the volume is cut into slabs (cuts fall between
+        // planes), so a_K - which every voxel's prior depends on - is the same bits for any number of slabs
+        for (int v = sa.seg_start[blockIdx.x] + threadIdx.x; v < sa.seg_start[blockIdx.x + 1]; v += 256)
         {
             if (sa.status[v] != 0) // ignored voxels (priors.cc:237-240) ...
                 continue;
@@ -307,23 +311,19 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
     }
 }
 
-// this slab's sums: the per-block partials added in a fixed order (deterministic): one 64-lane wave per
-// (parameter, sum), lane l adds blocks l, l + 64, ... in order, then a butterfly over the lanes
+// this slab's sums: the segments' partial sums added in segment order (the order a single device and any
+// slab decomposition share: fabber_core_amd/spatial_mgpu.py adds the slabs' segments the same way)
 template <int P>
 __global__ __launch_bounds__(64) void vb_spatial_ak_reduce_kernel(const SpatialArgs sa)
 {
-    const int k = blockIdx.x >> 1, which = blockIdx.x & 1;
+    const int k = threadIdx.x >> 1, which = threadIdx.x & 1;
     if (k >= P)
         return;
     double acc = 0;
     if (is_spatial_type(sa.ka.cfg.prior_type[k]))
-        for (int b = threadIdx.x; b < sa.n_blocks; b += 64)
+        for (int b = 0; b < sa.n_blocks; b++)
             acc += sa.partials[((size_t)b * P + k) * 2 + which];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        acc += __shfl_xor(acc, off);
-    if (threadIdx.x == 0)
-        sa.ak_sums[2 * k + which] = acc;
+    sa.ak_sums[2 * k + which] = acc;
 }
 
 template <int P>

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -319,7 +320,10 @@ struct fvb_spatial_run
     int V = 0, P = 0, owned_begin = 0, owned_end = 0;
     bool has_spatial = false;
     std::vector<int32_t> level_begin;
-    DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums;
+    std::vector<long long> level_value; // the level (weighted co-ordinate sum) of each entry of level_begin
+    int level_w[3] = { 1, 1, 1 };
+    DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums, d_seg_start;
+    int n_segments = 0;
     double t_geometry_ms = 0, t_neighbours_ms = 0;
     // the split first sweep (vb_spatial.h): whole-volume runs with first-neighbour priors (types M, m)
     bool allow_fast = false, fast = false;
@@ -330,8 +334,11 @@ struct fvb_spatial_run
 
     int open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out, hipStream_t stream_);
     int ak_sums(double *host_sums);
+    int ak_segment_sums(double *host_partials);
     int set_ak_sums(const double *host_sums);
     int sweep(int it);
+    int sweep_levels(int it, long long lo, long long hi);
+    int sweep_noise(int it);
     int copy_means(int v_begin, int v_count, double *host_means, int32_t *host_status, bool to_device);
     int finish();
 };
@@ -446,6 +453,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         }
     std::vector<int32_t> order(std::max(n_owned, 1));
     level_begin.clear();
+    level_value.clear();
+    level_w[0] = 1;
+    level_w[1] = (int)cy;
+    level_w[2] = (int)cz;
     if (lmax - lmin < (1LL << 22))
     {
         // counting sort (stable: voxels of a level stay in index order)
@@ -467,7 +478,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 running += n;
             }
             if (running > begin)
+            {
                 level_begin.push_back(begin);
+                level_value.push_back(lmin + (long long)l);
+            }
         }
         level_begin.push_back(n_owned);
         parallel([&](int t) {
@@ -485,7 +499,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         for (int i = 0; i < n_owned; i++)
         {
             if (i == 0 || level_of(idx[i]) != level_of(idx[i - 1]))
+            {
                 level_begin.push_back(i);
+                level_value.push_back(level_of(idx[i]));
+            }
             order[i] = owned_begin + idx[i];
         }
         level_begin.push_back(n_owned);
@@ -522,12 +539,21 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
 
     // ---- device memory ----
-    const int n_blocks = std::max(1, std::min(1024, (n_owned + 255) / 256));
+    // segments of the a_K sums: every z-plane of the owned voxels, cut every 4096 voxels from its first
+    std::vector<int32_t> seg_start;
+    for (int v = owned_begin; v < owned_end; v++)
+        if (v == owned_begin || Z[v] != Z[v - 1] || v - seg_start.back() >= 4096)
+            seg_start.push_back(v);
+    seg_start.push_back(owned_end);
+    const int n_blocks = (int)seg_start.size() - 1;
+    n_segments = n_blocks;
     FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V));
     FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * order.size()));
     FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS));
     FVB_HIP_CHECK(d_sums.alloc(sizeof(double) * FVB_MAX_PARAMS * 2));
-    FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)n_blocks * P * 2));
+    FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)std::max(n_blocks, 1) * P * 2));
+    FVB_HIP_CHECK(d_seg_start.alloc(sizeof(int32_t) * seg_start.size()));
+    FVB_HIP_CHECK(hipMemcpyAsync(d_seg_start.p, seg_start.data(), sizeof(int32_t) * seg_start.size(), hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(d_fprior.alloc(sizeof(double)));
     FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V));
     FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, stream));
@@ -537,7 +563,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     FVB_HIP_CHECK(hipMemcpyAsync(d_aK.p, aK0, sizeof(aK0), hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(hipMemsetAsync(d_fprior.p, 0, sizeof(double), stream));
     FVB_HIP_CHECK(hipMemsetAsync(d_sums.p, 0, sizeof(double) * FVB_MAX_PARAMS * 2, stream));
-    FVB_HIP_CHECK(hipMemsetAsync(d_partials.p, 0, sizeof(double) * (size_t)n_blocks * P * 2, stream));
+    FVB_HIP_CHECK(hipMemsetAsync(d_partials.p, 0, sizeof(double) * (size_t)std::max(n_blocks, 1) * P * 2, stream));
 
     memset(&sa, 0, sizeof(sa));
     sa.ka.cfg = cfg;
@@ -552,6 +578,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     sa.aK = (double *)d_aK.p;
     sa.ak_sums = (double *)d_sums.p;
     sa.partials = (double *)d_partials.p;
+    sa.seg_start = (const int32_t *)d_seg_start.p;
     sa.fprior_last = (double *)d_fprior.p;
     sa.status = (int32_t *)d_status.p;
     sa.spatial_dims = sp.spatial_dims;
@@ -632,13 +659,24 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
 int fvb_spatial_run::ak_sums(double *host_sums)
 {
     hipLaunchKernelGGL(k.ak_partial, dim3(sa.n_blocks), dim3(256), 0, stream, sa);
-    hipLaunchKernelGGL(k.ak_reduce, dim3(2 * P), dim3(64), 0, stream, sa);
+    hipLaunchKernelGGL(k.ak_reduce, dim3(1), dim3(64), 0, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     if (host_sums)
     {
         FVB_HIP_CHECK(hipMemcpyAsync(host_sums, d_sums.p, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, stream));
         FVB_HIP_CHECK(hipStreamSynchronize(stream));
     }
+    return 0;
+}
+
+// the segments' partial sums [n_segments][P][2] (for callers that add up several slabs' segments in order)
+int fvb_spatial_run::ak_segment_sums(double *host_partials)
+{
+    if (sa.n_blocks > 0)
+        hipLaunchKernelGGL(k.ak_partial, dim3(sa.n_blocks), dim3(256), 0, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    FVB_HIP_CHECK(hipMemcpyAsync(host_partials, d_partials.p, sizeof(double) * 2 * P * (size_t)sa.n_blocks, hipMemcpyDeviceToHost, stream));
+    FVB_HIP_CHECK(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -655,13 +693,29 @@ int fvb_spatial_run::set_ak_sums(const double *host_sums)
 
 int fvb_spatial_run::sweep(int it)
 {
+    int rc = sweep_levels(it, LLONG_MIN, LLONG_MAX);
+    return rc ? rc : sweep_noise(it);
+}
+
+// first sweep, the levels with lo <= value < hi (one launch per level)
+int fvb_spatial_run::sweep_levels(int it, long long lo, long long hi)
+{
     sa.it = it;
     const SpatialArgs *sap = (const SpatialArgs *)d_sa.p;
     for (size_t l = 0; l + 1 < level_begin.size(); l++)
     {
+        if (level_value[l] < lo || level_value[l] >= hi)
+            continue;
         const int begin = level_begin[l], count = level_begin[l + 1] - level_begin[l];
         hipLaunchKernelGGL(k.theta, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, sap, begin, count, it);
     }
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int fvb_spatial_run::sweep_noise(int it)
+{
+    sa.it = it;
     const int n_owned = owned_end - owned_begin;
     if (n_owned > 0)
         hipLaunchKernelGGL(k.noise, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
@@ -715,17 +769,17 @@ int fvb_spatial_run::copy_means(int v_begin, int v_count, double *host_means, in
     if (host_means)
     {
         if (to_device)
-            FVB_HIP_CHECK(hipMemcpy2DAsync(dev, sizeof(double) * (size_t)V, host_means, width, width, P, hipMemcpyHostToDevice, stream));
+            FVB_HIP_CHECK(hipMemcpy2DAsync(dev, sizeof(double) * (size_t)V, host_means, width, width, P, hipMemcpyDefault, stream));
         else
-            FVB_HIP_CHECK(hipMemcpy2DAsync(host_means, width, dev, sizeof(double) * (size_t)V, width, P, hipMemcpyDeviceToHost, stream));
+            FVB_HIP_CHECK(hipMemcpy2DAsync(host_means, width, dev, sizeof(double) * (size_t)V, width, P, hipMemcpyDefault, stream));
     }
     if (host_status)
     {
         int32_t *ds = (int32_t *)d_status.p + v_begin;
         if (to_device)
-            FVB_HIP_CHECK(hipMemcpyAsync(ds, host_status, sizeof(int32_t) * (size_t)v_count, hipMemcpyHostToDevice, stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(ds, host_status, sizeof(int32_t) * (size_t)v_count, hipMemcpyDefault, stream));
         else
-            FVB_HIP_CHECK(hipMemcpyAsync(host_status, ds, sizeof(int32_t) * (size_t)v_count, hipMemcpyDeviceToHost, stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(host_status, ds, sizeof(int32_t) * (size_t)v_count, hipMemcpyDefault, stream));
     }
     FVB_HIP_CHECK(hipStreamSynchronize(stream));
     return 0;
@@ -850,6 +904,14 @@ int32_t fabber_vb_spatial_ak_sums(fvb_spatial_run *run, double *sums)
     return run ? run->ak_sums(sums) : api_fail(-47, "run handle is NULL");
 }
 
+int32_t fabber_vb_spatial_ak_segment_sums(fvb_spatial_run *run, double *partials, int32_t *n_segments)
+{
+    if (!run || !n_segments)
+        return api_fail(-47, "run handle is NULL");
+    *n_segments = run->n_segments;
+    return partials ? run->ak_segment_sums(partials) : 0;
+}
+
 int32_t fabber_vb_spatial_set_ak_sums(fvb_spatial_run *run, const double *sums)
 {
     return run ? run->set_ak_sums(sums) : api_fail(-47, "run handle is NULL");
@@ -858,6 +920,36 @@ int32_t fabber_vb_spatial_set_ak_sums(fvb_spatial_run *run, const double *sums)
 int32_t fabber_vb_spatial_sweep(fvb_spatial_run *run, int32_t iteration)
 {
     return run ? run->sweep(iteration) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_sweep_levels(fvb_spatial_run *run, int32_t iteration, int64_t level_lo, int64_t level_hi)
+{
+    return run ? run->sweep_levels(iteration, level_lo, level_hi) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_sweep_noise(fvb_spatial_run *run, int32_t iteration)
+{
+    return run ? run->sweep_noise(iteration) : api_fail(-47, "run handle is NULL");
+}
+
+int32_t fabber_vb_spatial_level_weights(fvb_spatial_run *run, int32_t weights[3])
+{
+    if (!run || !weights)
+        return api_fail(-47, "run handle is NULL");
+    for (int i = 0; i < 3; i++)
+        weights[i] = run->level_w[i];
+    return 0;
+}
+
+int32_t fabber_vb_spatial_fprior(fvb_spatial_run *run, double *value, int32_t set)
+{
+    if (!run || !value)
+        return api_fail(-47, "run handle is NULL");
+    hipError_t e = set ? hipMemcpyAsync(run->d_fprior.p, value, sizeof(double), hipMemcpyDefault, run->stream)
+                       : hipMemcpyAsync(value, run->d_fprior.p, sizeof(double), hipMemcpyDefault, run->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(run->stream);
+    return e == hipSuccess ? 0 : api_fail(-100 - (int)e, hipGetErrorString(e));
 }
 
 int32_t fabber_vb_spatial_copy_means(fvb_spatial_run *run, int32_t v_begin, int32_t v_count, double *means, int32_t *status,

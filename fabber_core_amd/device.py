@@ -48,7 +48,7 @@ class DeviceProblem:
                 self.cfg.image_prior[int(name.split("_")[1])] = t.data_ptr()
         V = cfg.n_voxels
         self.mvn = torch.empty((holder.n_mvn_rows, V), dtype=torch.float64, device=self.device)
-        self.free_energy = torch.empty(V, dtype=torch.float64, device=self.device)
+        self.free_energy = torch.full((V,), float("nan"), dtype=torch.float64, device=self.device)  # (voxels that fail before any F keep NaN)
         self.status = torch.empty(V, dtype=torch.int32, device=self.device)
         self.iterations = torch.empty(V, dtype=torch.int32, device=self.device)
         self.out = vbabi.FvbOutputs()

@@ -293,18 +293,43 @@ int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp,
  *           neighbours, of their planes into the ghost voxels ...
  *   fabber_vb_spatial_close(run)                        result images of every local voxel, free
  *
- * Ghost voxels keep the values of the last exchange during a sweep (block-Jacobi across slab
- * boundaries, Gauss-Seidel inside a slab). With one process and no ghosts the sequence above is
- * exactly fabber_vb_run_spatial_device. All pointers except `data`, `out` are host pointers.
+ * Ghost voxels keep the values they were last given. Exchanging the boundary planes once per iteration
+ * makes the cuts block-Jacobi (the ghosts BELOW a slab are one iteration old). The reference's order
+ * (inference_vb.cc:614, :675) is kept exactly by running the first sweep in level ranges instead:
+ *
+ *       for each tick: fabber_vb_spatial_sweep_levels(run, it, lo, hi)   first sweep, levels lo <= level < hi
+ *                      ... send the top boundary planes to the slab above, receive the ghosts below ...
+ *       fabber_vb_spatial_sweep_noise(run, it)                           second sweep
+ *
+ * where slab r works on the c-th range of levels at tick c + r: what a voxel reads from the slab below has a
+ * lower level and was final one tick earlier, what it reads from the slab above has a higher level and is
+ * still the previous iteration's - the single-device sweep, voxel for voxel (fabber_core_amd/spatial_mgpu.py).
+ * The level of a voxel is x + y + z of its co-ordinates (x + 2 y + 3 z when a prior reads second neighbours),
+ * see fabber_vb_spatial_level_weights. With one process and no ghosts fabber_vb_spatial_sweep is exactly
+ * fabber_vb_run_spatial_device. All pointers except `data`, `out` are host pointers unless said otherwise.
  */
 typedef struct fvb_spatial_run fvb_spatial_run;
 int32_t fabber_vb_spatial_open(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
     void *stream, fvb_spatial_run **run);
 int32_t fabber_vb_spatial_ak_sums(fvb_spatial_run *run, double *sums /* [n_params][2] */);
+/* The same sums before the last addition: one (trace term, quadratic term) pair per parameter and SEGMENT of
+ * the owned voxels (a z-plane, cut every 4096 voxels). Segments do not depend on the slab decomposition, so
+ * adding all slabs' segments in voxel order gives the single-device sums bit for bit. partials = NULL: only
+ * *n_segments is returned; else partials [n_segments][n_params][2]. */
+int32_t fabber_vb_spatial_ak_segment_sums(fvb_spatial_run *run, double *partials, int32_t *n_segments);
 int32_t fabber_vb_spatial_set_ak_sums(fvb_spatial_run *run, const double *sums /* [n_params][2] */);
 int32_t fabber_vb_spatial_sweep(fvb_spatial_run *run, int32_t iteration);
+/* the two sweeps separately; level_lo / level_hi are LEVEL VALUES (weighted co-ordinate sums, global) */
+int32_t fabber_vb_spatial_sweep_levels(fvb_spatial_run *run, int32_t iteration, int64_t level_lo, int64_t level_hi);
+int32_t fabber_vb_spatial_sweep_noise(fvb_spatial_run *run, int32_t iteration);
+/* weights (wx, wy, wz) of the level function this run sorts its first sweep by */
+int32_t fabber_vb_spatial_level_weights(fvb_spatial_run *run, int32_t weights[3]);
+/* The free-energy term of the priors of the LAST voxel of the first sweep (the reference reuses one local
+ * variable for every voxel's F, inference_vb.cc:612,689,702): with slabs it is the last slab's; get it there
+ * (set = 0) and set it everywhere else (set = 1) before the second sweep when F is evaluated. */
+int32_t fabber_vb_spatial_fprior(fvb_spatial_run *run, double *value, int32_t set);
 /* posterior means [n_params][v_count] and status [v_count] of local voxels [v_begin, v_begin+v_count):
- * device -> host (to_device = 0) or host -> device (1). Either buffer may be NULL. */
+ * run -> buffer (to_device = 0) or buffer -> run (1). Either buffer may be NULL; host or device memory. */
 int32_t fabber_vb_spatial_copy_means(fvb_spatial_run *run, int32_t v_begin, int32_t v_count, double *means, int32_t *status,
     int32_t to_device);
 int32_t fabber_vb_spatial_close(fvb_spatial_run *run);

@@ -129,6 +129,7 @@ def population_stats(holder, a, b):
     q = [0.1, 0.5, 0.9]
     return dict(
         frac_within_1e4=float(np.mean(e_mean <= NORTH_STAR)),
+        frac_within_1e4_rel=float(np.mean(rel <= NORTH_STAR)),  # |a - b| / max(|b|, 1e-12), model parameters
         frac_within_1e6=float(np.mean(e_mean <= 1e-6)),
         median_err=float(np.median(e_mean)),
         bad_a=float(np.mean(a["status"] != 0)), bad_b=float(np.mean(b["status"] != 0)),
