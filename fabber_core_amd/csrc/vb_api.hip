@@ -304,7 +304,7 @@ const char *fabber_vb_kernel_name(const fvb_config *cfg)
     if (validate(cfg) != 0)
         return "invalid";
     LaneKernelInfo k = select_lane(cfg);
-    if (k.fn && g_variant != 2)
+    if ((k.fn || k.fn_tiles_f32) && g_variant != 2)
         return k.name;
     return "wave";
 }
@@ -353,7 +353,7 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
     fvb_config choice = *cfg;
     choice.n_voxels = kernel_voxels;
     LaneKernelInfo lk = select_lane(&choice);
-    if (lk.fn)
+    if (lk.fn || lk.fn_tiles_f32)
     {
         if (needs_save(cfg))
             FVB_HIP_CHECK(hipMallocAsync((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels, stream));
@@ -362,7 +362,8 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
         void *tiles = nullptr;
         // White noise, no masked timepoints: the series is re-laid per wavefront once (one read and one
         // write of the image) and every pass of the voxel loop streams that block (vb_lane_kernel.h).
-        if (lk.fn_tiles_f32 && n_unmasked == cfg->n_times && g_residual_mode != 1 && g_tiled)
+        // (the AR(1) kernels exist for the tiled series only)
+        if (lk.fn_tiles_f32 && (!lk.fn || (n_unmasked == cfg->n_times && g_residual_mode != 1 && g_tiled)))
         {
             const int V = cfg->n_voxels, T = cfg->n_times;
             const unsigned rgrid = (unsigned)((V + 255) / 256);

@@ -10,11 +10,12 @@ typedef void (*LaneKernelFn)(const KernelArgs);
 
 struct LaneKernelInfo
 {
-    LaneKernelFn fn; // reads the caller's [t][voxel] image in place (FEED_STRIDED: any element type, masked timepoints)
+    LaneKernelFn fn; // reads the caller's [t][voxel] image in place (FEED_STRIDED: any element type, masked timepoints);
+                     // NULL for the AR(1) kernels, which only exist for the tiled series
     int save_rows;
     const char *name;
-    // white noise only: the same loop fed from the tiled series (vb_lane_kernel.h), float / double
-    // elements - what runs unless timepoints are masked
+    // the same loop fed from the tiled series (vb_lane_kernel.h), float / double elements - what runs unless
+    // timepoints are masked
     LaneKernelFn fn_tiles_f32, fn_tiles_f64;
 };
 
@@ -42,7 +43,9 @@ LaneKernelInfo get_lane_ar_kernel_exp(int P, bool need_f);
 #define FVB_LANE_AR_CASE(MODEL, TAG, PP)                                                                     \
     case PP:                                                                                                 \
         if (need_f)                                                                                          \
-            return LaneKernelInfo{ vb_lane_ar_kernel<MODEL<PP>, PP, true>, lane_ar_save_rows<PP>(),          \
-                "lane_ar1<" TAG "," #PP ",F>" };                                                             \
-        return LaneKernelInfo{ vb_lane_ar_kernel<MODEL<PP>, PP, false>, lane_ar_save_rows<PP>(),             \
-            "lane_ar1<" TAG "," #PP ">" };
+            return LaneKernelInfo{ nullptr, lane_ar_save_rows<PP>(), "lane_ar1<" TAG "," #PP ",F>",          \
+                vb_lane_ar_kernel<MODEL<PP>, PP, true, FEED_TILES_F32>,                                      \
+                vb_lane_ar_kernel<MODEL<PP>, PP, true, FEED_TILES_F64> };                                    \
+        return LaneKernelInfo{ nullptr, lane_ar_save_rows<PP>(), "lane_ar1<" TAG "," #PP ">",                \
+            vb_lane_ar_kernel<MODEL<PP>, PP, false, FEED_TILES_F32>,                                         \
+            vb_lane_ar_kernel<MODEL<PP>, PP, false, FEED_TILES_F64> };

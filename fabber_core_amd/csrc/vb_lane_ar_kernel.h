@@ -112,13 +112,12 @@ __device__ __forceinline__ void ar_forms(const VoxelState<P> &st, const ArMoment
 }
 
 // The streaming pass: model + finite-difference Jacobian about `centre`, AR moments
-template <class Model, int P>
+template <class Model, int P, typename RAW>
 __device__ __forceinline__ int recentre_ar(
-    const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P], ArMoments<P> &mo, bool precise = false)
+    const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile, const double (&centre)[P], ArMoments<P> &mo, bool precise = false)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int T = ka.cfg.n_times;
-    const size_t V = (size_t)ka.cfg.n_voxels;
     double tp[P], tp2[P], tp3[P], rden[P];
 #pragma unroll
     for (int i = 0; i < P; i++)
@@ -189,7 +188,7 @@ __device__ __forceinline__ int recentre_ar(
             Jp[i] = J[i];
         rp = r;
     };
-    FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
+    for_each_timepoint_tiled<RAW>(lane_tile, T, step);
 #pragma unroll
     for (int i = 0; i < P; i++)
         mo.JT[i] = Jp[i];
@@ -198,12 +197,11 @@ __device__ __forceinline__ int recentre_ar(
 }
 
 // Direct k = y - g(ml) + J (ml - m): k'M00k, k'M10k, k'M20k summed as the reference does
-template <class Model, int P>
-__device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const ModelArgs &ma, int v,
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile,
     const ArMoments<P> &mo, const double (&m)[P], double &kk00, double &kk10, double &kk20)
 {
     const int T = ka.cfg.n_times;
-    const size_t V = (size_t)ka.cfg.n_voxels;
     double tp[P], tp2[P], tp3[P], rden[P], nd[P];
 #pragma unroll
     for (int i = 0; i < P; i++)
@@ -242,7 +240,7 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
             k_first = k;
         k_prev = k;
     };
-    FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
+    for_each_timepoint_tiled<RAW>(lane_tile, T, step);
     kk00 = sum_all - k_first * k_first;
     kk20 = sum_all - k_prev * k_prev;
     kk10 = -2 * cross;
@@ -255,8 +253,8 @@ struct ArForms
     double tr[3]; // tr(Sigma J'M J) for the three M
 };
 
-template <class Model, int P>
-__device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelArgs &ma, int v, const VoxelState<P> &st,
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile, const VoxelState<P> &st,
     const ArMoments<P> &mo, ArForms &f)
 {
     bool lost = false;
@@ -272,7 +270,7 @@ __device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelAr
     if (__any(want))
     {
         double e00, e10, e20;
-        exact_residual_ar<Model, P>(ka, ma, v, mo, st.m, e00, e10, e20);
+        exact_residual_ar<Model, P, RAW>(ka, ma, lane_tile, mo, st.m, e00, e10, e20);
         if (want)
         {
             f.kk[0] = e00;
@@ -440,15 +438,19 @@ __device__ __forceinline__ void restore_alpha(const KernelArgs &ka, int v, ArAlp
     al.a2 = p[6 * V];
 }
 
-template <class Model, int P, bool NEEDF>
+// FEED: FEED_TILES_F32 / FEED_TILES_F64 (vb_lane_kernel.h) - the series is always read from the tiled copy
+// (AR noise rejects masked timepoints, noisemodel_ar.cc:351-355, so there is no other case)
+template <class Model, int P, bool NEEDF, int FEED>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
+    typedef typename FeedTraits<FEED>::raw RAW;
     const int v = blockIdx.x * 64 + threadIdx.x;
     const int T = ka.cfg.n_times;
     const size_t V = (size_t)ka.cfg.n_voxels;
     if (v >= ka.cfg.n_voxels)
         return;
+    const RAW *lane_tile = (const RAW *)ka.tiles + (size_t)blockIdx.x * Tile<RAW>::block_elems(T) + (size_t)threadIdx.x * Tile<RAW>::G;
 
     ModelArgs ma;
     ma.iopt0 = ka.cfg.model_iopt[0];
@@ -496,10 +498,12 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const K
         }
         if (Model::needs_data_max)
         {
-            double data_max = load_data(ka, v);
+            constexpr int G = Tile<RAW>::G;
+            double data_max = (double)lane_tile[0];
+#pragma nounroll
             for (int t = 1; t < T; t++)
             {
-                const double y = load_data(ka, (size_t)t * V + v);
+                const double y = (double)lane_tile[(size_t)(t / G) * 64 * G + (t % G)];
                 data_max = (y > data_max) ? y : data_max;
             }
             Model::init_posterior(ma, data_max, st.m);
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const K
     int hist_len = 0;
     bool setup_failed = false;
 
-    status = recentre_ar<Model, P>(ka, ma, v, st.m, mo, true);
+    status = recentre_ar<Model, P, RAW>(ka, ma, lane_tile, st.m, mo, true);
     if (status != FVB_OK)
         setup_failed = true;
 
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const K
                 status = FVB_BAD_RESULT;
                 break;
             }
-            ar_residuals<Model, P>(ka, ma, v, st, mo, f);
+            ar_residuals<Model, P, RAW>(ka, ma, lane_tile, st, mo, f);
             if (NEEDF) // "theta"
                 FVB_EVAL_F_AR(f)
             status = update_noise_ar<P>(ka, st, al, f);
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const K
                 break;
             if (NEEDF) // "phi"
                 FVB_EVAL_F_AR(f)
-            status = recentre_ar<Model, P>(ka, ma, v, st.m, mo);
+            status = recentre_ar<Model, P, RAW>(ka, ma, lane_tile, st.m, mo);
             if (status != FVB_OK)
                 break;
             if (NEEDF) // "lin"
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const K
             {
                 restore_state<P>(ka, v, st);
                 restore_alpha<P>(ka, v, al);
-                status = recentre_ar<Model, P>(ka, ma, v, st.m, mo);
+                status = recentre_ar<Model, P, RAW>(ka, ma, lane_tile, st.m, mo);
                 if (status == FVB_OK && NEEDF)
                 {
                     do

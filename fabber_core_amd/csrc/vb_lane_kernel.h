@@ -360,6 +360,46 @@ __global__ __launch_bounds__(256) void retile_series(const RAW *__restrict__ dat
     }
 }
 
+// for (t = 0; t < T; t++) body(t, y_t) over a tiled series: trips of 8 timepoints, two register sets used
+// alternately, every load unconditional (the last one re-reads the final trip), the last T mod 8 one by one.
+template <typename RAW, class Body>
+__device__ __forceinline__ void for_each_timepoint_tiled(const RAW *lane_tile, int T, Body body)
+{
+    typedef Tile<RAW> TL;
+    constexpr int TRIP = 8;
+    constexpr int NL = TRIP / TL::G;
+    const int n_trips = T / TRIP;
+    if (n_trips > 0)
+    {
+        const typename TL::vec *p = (const typename TL::vec *)lane_tile;
+        typename TL::vec qa[NL], qb[NL];
+        auto fetch = [&](typename TL::vec(&q)[NL], int trip) {
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+                q[l] = p[(size_t)(trip * NL + l) * 64];
+        };
+        auto process = [&](const typename TL::vec(&q)[NL], int t0) {
+#pragma unroll
+            for (int j = 0; j < TRIP; j++)
+                body(t0 + j, (double)q[j / TL::G][j % TL::G]);
+        };
+        fetch(qa, 0);
+        int k = 0;
+        for (; k + 2 <= n_trips; k += 2)
+        {
+            fetch(qb, k + 1);
+            process(qa, k * TRIP);
+            fetch(qa, (k + 2 < n_trips) ? k + 2 : n_trips - 1);
+            process(qb, (k + 1) * TRIP);
+        }
+        if (k < n_trips)
+            process(qa, k * TRIP);
+    }
+#pragma nounroll
+    for (int t = n_trips * TRIP; t < T; t++)
+        body(t, (double)lane_tile[(size_t)(t / TL::G) * 64 * TL::G + (t % TL::G)]);
+}
+
 // recentre() for a tiled series without masked timepoints: the streaming pass of the throughput kernels.
 // Same arithmetic in the same order as recentre() above (the moments of voxel v are bit-identical); what
 // differs is how the samples arrive and that the code exists once:

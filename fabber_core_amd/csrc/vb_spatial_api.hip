@@ -1021,6 +1021,7 @@ int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp,
     if (out->free_energy)
     {
         FVB_HIP_CHECK(b_f.alloc(sizeof(double) * V));
+        FVB_HIP_CHECK(hipMemset(b_f.p, 0xff, sizeof(double) * V)); // NaN: a voxel that fails before any F is evaluated keeps it
         dout.free_energy = (double *)b_f.p;
     }
     if (out->status)
