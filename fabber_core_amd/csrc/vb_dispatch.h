@@ -24,6 +24,7 @@ struct LaneKernelInfo
 LaneKernelInfo get_lane_kernel_poly(int P, bool need_f);
 LaneKernelInfo get_lane_kernel_linear(int P, bool need_f);
 LaneKernelInfo get_lane_kernel_exp(int P, bool need_f);
+LaneKernelInfo get_lane_kernel_wide(int model, int P, bool need_f); // P = 7, 8 of any of the three
 // AR(1) noise (vb_lane_ar_kernel.h)
 LaneKernelInfo get_lane_ar_kernel_poly(int P, bool need_f);
 LaneKernelInfo get_lane_ar_kernel_linear(int P, bool need_f);

@@ -12,7 +12,7 @@ LaneKernelInfo get_lane_kernel_exp(int P, bool need_f)
         FVB_LANE_CASE(ExpModel, "exp", 4)
         FVB_LANE_CASE(ExpModel, "exp", 6)
     default:
-        return LaneKernelInfo{ nullptr, 0, nullptr };
+        return get_lane_kernel_wide(FVB_MODEL_EXP, P, need_f); // 7 and 8 parameters: vb_lane_wide.hip
     }
 }
 } // namespace fvb

@@ -14,7 +14,7 @@ LaneKernelInfo get_lane_kernel_poly(int P, bool need_f)
         FVB_LANE_CASE(PolyModel, "poly", 5)
         FVB_LANE_CASE(PolyModel, "poly", 6)
     default:
-        return LaneKernelInfo{ nullptr, 0, nullptr };
+        return get_lane_kernel_wide(FVB_MODEL_POLY, P, need_f); // 7 and 8 parameters: vb_lane_wide.hip
     }
 }
 } // namespace fvb

@@ -332,6 +332,54 @@ def test_gpu_reproduces_reference_stored_fixed_point(name):
     assert np.max(np.abs(got_means[:, P] / means[:, P] - 1)) < 1e-5
 
 
+@pytest.mark.parametrize("P", [7, 8])
+def test_seven_and_eight_parameters_on_the_lane_kernel(P):
+    """vb_lane_wide.hip: design matrices with 7 / 8 regressors (a cosine basis: well conditioned; a monomial
+    basis of this size is not, and then even two CPU builds of the oracle disagree) run one lane per voxel -
+    with heavy spills, and still 18 - 26 x the wave kernel's rate at volume sizes
+    (profiles/r2_lane_vs_wave_wide.jsonl). Strict per-voxel parity, with and without F, ragged voxel count."""
+    V, T = 4096 + 21, 40
+    rng = np.random.default_rng(8)
+    t = (np.arange(T) + 0.5) / T
+    X = np.stack([np.cos(np.pi * k * t) for k in range(P)], axis=1)
+    coef = rng.uniform(-2, 2, (P, V))
+    y = X @ coef + rng.normal(0, 0.05, (T, V))
+    for need_f in (False, True):
+        h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, max_iterations=6, need_f=need_f)
+        assert hiplib.kernel_name(h) == "lane<linear,%d%s>" % (P, ",F" if need_f else "")
+        check(h, y, what="linear P=%d" % P, check_f=need_f)
+    # the polynomial model of this size shares the template (PolyModel's design is the monomials 1 .. t^(P-1), over
+    # t = 1..12 cond(J'J) > 1e16: two CPU builds of the oracle end a median 13 posterior sd apart, so there is no
+    # value to compare) - the dispatch and a finite result are what is checked
+    h, yp = cases.poly_problem(3000, 12, P - 1, seed=77, max_iterations=4)
+    assert hiplib.kernel_name(h) == "lane<poly,%d>" % P
+    r = hipengine.run(h, yp)
+    assert np.isfinite(r["mvn"][:, r["status"] == 0]).all() and (r["status"] == 0).mean() > 0.9
+
+
+def test_four_exponentials_on_the_lane_kernel():
+    """exp(4) = 8 parameters: the fit is chaotic like the bi-exponential one (more so): one iteration from the
+    oracle's state per voxel, and population parity of a short run"""
+    V = 2000
+    rng = np.random.default_rng(9)
+    t = np.arange(100) * 0.02
+    y = sum(a * np.exp(-r * t[:, None]) for a, r in ((1.0, 0.5), (0.7, 2.0), (0.5, 6.0), (0.3, 15.0))) + rng.normal(0, 0.05, (100, V))
+    y = y.astype(np.float32)
+    h = vbabi.build_config(vbabi.MODEL_EXP, V, 100, num_exps=4, dt=0.02, max_iterations=3)
+    assert hiplib.kernel_name(h) == "lane<exp,8>"
+    state = oracle.run(h, y)
+    h1 = vbabi.build_config(vbabi.MODEL_EXP, V, 100, num_exps=4, dt=0.02, max_iterations=1, init_mvn=state["mvn"])
+    a, b = both(h1, y)
+    ok = np.isfinite(a["mvn"]).all(axis=0) & (a["status"] == 0) & (state["status"] == 0)
+    assert ok.mean() > 0.95 and np.array_equal(a["status"][ok], b["status"][ok])
+    e_mean, _, _ = parity.voxel_errors(h1, a, b, ok)
+    floor, _, _ = parity.voxel_errors(h1, a, oracle.run_fma(h1, y), ok)
+    print("exp(4) one step: median %.2e (CPU vs CPU %.2e), 90th pct %.2e (%.2e)"
+          % (np.median(e_mean), np.median(floor), np.quantile(e_mean, 0.9), np.quantile(floor, 0.9)))
+    assert np.median(e_mean) < max(1e-7, 3 * np.median(floor))
+    assert np.quantile(e_mean, 0.9) < max(1e-5, 3 * np.quantile(floor, 0.9))
+
+
 def test_postproc_images():
     h, y = cases.exp_problem(777, 100, 2, 0.02, seed=23, max_iterations=10)
     res = hipengine.run(h, y)

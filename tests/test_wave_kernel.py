@@ -71,7 +71,7 @@ def test_parameter_counts_without_a_lane_instantiation():
     y = X @ coef + rng.normal(0, 0.05, (T, V))
     assert h.cfg.n_params == 8
     hiplib.set_variant("auto")
-    assert hiplib.kernel_name(h) == "wave"  # no lane<linear,8>
+    assert hiplib.kernel_name(h) == "wave"  # (300 voxels: below the size at which "auto" takes lane<linear,8>)
     hiplib.set_variant("wave")
     check(h, y, what="linear P=8", check_f=True)
     # 16 regressors, 400 timepoints: 87 KB of LDS per voxel (above the 64 KB default limit)
