@@ -109,12 +109,29 @@ constexpr int WAVE_KERNEL_BELOW_VOXELS = 4096;
 
 LaneKernelInfo select_lane(const fvb_config *cfg)
 {
-    if (g_variant == 2 || cfg->n_phis != 1)
+    if (g_variant == 2 || (cfg->n_phis != 1 && (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis > 4)))
         return LaneKernelInfo{ nullptr, 0, nullptr };
     if (g_variant == 0 && cfg->noise == FVB_NOISE_WHITE && cfg->n_voxels < WAVE_KERNEL_BELOW_VOXELS
         && wave_layout(cfg->n_times, cfg->n_params, cfg->n_phis).bytes <= 160 * 1024)
         return LaneKernelInfo{ nullptr, 0, nullptr };
     const bool need_f = cfg->need_f != 0;
+    if (cfg->noise == FVB_NOISE_WHITE && cfg->n_phis > 1) // noise-pattern: 2 .. 4 precisions
+    {
+        if (cfg->n_times > 32768) // (the kernel keeps the class of every timepoint in LDS, one byte each)
+            return LaneKernelInfo{ nullptr, 0, nullptr };
+        const bool two = cfg->n_phis == 2;
+        switch (cfg->model)
+        {
+        case FVB_MODEL_POLY:
+            return two ? get_lane_pattern_kernel_poly_2(cfg->n_params) : get_lane_pattern_kernel_poly_4(cfg->n_params);
+        case FVB_MODEL_LINEAR:
+            return two ? get_lane_pattern_kernel_linear_2(cfg->n_params) : get_lane_pattern_kernel_linear_4(cfg->n_params);
+        case FVB_MODEL_EXP:
+            return two ? get_lane_pattern_kernel_exp_2(cfg->n_params) : get_lane_pattern_kernel_exp_4(cfg->n_params);
+        default:
+            return LaneKernelInfo{ nullptr, 0, nullptr };
+        }
+    }
     if (cfg->noise == FVB_NOISE_AR1)
     {
         switch (cfg->model)
@@ -382,7 +399,9 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
             FVB_HIP_CHECK(hipGetLastError());
             ka.tiles = tiles;
         }
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, stream, ka);
+        // (the several-precisions kernels keep the T class bytes of the noise pattern in dynamic LDS)
+        const size_t lds = (cfg->noise == FVB_NOISE_WHITE && cfg->n_phis > 1) ? (size_t)((cfg->n_times + 15) & ~15) : 0;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, ka);
         FVB_HIP_CHECK(hipGetLastError());
         if (tiles)
             FVB_HIP_CHECK(hipFreeAsync(tiles, stream));

@@ -29,7 +29,19 @@ LaneKernelInfo get_lane_kernel_wide(int model, int P, bool need_f); // P = 7, 8 
 LaneKernelInfo get_lane_ar_kernel_poly(int P, bool need_f);
 LaneKernelInfo get_lane_ar_kernel_linear(int P, bool need_f);
 LaneKernelInfo get_lane_ar_kernel_exp(int P, bool need_f);
+// white noise with several precisions (vb_lane_pattern_kernel.h): N = 2 or 4 moment sets, n_phis <= N used
+LaneKernelInfo get_lane_pattern_kernel_poly_2(int P);
+LaneKernelInfo get_lane_pattern_kernel_poly_4(int P);
+LaneKernelInfo get_lane_pattern_kernel_linear_2(int P);
+LaneKernelInfo get_lane_pattern_kernel_linear_4(int P);
+LaneKernelInfo get_lane_pattern_kernel_exp_2(int P);
+LaneKernelInfo get_lane_pattern_kernel_exp_4(int P);
 } // namespace fvb
+
+#define FVB_LANE_PATTERN_CASE(MODEL, TAG, PP, NN)                                                            \
+    case PP:                                                                                                 \
+        return LaneKernelInfo{ vb_lane_pattern_kernel<MODEL<PP>, PP, NN>, lane_pattern_save_rows<PP, NN>(),  \
+            "lane_phis<" TAG "," #PP "," #NN ">", nullptr, nullptr };
 
 #define FVB_LANE_CASE(MODEL, TAG, PP)                                                                        \
     case PP:                                                                                                 \

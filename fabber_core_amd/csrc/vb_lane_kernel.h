@@ -30,6 +30,9 @@
 // and a short pipeline win (C2: 1.42 ms vs 1.58 ms); from P = 3 the loop alone needs ~130 VGPRs,
 // three waves spill ~20 GB per launch and two waves with a deeper pipeline are both faster and
 // quieter on HBM (C3: 21.0 ms / 6 GB of spills vs 22.2 ms / 20 GB; C4 model 17.3 vs 18.6 ms).
+// From P = 7 one wave per SIMD with the whole 512-register file: two waves spill 450 - 2100 registers each,
+// one spills 10 - 140 and is 1.2 - 1.7 x faster (linear P = 7 / 8: 2.05 -> 1.76 / 4.22 -> 2.47 ms per 262144
+// voxels, four exponentials 6.0 -> 3.6 ms; for P <= 4 a single wave is 8 - 14 % slower).
 // FVB_LANE_WAVES_PER_SIMD / FVB_PREFETCH_DEPTH override both for experiments.
 namespace fvb
 {
@@ -39,7 +42,7 @@ constexpr int lane_waves()
 #ifdef FVB_LANE_WAVES_PER_SIMD
     return FVB_LANE_WAVES_PER_SIMD;
 #else
-    return P <= 2 ? 3 : 2;
+    return P <= 2 ? 3 : (P >= 7 ? 1 : 2);
 #endif
 }
 template <int P>

@@ -1,0 +1,21 @@
+// Instantiations of the several-precisions lane kernel (vb_lane_pattern_kernel.h) for the polynomial model (fwdmodel_poly.cc), 4 moment sets
+#include "vb_dispatch.h"
+#include "vb_lane_pattern_kernel.h"
+
+namespace fvb
+{
+LaneKernelInfo get_lane_pattern_kernel_poly_4(int P)
+{
+    switch (P)
+    {
+        FVB_LANE_PATTERN_CASE(PolyModel, "poly", 1, 4)
+        FVB_LANE_PATTERN_CASE(PolyModel, "poly", 2, 4)
+        FVB_LANE_PATTERN_CASE(PolyModel, "poly", 3, 4)
+        FVB_LANE_PATTERN_CASE(PolyModel, "poly", 4, 4)
+        FVB_LANE_PATTERN_CASE(PolyModel, "poly", 5, 4)
+        FVB_LANE_PATTERN_CASE(PolyModel, "poly", 6, 4)
+    default:
+        return LaneKernelInfo{ nullptr, 0, nullptr };
+    }
+}
+} // namespace fvb

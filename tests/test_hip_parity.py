@@ -380,6 +380,54 @@ def test_four_exponentials_on_the_lane_kernel():
     assert np.quantile(e_mean, 0.9) < max(1e-5, 3 * np.quantile(floor, 0.9))
 
 
+def _echo_noise(y, pattern, seed, sd=0.05):
+    """a different noise level per class of the pattern, so that the precisions differ"""
+    rng = np.random.default_rng(seed)
+    y = y.astype(np.float64)
+    pat = [int(c) for c in pattern]
+    for t in range(y.shape[0]):
+        y[t] += rng.normal(0, sd * pat[t % len(pat)], y.shape[1])
+    return y
+
+
+PATTERN_RUNS = {
+    "exp, two precisions, ragged": lambda: (cases.exp_problem(4096 + 77, 50, 1, 0.04, seed=3, max_iterations=8, noise_pattern="12", need_f=True), "12", "lane_phis<exp,2,2>", {}),
+    "bi-exponential start, three precisions": lambda: (cases.exp_problem(4200, 60, 2, 0.03, seed=4, max_iterations=2, noise_pattern="1231"), "1231", "lane_phis<exp,4,4>", {}),
+    "linear, four precisions, float series": lambda: (cases.linear_problem(5000, 64, seed=5, noise_pattern="1234", max_iterations=5, need_f=True), "1234", "lane_phis<linear,4,4>", dict(as_float=True)),
+    "F-reduction detector (save / revert)": lambda: (cases.poly_problem(4500, 24, 2, seed=6, noise_pattern="12", convergence="freduce", max_iterations=12, need_f=True), "12", "lane_phis<poly,3,2>", {}),
+    "trial mode + ARD": lambda: (cases.poly_problem(4500, 24, 1, seed=7, noise_pattern="112", convergence="trialmode", max_trials=3, max_iterations=12, need_f=True, param_overrides={"c1": dict(type="A")}), "112", "lane_phis<poly,2,2>", {}),
+    "Levenberg-Marquardt": lambda: (cases.exp_problem(4300, 50, 1, 0.04, seed=8, noise_pattern="12", convergence="lm", max_iterations=10, need_f=True), "12", "lane_phis<exp,2,2>", {}),
+    "masked timepoints, locked noise": lambda: (cases.poly_problem(4400, 20, 2, seed=9, noise_pattern="12", masked_timepoints=(3, 4, 11), locked_noise_stdev=0.08, max_iterations=5), "12", "lane_phis<poly,3,2>", {}),
+}
+
+
+@pytest.mark.parametrize("name", list(PATTERN_RUNS), ids=lambda s: s.replace(" ", "_"))
+def test_several_noise_precisions_on_the_lane_kernel(name):
+    """vb_lane_pattern_kernel.h (noise-pattern with 2 .. 4 precisions, noisemodel_white.cc:166-273) at sizes where
+    "auto" takes it, against the oracle - strict per-voxel parity, F where asked"""
+    (h, y), pattern, kernel, opts = PATTERN_RUNS[name]()
+    assert hiplib.kernel_name(h) == kernel
+    y = _echo_noise(y, pattern, seed=11)
+    if opts.get("as_float"):
+        y = y.astype(np.float32)
+    # (detectors that watch F: a voxel whose F change sits on the threshold may stop an iteration apart, as in
+    # test_convergence_detectors above)
+    uses_f = h.cfg.convergence != 0
+    check(h, y, what=name, check_f=bool(h.cfg.need_f), allow_floor=True, allow_iter_mismatch=h.cfg.n_voxels // 200 if uses_f else 0)
+
+
+def test_several_noise_precisions_continue_from_mvn():
+    """continue-from-mvn with the noise rows of a P + n_phis posterior (WhiteParams::InputFromMVN per precision)"""
+    h, y = cases.poly_problem(4300, 24, 2, seed=12, noise_pattern="123", max_iterations=3)
+    y = _echo_noise(y, "123", seed=13)
+    first = hipengine.run(h, y)
+    ref = oracle.run(h, y)
+    parity.strict(h, ref, first, what="first leg")
+    h2, _ = cases.poly_problem(4300, 24, 2, seed=12, noise_pattern="123", max_iterations=3, init_mvn=ref["mvn"])
+    assert hiplib.kernel_name(h2) == "lane_phis<poly,3,4>"
+    check(h2, y, what="continued", allow_floor=True)
+
+
 def test_postproc_images():
     h, y = cases.exp_problem(777, 100, 2, 0.02, seed=23, max_iterations=10)
     res = hipengine.run(h, y)

@@ -40,10 +40,13 @@ def test_models_against_oracle():
     assert check(h, y, what="linear")["rel_means"] < parity.NORTH_STAR
 
 
+@pytest.mark.parametrize("variant", ["wave", "lane"])
 @pytest.mark.parametrize("pattern", ["12", "123", "1122"])
-def test_noise_patterns_with_several_precisions(pattern):
+def test_noise_patterns_with_several_precisions(pattern, variant):
     """noise-pattern (noisemodel_white.cc:166-226): each digit selects the noise precision of
-    that timepoint, repeating; here with a masked timepoint as well."""
+    that timepoint, repeating; here with a masked timepoint as well. Both mappings: the wave kernel and
+    the lane kernel with per-precision moments (vb_lane_pattern_kernel.h)."""
+    hiplib.set_variant(variant)
     V, T = 400, 24
     rng = np.random.default_rng(5)
     h, y = cases.poly_problem(V, T, 2, seed=31, max_iterations=10, noise_pattern=pattern, masked_timepoints=(5,), need_f=True)
@@ -51,7 +54,12 @@ def test_noise_patterns_with_several_precisions(pattern):
     pat = [int(c) for c in pattern]
     for t in range(T):  # a different noise level per group so that the precisions differ
         y[t] += rng.normal(0, 0.05 * pat[t % len(pat)], V)
-    r = check(h, y, what="pattern " + pattern, check_f=True, allow_floor=(pattern == "1122"))  # four noise precisions: floor 1e-5
+    if variant == "lane":
+        assert hiplib.kernel_name(h) == "lane_phis<poly,3,%d>" % (2 if max(int(c) for c in pattern) == 2 else 4)
+        r = parity.strict(h, oracle.run(h, y), hipengine.run(h, y), cpu2=oracle.run_fma(h, y), what="pattern " + pattern,
+                          check_f=True, allow_floor=(pattern == "1122"))
+    else:
+        r = check(h, y, what="pattern " + pattern, check_f=True, allow_floor=(pattern == "1122"))  # four noise precisions: floor 1e-5
     n_phis = max(pat)
     assert h.cfg.n_phis == n_phis
     P = 3
