@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -274,6 +275,27 @@ double api_residual_tol()
 {
     return g_residual_tol;
 }
+// The current device's default memory pool keeps freed memory instead of returning it to the driver at the next
+// synchronisation (hipMallocAsync's default): work buffers of the size of the series are allocated by every run.
+void api_keep_pool_memory()
+{
+    static std::mutex lock;
+    static std::vector<int> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return;
+    std::lock_guard<std::mutex> hold(lock);
+    for (int d : done)
+        if (d == dev)
+            return;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+    {
+        uint64_t never = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
+    }
+    done.push_back(dev);
+}
 } // namespace fvb
 
 extern "C" {
@@ -299,6 +321,17 @@ int32_t fabber_vb_device_count(void)
 const char *fabber_vb_last_error(void)
 {
     return g_last_error.c_str();
+}
+
+void fabber_vb_release_cached_memory(void)
+{
+    int dev = 0;
+    hipMemPool_t pool;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+    {
+        (void)hipDeviceSynchronize();
+        (void)hipMemPoolTrimTo(pool, 0);
+    }
 }
 
 void fabber_vb_set_variant(int32_t variant)
@@ -356,6 +389,7 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
         return fail(-21, "data is NULL");
     if (cfg->noise == FVB_NOISE_AR1 && n_unmasked != cfg->n_times)
         return fail(-15, "Masked time points are not supported for the AR noise model"); // noisemodel_ar.cc:351-355
+    api_keep_pool_memory();
     KernelArgs ka;
     ka.cfg = *cfg;
     ka.out = *out;

@@ -84,6 +84,18 @@ struct SpatialArgs
     unsigned long long *sw_gran; // [n_spatial][n_pos][2] the means again as two self-validating 8-byte granules
                                  // {low / high half of the double, serial number of the sweep that wrote it}
     uint32_t sw_serial;      // this sweep's serial number (1, 2, ...; the buffer starts zeroed)
+    // ---- slab form of the split sweep (vb_spatial_slab_sweep_kernel): positions are slab-major, a slab = sl_dz
+    // z-planes, inside a slab level-major; sw_level_pos / sw_level_count then describe the RUNS (one slab's
+    // voxels of one level), sl_first_run[s] .. sl_first_run[s + 1] are slab s's, and a granule is the INBOX of its
+    // voxel: the mean of the z-1 neighbour when that lives in the slab below ----
+    int32_t sl_mode;         // 1 = slab form
+    int32_t n_slabs;
+    const int32_t *sl_first_run; // [n_slabs + 1]
+    int32_t sl_width;        // lanes that work on one run (a multiple of 64 that divides 1024)
+    int32_t sl_max_run;      // longest run (the LDS buffers hold two of them per spatial parameter)
+    int32_t sl_debug;        // timing experiments (wrong results): 1 = never wait for an inbox, 2 = never fetch another record,
+                             // 4 = no step, 8 = no stores
+    double *sw_nbr;          // [n_spatial][6][n_pos] the neighbours' means BEFORE the sweep (what a later neighbour contributes)
     uint32_t *sw_counter;    // (unused by the data-flow sweep; kept for the barrier variant)
     int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the
                              // sweep, a barrier timed out): the run is repeated with the per-level launches
@@ -579,9 +591,31 @@ __device__ __forceinline__ void store_sc1(double *p, double x)
 
 // A voxel that drops out in prep (the run is going to be repeated): hand its old means to the sweep with THIS
 // sweep's serial number, so that no neighbour waits for it.
-__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, uint32_t serial)
+__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, uint32_t serial, int v = -1)
 {
     const size_t NP = (size_t)sa.n_pos;
+    if (sa.sl_mode)
+    {
+        // slab form: the granules are inboxes - give every later neighbour's inbox this voxel's old mean
+        if (v < 0)
+            return;
+        const size_t V = (size_t)sa.ka.cfg.n_voxels;
+        for (int a = 0; a < 6; a++)
+        {
+            const int u = sa.nn[(size_t)v * 6 + a];
+            if (u < 0 || sa.pos_of[u] < pos)
+                continue;
+            for (int s = 0; s < sa.n_spatial; s++)
+            {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(sa.state[(size_t)sa.spatial_param[s] * V + v]);
+                unsigned long long *g = sa.sw_gran + ((size_t)s * NP + sa.pos_of[u]) * 2;
+                const unsigned long long now = (unsigned long long)serial << 32;
+                __hip_atomic_store(g, now | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, now | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
     for (int s = 0; s < sa.n_spatial; s++)
     {
         unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
@@ -647,11 +681,21 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
                 sa.sw_q[si * NP + pos] = pcov * spatial_prec;
                 sa.sw_rec[si * NP + pos] = 1 / double(nn);
                 sa.sw_x[si * NP + pos] = st.m[k];
-                // the mean as the sweep's neighbours read it: a value of the PREVIOUS sweep
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(st.m[k]);
-                const unsigned long long old = (unsigned long long)(serial - 1) << 32;
-                sa.sw_gran[((size_t)si * NP + pos) * 2] = old | (bits & 0xffffffffull);
-                sa.sw_gran[((size_t)si * NP + pos) * 2 + 1] = old | (bits >> 32);
+                if (sa.sl_mode)
+                {
+                    // what each neighbour contributes if the sweep reaches it AFTER this voxel: its mean now
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+                        sa.sw_nbr[((size_t)si * 6 + a) * NP + pos] = live1[a] ? sa.state[(size_t)(L::M + k) * V + n1[a]] : 0.0;
+                }
+                else
+                {
+                    // the mean as the sweep's neighbours read it: a value of the PREVIOUS sweep
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(st.m[k]);
+                    const unsigned long long old = (unsigned long long)(serial - 1) << 32;
+                    sa.sw_gran[((size_t)si * NP + pos) * 2] = old | (bits & 0xffffffffull);
+                    sa.sw_gran[((size_t)si * NP + pos) * 2 + 1] = old | (bits >> 32);
+                }
             }
             si++;
         }
@@ -700,7 +744,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         {
             sa.sw_flags[0] = 1;
             sa.sw_alive[pos] = 0;
-            sweep_release(sa, pos, serial);
+            sweep_release(sa, pos, serial, v);
             return;
         }
         (void)sk;
@@ -718,7 +762,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     {
         sa.sw_flags[0] = 1; // this voxel fails in the first sweep: not modelled here
         sa.sw_alive[pos] = 0;
-        sweep_release(sa, pos, serial);
+        sweep_release(sa, pos, serial, v);
         return;
     }
     si = 0;
@@ -950,6 +994,254 @@ __global__ __launch_bounds__(256) void vb_spatial_sweep_kernel(const SpatialArgs
     }
 }
 
+// ---- the ordered part, slab form ------------------------------------------------------------------------
+// The data-flow sweep above hands EVERY mean over through device-scope memory: 3.8 us per level, 382 levels
+// at 128^3. Here a workgroup owns a slab of sl_dz z-planes and walks the slab's levels in order; the means of
+// the previous level - the x-1, y-1 and (inside the slab) z-1 neighbours - are in LDS, a level costs a
+// workgroup barrier. Only the z-1 neighbours of a slab's lowest plane come from another workgroup: the slab
+// below writes them into the INBOX granule of the voxel that needs them (sc1 stores, self-validating as above)
+// and, since a voxel of level l needs its z-1 neighbour of level l-1, runs sl_dz - 1 levels ahead of what its
+// upper neighbour needs: the hand-over is off the critical path. The later neighbours (x+1, y+1, z+1)
+// contribute the means they had BEFORE the sweep; the prep kernel has put those next to the record (sw_nbr).
+// 1024 lanes = G groups of sl_width lanes; group g takes the runs g, g + G, ... of the slab and requests its
+// next record (and its inbox) right after finishing one: G levels of time to arrive.
+template <int P, int NS>
+struct SlabRecord
+{
+    int alive;
+    int np[6];
+    double rhs0[P];
+    double pprec[NS], q[NS], rec[NS];
+    double sig[NS][P];
+    double nbr[NS][6];
+    unsigned long long in_lo[NS], in_hi[NS];
+    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
+    {
+        const size_t NP = (size_t)sa.n_pos;
+        const bool have = pos >= 0;
+        pos = have ? pos : 0;
+        const int alive_word = sa.sw_alive[pos];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+            np[a] = sa.sw_npos[a * NP + pos];
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            rhs0[j] = sa.sw_rhs0[j * NP + pos];
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+            if (s < ns)
+            {
+                pprec[s] = sa.sw_pprec[s * NP + pos];
+                q[s] = sa.sw_q[s * NP + pos];
+                rec[s] = sa.sw_rec[s * NP + pos];
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    sig[s][j] = sa.sw_sig[((size_t)s * P + j) * NP + pos];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+                    nbr[s][a] = sa.sw_nbr[((size_t)s * 6 + a) * NP + pos];
+                const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
+                in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        alive = have ? alive_word : 0;
+    }
+};
+
+// A voxel whose z-1 neighbour lives in the slab below waits here until its inbox holds THIS sweep's value. The
+// inbox was requested with the record; a workgroup's groups reach their turn several levels early, so a value that
+// was not there yet is polled for while the levels before this one are still being worked on.
+template <int P, int NS>
+__device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecord<P, NS> &r, int pos, int ns, int slab_begin)
+{
+    if (!r.alive)
+        return;
+    bool from_below = false; // (at most one neighbour)
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+        from_below |= (r.np[a] >= 0) && (r.np[a] < slab_begin);
+    if (!from_below || (sa.sl_debug & 1))
+        return;
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
+            int spins = 0;
+#pragma nounroll
+            while ((r.in_lo[s] >> 32) != serial || (r.in_hi[s] >> 32) != serial)
+            {
+                if (++spins > (1 << 22)) // never (slabs start in order and every slab only waits for the one below)
+                {
+                    sa.sw_flags[0] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                r.in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r.in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+}
+
+// one voxel of the run [begin, begin + count): slot = its index in the run. prev_* = the slab's previous run
+// (its means are in lds_prev), slab_begin / slab_end = the slab's positions. Straight-line code: a workgroup has
+// two to eight waves at work on a level, so every instruction's latency is on the chain; the six neighbours are
+// selected, not branched on (a missing neighbour adds the +0.0 the prep kernel stored for it: x + 0.0 is x, and
+// the sum starts from +0.0, so it is the sum over the live neighbours bit for bit).
+// The part of a step that the NEXT level waits for: neighbours' means -> this voxel's mean in LDS. Returns the
+// means and prior means; slab_store writes them to memory after the level's barrier.
+template <int P, int NS>
+__device__ __forceinline__ void slab_step(const SpatialArgs &sa, SlabRecord<P, NS> &r, int pos, int slot, int ns, int prev_begin,
+    int prev_count, int slab_begin, const double *lds_prev, double *lds_cur, int lds_stride, double (&m_out)[NS], double (&pm_out)[NS])
+{
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+    double rhs[P];
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        rhs[j] = r.rhs0[j];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            const double val_in = __longlong_as_double((long long)((r.in_hi[s] << 32) | (r.in_lo[s] & 0xffffffffull)));
+            double from_lds[6];
+            bool in_prev[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+            {
+                const unsigned off = (unsigned)(r.np[a] - prev_begin);
+                in_prev[a] = off < (unsigned)prev_count;
+                from_lds[a] = lds_prev[s * lds_stride + (in_prev[a] ? (int)off : 0)];
+            }
+            double contrib = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+            {
+                const bool below = (r.np[a] >= 0) && (r.np[a] < slab_begin);
+                contrib += in_prev[a] ? from_lds[a] : (below ? val_in : r.nbr[s][a]);
+            }
+            const double spatial_mean = contrib * r.rec[s];
+            const double pm = r.q[s] * spatial_mean;
+            pm_out[s] = pm;
+            const int k = sa.spatial_param[s];
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                rhs[j] = (j == k) ? theta_rhs(rhs[j], r.pprec[s], pm) : rhs[j];
+        }
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            double m = 0;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                m = __builtin_fma(r.sig[s][j], rhs[j], m);
+            lds_cur[s * lds_stride + slot] = m;
+            m_out[s] = m;
+        }
+}
+
+// ... and the part nobody in the slab waits for: the mean into the inbox of the z+1 neighbour if that lives in the
+// slab above, mean and prior mean to memory for the kernels after this one
+template <int P, int NS>
+__device__ __forceinline__ void slab_store(const SpatialArgs &sa, const SlabRecord<P, NS> &r, int pos, int ns, int slab_end,
+    const double (&m)[NS], const double (&pm)[NS])
+{
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+    int above = -1;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+        above = (r.np[a] >= slab_end) ? r.np[a] : above;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            if (above >= 0)
+            {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(m[s]);
+                unsigned long long *g = sa.sw_gran + ((size_t)s * NP + above) * 2;
+                __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sa.sw_x[s * NP + pos] = m[s];
+            sa.sw_pm[s * NP + pos] = pm[s];
+        }
+}
+
+template <int P, int NS>
+__global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const SpatialArgs sa)
+{
+    extern __shared__ double s_mem[]; // [2][ns][sl_max_run] means of the last two runs, then the slab's run table
+    const int ns = sa.n_spatial;
+    const int W = sa.sl_width, G = 1024 / W;
+    const int g = threadIdx.x / W, lane = threadIdx.x % W; // (W is a multiple of 64: g is wave-uniform)
+    const int stride = sa.sl_max_run;
+    const int run0 = sa.sl_first_run[blockIdx.x], n_runs = sa.sl_first_run[blockIdx.x + 1] - run0;
+    int *tab = (int *)(s_mem + (size_t)2 * ns * stride); // [2][n_runs]: first position, count; then one counter
+    for (int i = threadIdx.x; i < n_runs; i += 1024)
+    {
+        tab[i] = sa.sw_level_pos[run0 + i];
+        tab[n_runs + i] = sa.sw_level_count[run0 + i];
+    }
+    if (threadIdx.x == 0)
+        tab[2 * n_runs] = 0; // `progress`, see below
+    __syncthreads();
+    if (n_runs == 0)
+        return;
+    const int slab_begin = tab[0], slab_end = tab[n_runs - 1] + tab[2 * n_runs - 1];
+    // No workgroup barrier per level: every wave would have to arrive, also the ones that are busy storing the last
+    // level's results and requesting their next records. A level is complete when each of the W / 64 waves of its
+    // group has added 1 to `progress` (LDS) after its means are in LDS; the group of the next level polls that
+    // counter - the only thing a level waits for is the level before it.
+    int *progress = tab + 2 * n_runs;
+    const int waves_per_group = W / 64;
+    SlabRecord<P, NS> r;
+    if (g < n_runs)
+        r.load(sa, lane < tab[n_runs + g] ? tab[g] + lane : -1, ns);
+    for (int li = g; li < n_runs; li += G)
+    {
+        const int begin = tab[li], count = tab[n_runs + li];
+        const int prev_begin = li > 0 ? tab[li - 1] : 0, prev_count = li > 0 ? tab[n_runs + li - 1] : 0;
+        const double *lds_prev = s_mem + (size_t)((li + 1) & 1) * ns * stride;
+        double *lds_cur = s_mem + (size_t)(li & 1) * ns * stride;
+        if (lane < count)
+            slab_wait_inbox<P, NS>(sa, r, begin + lane, ns, slab_begin);
+        // level li - 1 complete? (then level li - 2's means, which this level overwrites, have been read too)
+        const int need = li * waves_per_group;
+        while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        double m[NS], pm[NS];
+        const bool work = lane < count && r.alive;
+        if (work && !(sa.sl_debug & 4))
+            slab_step<P, NS>(sa, r, begin + lane, lane, ns, prev_begin, prev_count, slab_begin, lds_prev, lds_cur, stride, m, pm);
+        for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide: 1024 lanes, one group)
+        {
+            SlabRecord<P, NS> one;
+            one.load(sa, begin + i, ns);
+            if (!one.alive)
+                continue;
+            slab_wait_inbox<P, NS>(sa, one, begin + i, ns, slab_begin);
+            double m1[NS], pm1[NS];
+            slab_step<P, NS>(sa, one, begin + i, i, ns, prev_begin, prev_count, slab_begin, lds_prev, lds_cur, stride, m1, pm1);
+            slab_store<P, NS>(sa, one, begin + i, ns, slab_end, m1, pm1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // while the next group works: results to memory, then this group's next record
+        if (work && !(sa.sl_debug & 8))
+            slab_store<P, NS>(sa, r, begin + lane, ns, slab_end, m, pm);
+        const int nx = li + G;
+        if (nx < n_runs && !(sa.sl_debug & 2))
+            r.load(sa, lane < tab[n_runs + nx] ? tab[nx] + lane : -1, ns);
+    }
+}
+
 // ---- second sweep: UpdateNoise, ReCentre, F (inference_vb.cc:674-722), all voxels -------------
 template <class Model, int P, bool NEEDF, bool FAST = false>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(const SpatialArgs sa)
@@ -1100,6 +1392,7 @@ struct SpatialKernels
     SpatialPrepFn prep;
     SpatialSweepFn sweep[3]; // built for 1, 2 and up to P spatial parameters (what a lane keeps in registers grows with it)
     SpatialKernelFn noise_fast;
+    SpatialSweepFn slab_sweep[3]; // the slab form of the sweep, same three builds
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
@@ -1118,6 +1411,8 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
             { vb_spatial_sweep_kernel<PP, 1>, vb_spatial_sweep_kernel<PP, (PP < 2 ? PP : 2)>,                  \
                 vb_spatial_sweep_kernel<PP, PP> },                                                           \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true, true>                     \
-                   : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true> };
+                   : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true>,                   \
+            { vb_spatial_slab_sweep_kernel<PP, 1>, vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>,        \
+                vb_spatial_slab_sweep_kernel<PP, PP> } };
 
 } // namespace fvb

@@ -27,6 +27,7 @@ int api_fail(int code, const std::string &msg); // vb_api.hip
 int api_validate(const fvb_config *cfg, bool allow_spatial);
 int api_residual_mode();
 double api_residual_tol();
+void api_keep_pool_memory();
 }
 
 namespace
@@ -163,17 +164,23 @@ std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector
     return "";
 }
 
+// Device memory from the device's stream-ordered pool. The pool keeps what a run gives back (release threshold
+// set to "never" the first time), so a caller that runs volume after volume pays for its ~20 allocations once:
+// 4 ms per run of the 128^3 configuration with hipMalloc / hipFree.
 struct DevMem
 {
     void *p = nullptr;
+    hipStream_t stream = nullptr;
     ~DevMem()
     {
         if (p)
-            (void)hipFree(p);
+            (void)hipFreeAsync(p, stream);
     }
-    hipError_t alloc(size_t bytes)
+    hipError_t alloc(size_t bytes, hipStream_t s = nullptr)
     {
-        return hipMalloc(&p, bytes ? bytes : 8);
+        fvb::api_keep_pool_memory();
+        stream = s;
+        return hipMallocAsync(&p, bytes ? bytes : 8, s);
     }
 };
 
@@ -269,8 +276,8 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
         }                                                                                                    \
     } while (0)
     DevMem d_coords, d_scan, d_dense;
-    FVB_GEOM_CHECK(d_coords.alloc(sizeof(int32_t) * 3 * (size_t)V));
-    FVB_GEOM_CHECK(d_scan.alloc(sizeof(GeomScan)));
+    FVB_GEOM_CHECK(d_coords.alloc(sizeof(int32_t) * 3 * (size_t)V, stream));
+    FVB_GEOM_CHECK(d_scan.alloc(sizeof(GeomScan), stream));
     FVB_GEOM_CHECK(hipMemcpyAsync(d_coords.p, h_coords, sizeof(int32_t) * 3 * (size_t)V, hipMemcpyHostToDevice, stream));
     FVB_GEOM_CHECK(hipMemsetAsync(d_scan.p, 0, sizeof(GeomScan), stream));
     const unsigned blocks = (unsigned)std::min(1024, (V + 255) / 256);
@@ -292,7 +299,7 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
     const long long span = last - first + 1;
     if (span <= 0 || span > std::max<long long>(64LL * V, 1 << 20))
         return 1;
-    FVB_GEOM_CHECK(d_dense.alloc(sizeof(int32_t) * (size_t)span));
+    FVB_GEOM_CHECK(d_dense.alloc(sizeof(int32_t) * (size_t)span, stream));
     FVB_GEOM_CHECK(hipMemsetAsync(d_dense.p, 0xff, sizeof(int32_t) * (size_t)span, stream)); // -1
     const unsigned grid = (unsigned)((V + 255) / 256);
     hipLaunchKernelGGL(geom_dense_kernel, dim3(grid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, xsize, ysize, first,
@@ -328,7 +335,9 @@ struct fvb_spatial_run
     // the split first sweep (vb_spatial.h): whole-volume runs with first-neighbour priors (types M, m)
     bool allow_fast = false, fast = false;
     std::vector<int32_t> level_begin_counts; // voxels per level
-    DevMem d_pos_of, d_level_pos, d_level_count, d_sw_f64, d_sw_i32, d_sw_sync, d_sw_gran;
+    DevMem d_pos_of, d_level_pos, d_level_count, d_sw_f64, d_sw_i32, d_sw_sync, d_sw_gran, d_slab_first;
+    int max_runs_per_slab = 0;
+    bool slab_form = false; // the sweep's workgroups own z-slabs (vb_spatial_slab_sweep_kernel), else the data-flow sweep
     int sweep_fast(int it);
     int fast_failed(bool &failed);
 
@@ -373,14 +382,14 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         k = get_spatial_kernels_exp(P, need_f);
         break;
     default:
-        k = SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+        k = SpatialKernels{};
     }
     if (!k.setup)
         return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
 
     // ---- geometry: neighbour table on the device where the geometry allows, else on the host ----
     const auto t_start = std::chrono::steady_clock::now();
-    FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6));
+    FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6, stream));
     std::string err;
     const int on_device = (V > 0 && !getenv("FVB_SPATIAL_HOST_GEOMETRY"))
         ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err) : 1;
@@ -516,10 +525,90 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             spatial_param[n_spatial++] = kk;
     fast = allow_fast && has_spatial && !second_neighbours && owned_begin == 0 && owned_end == V && n_owned > 0
         && !getenv("FVB_SPATIAL_PER_LEVEL") && level_begin.size() <= 6000; // (the sweep keeps the level table in LDS)
-    std::vector<int32_t> pos_of, level_pos, level_count;
-    int n_pos = 0;
-    if (fast)
+    std::vector<int32_t> pos_of, level_pos, level_count, slab_first;
+    int n_pos = 0, sl_width = 64, sl_max_run = 0, sl_dz = 0;
+    slab_form = false;
+    if (fast && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll")) && lmax - lmin < (1LL << 22))
     {
+        // Slab-major numbering: a slab = dz z-planes, inside a slab the voxels level by level (index order in a
+        // level). dz: as few planes as keep the slabs within the chip's workgroups (every slab is one resident
+        // workgroup): one plane per slab up to 192 planes. Thicker slabs mean fewer hand-overs between workgroups
+        // (2.4 us each, one after the other) but longer runs and fewer groups per workgroup to hide the records'
+        // latency: measured at 128^3, 0.52 ms per sweep with dz = 1, 0.55 with 2, 0.87 with 4.
+        int zmin = Z[owned_begin], zmax = Z[owned_begin];
+        for (int v = owned_begin; v < owned_end; v++)
+        {
+            zmin = std::min(zmin, (int)Z[v]);
+            zmax = std::max(zmax, (int)Z[v]);
+        }
+        const long long nz = (long long)zmax - zmin + 1;
+        long long dz = std::max(1LL, (nz + 191) / 192);
+        if (const char *forced = getenv("FVB_SPATIAL_SLAB_DZ"))
+            dz = std::max((nz + 191) / 192, (long long)std::max(1, atoi(forced)));
+        const long long n_slabs = (nz + dz - 1) / dz;
+        const size_t nl = (size_t)(lmax - lmin + 1);
+        if (sp.spatial_dims <= 3 && n_slabs * (long long)nl <= (1LL << 21))
+        {
+            const size_t nk = (size_t)n_slabs * nl;
+            auto key_of = [&](int i) -> size_t {
+                return (size_t)((Z[owned_begin + i] - zmin) / dz) * nl + (size_t)(level_of(i) - lmin);
+            };
+            std::vector<std::vector<int32_t> > count(nt, std::vector<int32_t>(nk, 0));
+            parallel([&](int t) {
+                int32_t *c = count[t].data();
+                for (int i = chunk(t); i < chunk(t + 1); i++)
+                    c[key_of(i)]++;
+            });
+            slab_first.assign((size_t)n_slabs + 1, 0);
+            int32_t running = 0;
+            for (size_t key = 0; key < nk; key++)
+            {
+                if (key % nl == 0)
+                    slab_first[key / nl] = (int32_t)level_pos.size();
+                const int32_t begin = running;
+                for (int t = 0; t < nt; t++) // thread order = index order
+                {
+                    const int32_t n = count[t][key];
+                    count[t][key] = running;
+                    running += n;
+                }
+                if (running > begin)
+                {
+                    level_pos.push_back(begin);
+                    level_count.push_back(running - begin);
+                    sl_max_run = std::max(sl_max_run, (int)(running - begin));
+                }
+            }
+            slab_first[(size_t)n_slabs] = (int32_t)level_pos.size();
+            if (sl_max_run <= 8192 && n_slabs <= 224)
+            {
+                pos_of.assign((size_t)V, 0);
+                parallel([&](int t) {
+                    int32_t *c = count[t].data();
+                    for (int i = chunk(t); i < chunk(t + 1); i++)
+                        pos_of[(size_t)owned_begin + i] = c[key_of(i)]++;
+                });
+                n_pos = (n_owned + 15) / 16 * 16;
+                // lanes per run: the next power of two from 64 that holds the longest run, 1024 at most
+                while (sl_width < sl_max_run && sl_width < 1024)
+                    sl_width *= 2;
+                if (const char *forced = getenv("FVB_SPATIAL_SLAB_WIDTH")) // tests: lanes that take several voxels of a run
+                    sl_width = std::max(64, std::min(1024, atoi(forced) / 64 * 64));
+                sl_dz = (int)dz;
+                slab_form = true;
+                level_begin_counts = level_count;
+            }
+            else
+            {
+                level_pos.clear();
+                level_count.clear();
+                sl_max_run = 0;
+            }
+        }
+    }
+    if (fast && !slab_form)
+    {
+        // level-major numbering for the data-flow sweep
         // every level starts on a multiple of 16 positions: a wave's 64 consecutive doubles are whole 128-byte lines
         const size_t nl = level_begin.size() - 1;
         level_pos.resize(nl);
@@ -547,15 +636,15 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     seg_start.push_back(owned_end);
     const int n_blocks = (int)seg_start.size() - 1;
     n_segments = n_blocks;
-    FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V));
-    FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * order.size()));
-    FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS));
-    FVB_HIP_CHECK(d_sums.alloc(sizeof(double) * FVB_MAX_PARAMS * 2));
-    FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)std::max(n_blocks, 1) * P * 2));
-    FVB_HIP_CHECK(d_seg_start.alloc(sizeof(int32_t) * seg_start.size()));
+    FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V, stream));
+    FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * order.size(), stream));
+    FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS, stream));
+    FVB_HIP_CHECK(d_sums.alloc(sizeof(double) * FVB_MAX_PARAMS * 2, stream));
+    FVB_HIP_CHECK(d_partials.alloc(sizeof(double) * (size_t)std::max(n_blocks, 1) * P * 2, stream));
+    FVB_HIP_CHECK(d_seg_start.alloc(sizeof(int32_t) * seg_start.size(), stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_seg_start.p, seg_start.data(), sizeof(int32_t) * seg_start.size(), hipMemcpyHostToDevice, stream));
-    FVB_HIP_CHECK(d_fprior.alloc(sizeof(double)));
-    FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V));
+    FVB_HIP_CHECK(d_fprior.alloc(sizeof(double), stream));
+    FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V, stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, stream));
     double aK0[FVB_MAX_PARAMS];
     for (int i = 0; i < FVB_MAX_PARAMS; i++)
@@ -593,18 +682,18 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     if (fast)
     {
         const size_t NP = (size_t)n_pos, ns = (size_t)n_spatial;
-        FVB_HIP_CHECK(d_pos_of.alloc(sizeof(int32_t) * (size_t)V));
-        FVB_HIP_CHECK(d_level_pos.alloc(sizeof(int32_t) * level_pos.size()));
-        FVB_HIP_CHECK(d_level_count.alloc(sizeof(int32_t) * level_count.size()));
+        FVB_HIP_CHECK(d_pos_of.alloc(sizeof(int32_t) * (size_t)V, stream));
+        FVB_HIP_CHECK(d_level_pos.alloc(sizeof(int32_t) * level_pos.size(), stream));
+        FVB_HIP_CHECK(d_level_count.alloc(sizeof(int32_t) * level_count.size(), stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_pos_of.p, pos_of.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_pos.p, level_pos.data(), sizeof(int32_t) * level_pos.size(), hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_count.p, level_count.data(), sizeof(int32_t) * level_count.size(), hipMemcpyHostToDevice, stream));
-        // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]
-        const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P) * NP;
-        FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64));
-        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * 7 * NP)); // npos [6][NP], alive [NP]
-        FVB_HIP_CHECK(d_sw_sync.alloc(64));                      // counter, flags[2]
-        FVB_HIP_CHECK(d_sw_gran.alloc(sizeof(unsigned long long) * 2 * ns * NP));
+        // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; slab form: nbr [ns][6][NP]
+        const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P + (slab_form ? 6 * ns : 0)) * NP;
+        FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64, stream));
+        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * 7 * NP, stream)); // npos [6][NP], alive [NP]
+        FVB_HIP_CHECK(d_sw_sync.alloc(64, stream));                      // counter, flags[2]
+        FVB_HIP_CHECK(d_sw_gran.alloc(sizeof(unsigned long long) * 2 * ns * NP, stream));
         FVB_HIP_CHECK(hipMemsetAsync(d_sw_gran.p, 0, sizeof(unsigned long long) * 2 * ns * NP, stream));
         sa.sw_gran = (unsigned long long *)d_sw_gran.p;
         sa.sw_serial = 0;
@@ -619,6 +708,21 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sw_rec = f + 4 * ns * NP;
         sa.sw_rhs0 = f + 5 * ns * NP;
         sa.sw_sig = f + (5 * ns + (size_t)P) * NP;
+        if (slab_form)
+        {
+            sa.sw_nbr = f + (5 * ns + (size_t)P + ns * (size_t)P) * NP;
+            FVB_HIP_CHECK(d_slab_first.alloc(sizeof(int32_t) * slab_first.size(), stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(d_slab_first.p, slab_first.data(), sizeof(int32_t) * slab_first.size(), hipMemcpyHostToDevice, stream));
+            sa.sl_mode = 1;
+            sa.n_slabs = (int32_t)slab_first.size() - 1;
+            sa.sl_first_run = (const int32_t *)d_slab_first.p;
+            sa.sl_width = sl_width;
+            sa.sl_max_run = sl_max_run;
+            sa.sl_debug = getenv("FVB_SLAB_DEBUG") ? atoi(getenv("FVB_SLAB_DEBUG")) : 0;
+            max_runs_per_slab = 0;
+            for (size_t b = 0; b + 1 < slab_first.size(); b++)
+                max_runs_per_slab = std::max(max_runs_per_slab, (int)(slab_first[b + 1] - slab_first[b]));
+        }
         sa.sw_npos = (int32_t *)d_sw_i32.p;
         sa.sw_alive = (int32_t *)d_sw_i32.p + 6 * NP;
         sa.sw_counter = (uint32_t *)d_sw_sync.p;
@@ -645,7 +749,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     sa.ka.n_unmasked = n_unmasked;
     // the argument block the per-level launches read (nothing in it changes per launch)
-    FVB_HIP_CHECK(d_sa.alloc(sizeof(SpatialArgs)));
+    FVB_HIP_CHECK(d_sa.alloc(sizeof(SpatialArgs), stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_sa.p, &sa, sizeof(SpatialArgs), hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(hipStreamSynchronize(stream)); // `sa`, nn, order are pageable host memory
 
@@ -730,6 +834,18 @@ int fvb_spatial_run::sweep_fast(int it)
     sa.sw_serial++; // this sweep's number
     const int n_owned = owned_end - owned_begin;
     hipLaunchKernelGGL(k.prep, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
+    const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
+    if (slab_form)
+    {
+        // one workgroup of 1024 lanes per slab (at most 224: resident together on any MI355X)
+        const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
+        if (lds > 48 * 1024)
+            FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k.slab_sweep[which], dim3((unsigned)sa.n_slabs), dim3(1024), lds, stream, sa);
+        hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
+        FVB_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     // few workgroups, all resident at once on any MI355X (256 CUs): the level barrier is a counter
     const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
     const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane

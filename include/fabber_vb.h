@@ -377,6 +377,12 @@ int32_t fabber_nlls_run_device(const fvb_config *cfg, const fvb_nlls *nl, const 
 int32_t fabber_nlls_run_host(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
     int32_t device);
 
+/* The engine's work buffers (the re-laid series, the spatial run's state) come from the current device's
+ * stream-ordered memory pool, which keeps them between runs (a caller that fits volume after volume allocates
+ * once). This returns what the pool holds to the driver; the reference has no counterpart (host memory, freed by
+ * the run). */
+void fabber_vb_release_cached_memory(void);
+
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);
 

@@ -415,8 +415,37 @@ def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch)
         h, sp0, y, bad = failing_voxel_problem("M", need_f=False)
         coords = sp0.coords
     sp = vbabi.SpatialHolder(coords, **sp_kw)
-    split = hiplib.run_spatial_host(h, sp, y)
+    # the forms of the ordered part: workgroups that own z-slabs of 1 / 2 / 3 planes (previous level in LDS, inbox
+    # hand-over between slabs; the default picks the thickness from the volume) and the data-flow sweep of round 2
+    forms = {}
+    for name, env in (("default", {}), ("slabs of 1", {"FVB_SPATIAL_SLAB_DZ": "1"}), ("slabs of 2", {"FVB_SPATIAL_SLAB_DZ": "2"}),
+                      ("slabs of 3", {"FVB_SPATIAL_SLAB_DZ": "3"}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        forms[name] = hiplib.run_spatial_host(h, sp, y)
+        for k in env:
+            monkeypatch.delenv(k)
     monkeypatch.setenv("FVB_SPATIAL_PER_LEVEL", "1")
     per_level = hiplib.run_spatial_host(h, sp, y)
-    for k in ("mvn", "status", "iterations", "free_energy"):
-        assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, k)
+    for name, split in forms.items():
+        for k in ("mvn", "status", "iterations", "free_energy"):
+            assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, name, k)
+
+
+@gpu
+def test_slab_sweep_with_runs_longer_than_a_workgroup(monkeypatch):
+    """a 40 x 40 x 3 volume swept as ONE slab of three planes: its longest run (the voxels of one level) has more
+    than 64 voxels, and with FVB_SPATIAL_SLAB_WIDTH=64 the group's lanes take several voxels each"""
+    mask, coords = masked_volume((40, 40, 3), seed=35, keep=0.97)
+    _, y = smooth_exp_data(coords, 30, 0.04, seed=36)
+    h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 30, num_exps=1, dt=0.04, max_iterations=4, param_overrides={"amp1": dict(type="M")})
+    sp = vbabi.SpatialHolder(coords)
+    monkeypatch.setenv("FVB_SPATIAL_SLAB_DZ", "3")
+    monkeypatch.setenv("FVB_SPATIAL_SLAB_WIDTH", "64")
+    slab = hiplib.run_spatial_host(h, sp, y)
+    monkeypatch.delenv("FVB_SPATIAL_SLAB_WIDTH")
+    wide = hiplib.run_spatial_host(h, sp, y)
+    monkeypatch.setenv("FVB_SPATIAL_PER_LEVEL", "1")
+    per_level = hiplib.run_spatial_host(h, sp, y)
+    for k in ("mvn", "status", "iterations"):
+        assert np.array_equal(slab[k], per_level[k], equal_nan=True) and np.array_equal(wide[k], per_level[k], equal_nan=True), k
