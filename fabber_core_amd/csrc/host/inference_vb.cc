@@ -527,6 +527,26 @@ void Vb::DoCalculations(FabberRunData &rundata)
     const int device = device_list.empty() ? rundata.GetIntDefault("device", 0, 0) : device_list[0];
     const Matrix &coords = rundata.GetVoxelCoords();
     int rc;
+    // a model evaluated on the host: one model instance per host thread (host-model-threads, default: the
+    // hardware's, at most 16)
+    HostModelContext ctx = { this, m_model, &rundata, &data, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
+    std::vector<std::unique_ptr<FwdModel> > copies;
+    auto prepare_host_model = [&]() {
+        int nthreads = rundata.GetIntDefault("host-model-threads", 0, 0, 256);
+        if (nthreads == 0)
+            nthreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+        ctx.models.push_back(m_model);
+        for (int k = 1; k < nthreads; k++)
+        {
+            copies.emplace_back(FwdModel::NewFromName(rundata.GetString("model")));
+            copies.back()->SetLogger(m_log);
+            copies.back()->Initialize(rundata);
+            vector<Parameter> tmp;
+            copies.back()->GetParameters(rundata, tmp); // resolves the transforms EvaluateFabber applies
+            ctx.models.push_back(copies.back().get());
+        }
+        LOG << "Vb::Model evaluations on " << nthreads << " host thread(s)" << endl;
+    };
     if (m_locked_linear)
     {
         // In the voxelwise loop the locked centres only serve the set-up re-centre, which the loop
@@ -567,33 +587,30 @@ void Vb::DoCalculations(FabberRunData &rundata)
         LOG << "Vb::Spatial calculations on the MI355X engine, " << m_nvoxels << " voxels x " << cfg.n_times
             << " timepoints, " << cfg.max_iterations << " iterations" << endl;
         s_progress_rundata = &rundata;
-        rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
+        if (m_store->has_device_model)
+            rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
+        else
+        {
+            // any FwdModel under spatial VB, as in the reference: the model's two re-centres per iteration
+            // run here on the host, the sweeps on the device (fabber_vb_run_spatial_hostmodel_host)
+            LOG << "Vb::the model is evaluated on the host" << endl;
+            BuildInitialMvn(rundata, cfg);
+            prepare_host_model();
+            rc = fabber_vb_run_spatial_hostmodel_host(&cfg, &sp, data.Store(), &out, device, &Vb::LineariseCallback, &ctx, spatial_progress);
+            if (rc == -54 && ctx.error != "")
+            {
+                s_progress_rundata = NULL;
+                throw FabberInternalError(ctx.error);
+            }
+        }
         s_progress_rundata = NULL;
     }
     else if (!m_store->has_device_model)
     {
-        if (IsSpatial(rundata))
-            throw FabberInternalError("Spatial VB needs a model with a device body (FwdModel::GetDeviceModel)");
         LOG << "Vb::Voxelwise calculations on the MI355X engine with the model evaluated on the host, " << m_nvoxels
             << " voxels x " << cfg.n_times << " timepoints" << endl;
         BuildInitialMvn(rundata, cfg);
-        HostModelContext ctx = { this, m_model, &rundata, &data, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
-        // one model instance per host thread (host-model-threads, default: the hardware's, at most 16)
-        int nthreads = rundata.GetIntDefault("host-model-threads", 0, 0, 256);
-        if (nthreads == 0)
-            nthreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-        std::vector<std::unique_ptr<FwdModel> > copies;
-        ctx.models.push_back(m_model);
-        for (int k = 1; k < nthreads; k++)
-        {
-            copies.emplace_back(FwdModel::NewFromName(rundata.GetString("model")));
-            copies.back()->SetLogger(m_log);
-            copies.back()->Initialize(rundata);
-            vector<Parameter> tmp;
-            copies.back()->GetParameters(rundata, tmp); // resolves the transforms EvaluateFabber applies
-            ctx.models.push_back(copies.back().get());
-        }
-        LOG << "Vb::Model evaluations on " << nthreads << " host thread(s)" << endl;
+        prepare_host_model();
         rc = fabber_vb_run_hostmodel_host(&cfg, data.Store(), &out, device, &Vb::LineariseCallback, &ctx);
         if (rc == -54 && ctx.error != "")
             throw FabberInternalError(ctx.error);

@@ -32,6 +32,10 @@ struct ModelArgs
     int32_t iopt0;        // poly: degree; exp: number of exponentials
     double dopt0;         // exp: dt
     const double *design; // linear: [T][P] row-major
+    // host-evaluated models (HostLinModel below): THIS voxel's linearisation, g [lin_T] then J [lin_T][P], as
+    // the host's model code computed it about the centre the caller is working with
+    const double *lin;
+    int32_t lin_T;
 };
 
 // A "sweep" produces, for t = 0, 1, 2, ... in order, the 2P + 1 predictions the central
@@ -181,6 +185,7 @@ struct LinearInParameterSweep
 template <int P>
 struct PolyModel
 {
+    static constexpr bool host_evaluated = false;
     static constexpr int model_id = FVB_MODEL_POLY;
     typedef LinearInParameterSweep<PolyModel<P>, P> Sweep;
     // d f / d p_n at timepoint t (the model is linear in every parameter)
@@ -215,6 +220,7 @@ struct PolyModel
 template <int P>
 struct LinearModel
 {
+    static constexpr bool host_evaluated = false;
     static constexpr int model_id = FVB_MODEL_LINEAR;
     typedef LinearInParameterSweep<LinearModel<P>, P> Sweep;
     static FVB_HD double basis(const ModelArgs &a, int t, int n)
@@ -241,6 +247,7 @@ struct LinearModel
 template <int P>
 struct ExpModel
 {
+    static constexpr bool host_evaluated = false;
     static_assert(P % 2 == 0, "exp model has 2 parameters per exponential");
     static constexpr int model_id = FVB_MODEL_EXP;
     static FVB_HD double eval(const ModelArgs &a, int t, const double (&p)[P])
@@ -441,6 +448,49 @@ struct ExpModel
 #pragma unroll
             for (int i = 0; i < P; i++)
                 J[i] = (f2[i] - f3[i]) * rden[i];
+        }
+    };
+};
+
+// A model that exists only as host code (a FwdModel subclass of a model library written for the reference,
+// cfg.model = FVB_MODEL_HOSTJAC): the host evaluates it - the 2P + 1 predictions of
+// LinearizedFwdModel::ReCentre (fwdmodel_linear.cc:126-182) - and hands over g and J; the "sweep" of such
+// a model reads them back, so that everything built on sweeps (the streaming moments, the directly summed
+// residual) works unchanged. Which linearisation ma.lin points to (the one about the centre being asked for)
+// is the calling kernel's business.
+template <int P>
+struct HostLinModel
+{
+    static constexpr bool host_evaluated = true;
+    static constexpr int model_id = FVB_MODEL_HOSTJAC;
+    static constexpr bool needs_data_max = false;
+    static FVB_HD void init_posterior(const ModelArgs &, double, double (&)[P])
+    {
+    }
+    // (pointwise evaluation at arbitrary parameters is what such a model cannot do on the device; only the
+    // wave-cooperative rescue of the tile-fed lane kernels asks for it, and no host-model route uses those)
+    static FVB_HD double eval(const ModelArgs &, int, const double (&)[P])
+    {
+        return __builtin_nan("");
+    }
+    struct Sweep
+    {
+        const double *g_row, *j_rows;
+        FVB_HD void init(const ModelArgs &a, const double (&)[P], const double (&)[P], const double (&)[P])
+        {
+            g_row = a.lin;
+            j_rows = a.lin + a.lin_T;
+        }
+        FVB_HD void set_precise(bool)
+        {
+        }
+        FVB_HD void eval_jac(const ModelArgs &, int t, const double (&)[P], const double (&)[P], const double (&)[P],
+            const double (&)[P], double &g, double (&J)[P])
+        {
+            g = g_row[t];
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                J[i] = j_rows[(size_t)t * P + i];
         }
     };
 };

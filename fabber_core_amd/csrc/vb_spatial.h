@@ -64,6 +64,9 @@ struct SpatialArgs
     int32_t owned_begin, owned_end;
     int32_t n_voxels_global; // the V of h_K = V/2 + q2 (priors.cc:321)
     double *ak_sums;         // [P][2] (trace_term, term2): this slab's, then the all-reduced ones
+    // host-evaluated models (HostLinModel): [V][n_times * (P + 1)] linearisations, g then J per voxel - about the
+    // centre the moments in the state belong to (lin_cur) and about the means the second sweep re-centres on (lin_next)
+    const double *lin_cur, *lin_next;
     // ---- the split first sweep (SweepPlan below); NULL / 0 when the per-level launches are used ----
     const int32_t *pos_of;   // [V] position of a voxel in the level-major numbering
     int32_t n_pos;           // positions, every level padded to a multiple of 16
@@ -249,6 +252,11 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
     {
         st.pm[i] = 0;
         st.pprec[i] = 1;
+    }
+    if (Model::host_evaluated)
+    {
+        ma.lin_T = T;
+        ma.lin = sa.lin_next + (size_t)v * T * (P + 1);
     }
     const int status = recentre<Model, P>(ka, ma, v, st.m, mo, true);
     sa.status[v] = status ? (status | 0x100) : 0;
@@ -1315,8 +1323,15 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
         }
     }
     double kk, trSA;
+    if (Model::host_evaluated) // the residual about the centre the moments belong to ...
+    {
+        ma.lin_T = ka.cfg.n_times;
+        ma.lin = sa.lin_cur + (size_t)v * ka.cfg.n_times * (P + 1);
+    }
     residual_and_trace<Model, P>(ka, ma, v, st, mo, kk, trSA);
     update_noise<P>(ka, st, kk, trSA);
+    if (Model::host_evaluated) // ... and the re-centre about the means of this iteration's first sweep
+        ma.lin = sa.lin_next + (size_t)v * ka.cfg.n_times * (P + 1);
     int status = recentre<Model, P>(ka, ma, v, st.m, mo);
     if (status == FVB_OK && NEEDF)
     {
@@ -1397,6 +1412,7 @@ struct SpatialKernels
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
 SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
+SpatialKernels get_spatial_kernels_host(int P, bool need_f); // models evaluated on the host (HostLinModel)
 
 #define FVB_SPATIAL_CASE(MODEL, TAG, PP)                                                                     \
     case PP:                                                                                                 \

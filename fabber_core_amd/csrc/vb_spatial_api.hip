@@ -340,6 +340,8 @@ struct fvb_spatial_run
     bool slab_form = false; // the sweep's workgroups own z-slabs (vb_spatial_slab_sweep_kernel), else the data-flow sweep
     int sweep_fast(int it);
     int fast_failed(bool &failed);
+    // host-evaluated models: the linearisations the set-up re-centre reads (see HostLin below)
+    const double *lin_cur = nullptr, *lin_next = nullptr;
 
     int open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out, hipStream_t stream_);
     int ak_sums(double *host_sums);
@@ -380,6 +382,9 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         break;
     case FVB_MODEL_EXP:
         k = get_spatial_kernels_exp(P, need_f);
+        break;
+    case FVB_MODEL_HOSTJAC:
+        k = get_spatial_kernels_host(P, need_f);
         break;
     default:
         k = SpatialKernels{};
@@ -655,6 +660,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     FVB_HIP_CHECK(hipMemsetAsync(d_partials.p, 0, sizeof(double) * (size_t)std::max(n_blocks, 1) * P * 2, stream));
 
     memset(&sa, 0, sizeof(sa));
+    sa.lin_cur = lin_cur;
+    sa.lin_next = lin_next;
     sa.ka.cfg = cfg;
     sa.ka.out = *d_out;
     sa.ka.data = d_data;
@@ -912,8 +919,75 @@ int fvb_spatial_run::finish()
 
 namespace
 {
+// A model that is evaluated on the host (FVB_MODEL_HOSTJAC) under spatial VB: the two places of the loop that
+// run the model - the set-up re-centre and the re-centre that ends every iteration's second sweep
+// (inference_vb.cc:235,695) - become a call of the caller's linearisation callback for the voxels still
+// taking part, about the means the first sweep left, and an upload of g and J; the kernels read them through
+// HostLinModel. Two device buffers [V][T (P + 1)]: the second sweep needs the linearisation about the OLD
+// centre for k = y - g + J (centre - mean) next to the new one.
+struct HostLin
+{
+    fvb_linearise_fn linearise = nullptr;
+    void *user = nullptr;
+    const double *init_means = nullptr; // host, [V][P]: the centres of the set-up re-centre
+    size_t V = 0, T = 0;
+    int P = 0;
+    DevMem buf[2];
+    int cur = 0; // buf[cur] belongs to the moments in the state
+    std::vector<double> lin, means_rows, means;
+    std::vector<int32_t> status, ids;
+    size_t stride() const
+    {
+        return T * (size_t)(P + 1);
+    }
+    int open(const fvb_config *cfg, hipStream_t stream)
+    {
+        V = (size_t)cfg->n_voxels;
+        T = (size_t)cfg->n_times;
+        P = cfg->n_params;
+        const double bytes = (double)V * stride() * sizeof(double);
+        if (bytes > 48e9)
+            return api_fail(-55, "host-evaluated model under spatial VB: two linearisation buffers of " + std::to_string((long long)(bytes / 1e9))
+                + " GB each do not fit the budget (48 GB each)");
+        for (int i = 0; i < 2; i++)
+            FVB_HIP_CHECK(buf[i].alloc(sizeof(double) * V * stride(), stream));
+        lin.resize(V * stride());
+        return 0;
+    }
+    // g and J of the voxels with status 0 about means [V][P] (voxel-major) into buf[which]
+    int relinearise(const double *centres, const int32_t *voxel_status, int which, hipStream_t stream)
+    {
+        ids.clear();
+        for (size_t v = 0; v < V; v++)
+            if (!voxel_status || voxel_status[v] == 0)
+                ids.push_back((int32_t)v);
+        if (ids.empty())
+            return 0;
+        const bool all = ids.size() == V;
+        const double *active = centres;
+        if (!all)
+        {
+            means.resize(ids.size() * (size_t)P);
+            for (size_t a = 0; a < ids.size(); a++)
+                for (int i = 0; i < P; i++)
+                    means[a * P + i] = centres[(size_t)ids[a] * P + i];
+            active = means.data();
+        }
+        const int cb = linearise(user, (int32_t)ids.size(), ids.data(), active, lin.data());
+        if (cb != 0)
+            return api_fail(-54, "the model's linearisation callback failed (code " + std::to_string(cb) + ")");
+        if (!all) // spread the active voxels' blocks out to their own places (back to front: in place)
+            for (size_t a = ids.size(); a-- > 0;)
+                if ((size_t)ids[a] != a)
+                    memmove(lin.data() + (size_t)ids[a] * stride(), lin.data() + a * stride(), sizeof(double) * stride());
+        FVB_HIP_CHECK(hipMemcpyAsync(buf[which].p, lin.data(), sizeof(double) * V * stride(), hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
+    }
+};
+
 int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data, const fvb_outputs *d_out,
-    hipStream_t stream, void (*progress_cb)(int, int), bool allow_fast = true)
+    hipStream_t stream, void (*progress_cb)(int, int), bool allow_fast = true, HostLin *hl = nullptr)
 {
     const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -922,8 +996,16 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
     };
     const auto t_start = now();
     fvb_spatial_run run;
-    run.allow_fast = allow_fast;
-    int rc = run.open(cfg, sp, d_data, d_out, stream);
+    run.allow_fast = allow_fast && !hl; // (a host model's means must be complete before the second sweep starts)
+    int rc;
+    if (hl)
+    {
+        if ((rc = hl->open(cfg, stream)) != 0 || (rc = hl->relinearise(hl->init_means, nullptr, 0, stream)) != 0)
+            return rc;
+        hl->cur = 0;
+        run.lin_cur = run.lin_next = (const double *)hl->buf[0].p;
+    }
+    rc = run.open(cfg, sp, d_data, d_out, stream);
     if (rc)
         return rc;
     const auto t_open = now();
@@ -935,6 +1017,31 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
         {
             if ((rc = run.ak_sums(nullptr)) != 0 || (rc = run.set_ak_sums(nullptr)) != 0)
                 return rc;
+        }
+        if (hl)
+        {
+            // first sweep; the model about the new means (host); second sweep
+            if ((rc = run.sweep_levels(it, LLONG_MIN, LLONG_MAX)) != 0)
+                return rc;
+            const size_t V = hl->V;
+            const int P = hl->P;
+            hl->means_rows.resize(V * (size_t)P);
+            hl->status.resize(V);
+            if ((rc = run.copy_means(0, (int)V, hl->means_rows.data(), hl->status.data(), false)) != 0)
+                return rc;
+            std::vector<double> centres(V * (size_t)P); // [V][P]
+            for (int i = 0; i < P; i++)
+                for (size_t v = 0; v < V; v++)
+                    centres[v * P + i] = hl->means_rows[(size_t)i * V + v];
+            const int spare = 1 - hl->cur;
+            if ((rc = hl->relinearise(centres.data(), hl->status.data(), spare, stream)) != 0)
+                return rc;
+            run.sa.lin_cur = (const double *)hl->buf[hl->cur].p;
+            run.sa.lin_next = (const double *)hl->buf[spare].p;
+            if ((rc = run.sweep_noise(it)) != 0)
+                return rc;
+            hl->cur = spare;
+            continue;
         }
         if ((rc = (run.fast ? run.sweep_fast(it) : run.sweep(it))) != 0)
             return rc;
@@ -964,8 +1071,19 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
 
 extern "C" {
 
+static int32_t run_spatial_checked(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out, void *stream,
+    void (*progress_cb)(int, int), HostLin *hl);
+
 int32_t fabber_vb_run_spatial_device(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
     const fvb_outputs *out, void *stream, void (*progress_cb)(int, int))
+{
+    if (cfg && cfg->model == FVB_MODEL_HOSTJAC)
+        return api_fail(-56, "a model evaluated on the host runs spatial VB through fabber_vb_run_spatial_hostmodel_host");
+    return run_spatial_checked(cfg, sp, data, out, stream, progress_cb, nullptr);
+}
+
+static int32_t run_spatial_checked(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out, void *stream,
+    void (*progress_cb)(int, int), HostLin *hl)
 {
     int rc = api_validate(cfg, true);
     if (rc)
@@ -982,7 +1100,7 @@ int32_t fabber_vb_run_spatial_device(const fvb_config *cfg, const fvb_spatial *s
         return 0;
     if (!data)
         return api_fail(-21, "data is NULL");
-    return run_spatial(cfg, sp, data, out, (hipStream_t)stream, progress_cb);
+    return run_spatial(cfg, sp, data, out, (hipStream_t)stream, progress_cb, true, hl);
 }
 
 int32_t fabber_vb_spatial_open(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
@@ -1083,8 +1201,42 @@ int32_t fabber_vb_spatial_close(fvb_spatial_run *run)
     return rc;
 }
 
+static int32_t run_spatial_host_impl(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    int32_t device, void (*progress_cb)(int, int), HostLin *hl);
+
 int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data,
     const fvb_outputs *out, int32_t device, void (*progress_cb)(int, int))
+{
+    if (cfg && cfg->model == FVB_MODEL_HOSTJAC)
+        return api_fail(-56, "a model evaluated on the host runs spatial VB through fabber_vb_run_spatial_hostmodel_host");
+    return run_spatial_host_impl(cfg, sp, data, out, device, progress_cb, nullptr);
+}
+
+int32_t fabber_vb_run_spatial_hostmodel_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    int32_t device, fvb_linearise_fn linearise, void *user, void (*progress_cb)(int, int))
+{
+    if (!cfg || cfg->model != FVB_MODEL_HOSTJAC)
+        return api_fail(-56, "fabber_vb_run_spatial_hostmodel_host is for cfg->model = FVB_MODEL_HOSTJAC");
+    if (!linearise)
+        return api_fail(-50, "linearisation callback is NULL");
+    if (!cfg->init_mvn)
+        return api_fail(-52, "host-evaluated models need the initial posterior as init_mvn (the model's InitVoxelPosterior runs on the host)");
+    // the centres of the set-up re-centre: the means of the initial posterior, voxel-major
+    const size_t V = (size_t)cfg->n_voxels;
+    const int P = cfg->n_params, n = P + 1, nCov = n * (n + 1) / 2;
+    std::vector<double> init_means(V * (size_t)P);
+    for (size_t v = 0; v < V; v++)
+        for (int i = 0; i < P; i++)
+            init_means[v * P + i] = cfg->init_mvn[(size_t)(nCov + i) * V + v];
+    HostLin hl;
+    hl.linearise = linearise;
+    hl.user = user;
+    hl.init_means = init_means.data();
+    return run_spatial_host_impl(cfg, sp, data, out, device, progress_cb, &hl);
+}
+
+static int32_t run_spatial_host_impl(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    int32_t device, void (*progress_cb)(int, int), HostLin *hl)
 {
     int rc = api_validate(cfg, true);
     if (rc)
@@ -1150,7 +1302,7 @@ int32_t fabber_vb_run_spatial_host(const fvb_config *cfg, const fvb_spatial *sp,
         FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * V));
         dout.iterations = (int32_t *)b_it.p;
     }
-    rc = fabber_vb_run_spatial_device(&d, sp, b_data.p, &dout, nullptr, progress_cb);
+    rc = run_spatial_checked(&d, sp, b_data.p, &dout, nullptr, progress_cb, hl);
     if (rc)
         return rc;
     FVB_HIP_CHECK(hipDeviceSynchronize());

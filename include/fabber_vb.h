@@ -351,6 +351,19 @@ int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const void *data, co
     fvb_linearise_fn linearise, void *user);
 
 /*
+ * Spatial VB (Vb::DoCalculationsSpatial, inference_vb.cc:578-767) with such a model: any FwdModel of a model
+ * library under method=spatialvb, as in the reference. The two places of the loop that run the model - the
+ * set-up re-centre (:235) and the re-centre that ends every iteration's second sweep (:695) - call `linearise`
+ * for the voxels still taking part, about the means the first sweep left; priors, both sweeps, the a_K updates
+ * and F run on the device as for the built-in models (the first sweep with one launch per level: the means must
+ * be complete on the host before the second sweep starts). Arguments as fabber_vb_run_spatial_host plus the
+ * callback; cfg->init_mvn must hold the initial posterior. Device memory: two buffers of
+ * n_voxels x n_times x (n_params + 1) doubles (-55 beyond 48 GB each).
+ */
+int32_t fabber_vb_run_spatial_hostmodel_host(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    int32_t device, fvb_linearise_fn linearise, void *user, void (*progress_cb)(int, int));
+
+/*
  * Non-linear least squares, method=nlls (NLLSInferenceTechnique::DoCalculations,
  * inference_nlls.cc:94-214; cost function / gradient / Gauss-Newton Hessian NLLSCF :223-290). The
  * minimiser is FSL MISCMATHS nonlin (NL_LM), restated in csrc/vb_nlls_kernel.h. Of fvb_config the

@@ -114,3 +114,52 @@ def test_third_party_model_fits_its_data(plugin):
     out = fabber.run(data, {"model": "bump", "noise": "white", "method": "vb", "save-mean": True, "allow-bad-voxels": True},
                      model_libs=[plugin])
     assert np.isfinite(out["mean_amp"][0, 0, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prior", ["M", "P"])
+def test_host_evaluated_model_under_spatial_vb(plugin, prior):
+    """Any FwdModel runs under method=spatialvb in the reference (inference_vb.cc:578-767): here the library's
+    'mypoly' (no device body) and a built-in model forced onto the host route, with a spatial prior on one
+    parameter, ARD on another and F, against the device route of the same problem - the model's two re-centres
+    per iteration run on the host, both sweeps on the device (fabber_vb_run_spatial_hostmodel_host)."""
+    rng = np.random.default_rng(4)
+    shape, T = (9, 8, 5), 16
+    t = np.arange(1, T + 1)
+    x = np.arange(shape[0])[:, None, None]
+    c0 = 2.0 + np.sin(x / 2.0) + np.zeros(shape)
+    data = (c0[..., None] + 0.3 * t + 0.01 * t * t + rng.normal(0, 0.2, shape + (T,))).astype(np.float32)
+    opts = {"degree": 2, "noise": "white", "method": "spatialvb", "max-iterations": 6, "param-spatial-priors": prior + "AN",
+            "save-mean": True, "save-mvn": True, "save-free-energy": True, "save-noise-mean": True, "save-model-fit": True}
+    dev = fabber.run(data, dict(opts, model="poly"))
+    host = fabber.run(data, dict(opts, model="mypoly"), model_libs=[plugin])
+    assert "the model is evaluated on the host" in host["log"]
+    forced = fabber.run(data, dict(opts, model="poly", **{"host-model": True}))
+    for other in (host, forced):
+        for k in ("mean_c0", "mean_c1", "mean_c2", "noise_means", "modelfit"):
+            assert np.allclose(other[k], dev[k], rtol=2e-5, atol=1e-5), k
+        assert np.allclose(other["finalMVN"], dev["finalMVN"], rtol=1e-4, atol=1e-7)
+        assert np.allclose(other["freeEnergy"], dev["freeEnergy"], rtol=1e-5)
+    # the spatial prior did something: the fit differs from the voxelwise one
+    plain = fabber.run(data, {"model": "poly", "degree": 2, "noise": "white", "method": "vb", "max-iterations": 6, "save-mean": True})
+    assert np.abs(plain["mean_c0"] - dev["mean_c0"]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_nonlinear_host_model_under_spatial_vb_with_a_masked_volume(plugin):
+    """the third-party model (nonlinear, transforms) on a masked volume with a voxel that fails: the host route
+    skips it as the device route does; against the exponential model's device route for a built-in model"""
+    rng = np.random.default_rng(5)
+    shape, T = (7, 6, 4), 40
+    t = np.arange(T) * 0.04
+    amp = 0.5 + 0.5 * (np.arange(shape[0])[:, None, None] > 3) + np.zeros(shape)
+    data = (amp[..., None] * np.exp(-t) + rng.normal(0, 0.05, shape + (T,))).astype(np.float32)
+    mask = (rng.random(shape) < 0.85).astype(np.int32)
+    opts = {"model": "exp", "num-exps": 1, "dt": 0.04, "noise": "white", "method": "spatialvb", "max-iterations": 5,
+            "param-spatial-priors": "MN", "save-mean": True, "save-mvn": True}
+    dev = fabber.run(data, opts, mask=mask)
+    host = fabber.run(data, dict(opts, **{"host-model": True}), mask=mask)
+    sel = mask > 0
+    assert np.allclose(host["mean_amp1"][sel], dev["mean_amp1"][sel], rtol=1e-5)
+    assert np.allclose(host["mean_r1"][sel], dev["mean_r1"][sel], rtol=1e-5)
+    assert np.allclose(host["finalMVN"][sel], dev["finalMVN"][sel], rtol=1e-4, atol=1e-8)
