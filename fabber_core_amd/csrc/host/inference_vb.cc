@@ -338,7 +338,9 @@ void Vb::BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg)
 {
     if (cfg.init_mvn)
         return; // continue-from-mvn
-    const int P = cfg.n_params, N = cfg.n_phis, n = P + N, V = cfg.n_voxels;
+    // noise entries of the MVN: white = the precisions; AR(1) = the alphas, then the precisions (noisemodel_ar.cc:287-300)
+    const int NA = (cfg.noise == FVB_NOISE_AR1) ? 2 + cfg.ar_cross_terms : 0;
+    const int P = cfg.n_params, N = cfg.n_phis, n = P + NA + N, V = cfg.n_voxels;
     const int rows = fabber_vb_mvn_rows(n), nCov = n * (n + 1) / 2;
     const Matrix &data = rundata.GetMainVoxelData();
     const Matrix &coords = rundata.GetVoxelCoords();
@@ -363,10 +365,15 @@ void Vb::BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg)
                 img.at0(i * (i + 1) / 2 + j, v) = cov(i + 1, j + 1);
             img.at0(nCov + i, v) = post.means(i + 1);
         }
+        for (int a = 0; a < NA; a++) // Ar1cNoiseModel's initial alpha posterior: N(0, 1e4 I) (noisemodel_ar.cc:379-403)
+        {
+            const int q = P + a;
+            img.at0(q * (q + 1) / 2 + q, v) = 1e4;
+        }
         for (int k = 0; k < N; k++)
         {
             const double b = cfg.noise_post_b[k], c = cfg.noise_post_c[k];
-            const int q = P + k;
+            const int q = P + NA + k;
             img.at0(q * (q + 1) / 2 + q, v) = b * b * c; // GammaDist variance / mean, as OutputAsMVN
             img.at0(nCov + q, v) = b * c;
         }

@@ -3,7 +3,7 @@
  * (vb_hostmodel.h): alternates the caller's linearisation callback with one step launch until
  * every voxel is done.
  */
-#include "vb_hostmodel.h"
+#include "vb_hostmodel_ar.h"
 
 #include <hip/hip_runtime.h>
 
@@ -52,8 +52,7 @@ extern "C" int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const voi
         return rc;
     if (!linearise)
         return api_fail(-50, "linearisation callback is NULL");
-    if (cfg->noise != FVB_NOISE_WHITE)
-        return api_fail(-51, "host-evaluated models run with the white noise model only");
+    const bool ar = cfg->noise == FVB_NOISE_AR1;
     if (!cfg->init_mvn)
         return api_fail(-52, "host-evaluated models need the initial posterior as init_mvn (the model's InitVoxelPosterior runs on the host)");
     if (!out || !out->mvn)
@@ -68,8 +67,8 @@ extern "C" int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const voi
     if (!data)
         return api_fail(-21, "data is NULL");
     const int P = cfg->n_params, N = cfg->n_phis;
-    const int n = P + N, rows = n * (n + 1) / 2 + n + 1;
-    const WaveLayout L = wave_layout((int)T, P, N);
+    const int n = P + (ar ? 2 + cfg->ar_cross_terms + N : N), rows = n * (n + 1) / 2 + n + 1;
+    const WaveLayout L = wave_layout((int)T, P, N, ar);
     if (L.bytes > 160 * 1024)
         return api_fail(-41, "host-model step kernel: " + std::to_string(L.bytes) + " bytes of LDS needed exceed the 160 KB of a gfx950 CU");
     const size_t esz = cfg->data_f64 ? 8 : 4;
@@ -142,25 +141,49 @@ extern "C" int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const voi
             n_unmasked += (cfg->phi_index[t] != 255);
     }
     ha.ka.n_unmasked = n_unmasked;
+    if (ar && n_unmasked != (int)T)
+        return api_fail(-15, "Masked time points are not supported for the AR noise model"); // noisemodel_ar.cc:351-355
     ha.ka.residual_mode = 1;
     ha.ka.residual_tol = 0;
     ha.L = L;
     ha.persist_doubles = L.part - L.b;
     FVB_HIP_CHECK(b_persist.alloc(sizeof(double) * (size_t)ha.persist_doubles * V));
-    FVB_HIP_CHECK(b_scalars.alloc(sizeof(HmScalars) * V));
-    FVB_HIP_CHECK(hipMemset(b_scalars.p, 0, sizeof(HmScalars) * V)); // phase = HM_NEW
+    // the step kernel: white noise, or AR(1) with the alpha posterior kept per (echoes, alphas)
+    typedef void (*StepFn)(const HmArgs);
+    StepFn fn = cfg->need_f ? vb_wave_step_kernel<true> : vb_wave_step_kernel<false>;
+    size_t scalars_bytes = sizeof(HmScalars);
+    if (ar)
+    {
+        switch (N * 10 + 2 + cfg->ar_cross_terms)
+        {
+#define FVB_AR_STEP(KEY, NPHI, NA)                                                                           \
+    case KEY:                                                                                                \
+        fn = cfg->need_f ? vb_wave_ar_step_kernel<NPHI, NA, true> : vb_wave_ar_step_kernel<NPHI, NA, false>;  \
+        scalars_bytes = sizeof(HmArScalars<NPHI, NA>);                                                       \
+        break;
+            FVB_AR_STEP(12, 1, 2)
+            FVB_AR_STEP(22, 2, 2)
+            FVB_AR_STEP(23, 2, 3)
+            FVB_AR_STEP(24, 2, 4)
+#undef FVB_AR_STEP
+        default:
+            return api_fail(-40, "AR(1) noise: num-echoes must be 1 or 2, cross terms need two echoes");
+        }
+    }
+    FVB_HIP_CHECK(b_scalars.alloc(scalars_bytes * V));
+    FVB_HIP_CHECK(hipMemset(b_scalars.p, 0, scalars_bytes * V)); // phase = HM_NEW
     FVB_HIP_CHECK(b_lin.alloc(sizeof(double) * lin_stride * V));
     FVB_HIP_CHECK(b_slot.alloc(sizeof(int32_t) * V));
     FVB_HIP_CHECK(b_means.alloc(sizeof(double) * (size_t)P * V));
     FVB_HIP_CHECK(b_phase.alloc(sizeof(int32_t) * V));
     ha.persist = (double *)b_persist.p;
     ha.scalars = (HmScalars *)b_scalars.p;
+    ha.ar_scalars = b_scalars.p;
     ha.lin = (const double *)b_lin.p;
     ha.lin_slot = (const int32_t *)b_slot.p;
     ha.means_out = (double *)b_means.p;
     ha.phase_out = (int32_t *)b_phase.p;
 
-    auto fn = cfg->need_f ? vb_wave_step_kernel<true> : vb_wave_step_kernel<false>;
     if (L.bytes > 64 * 1024)
         FVB_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes));
 

@@ -574,6 +574,90 @@ __device__ __forceinline__ bool ar_free_energy(const KernelArgs &ka, WaveCtx &cx
     return ok;
 }
 
+// result MVN: MVNDist(fwd_post, Ar1cParams::OutputAsMVN()) (noisemodel_ar.cc:287-300), and the per-voxel outputs
+template <int NPHI, int NA>
+__device__ __forceinline__ void ar_write_outputs(const KernelArgs &ka, WaveCtx &cx, const ArState<NPHI, NA> &st, int status,
+    bool setup_failed, double F, int it, int hist_len)
+{
+    const WaveLayout &L = cx.L;
+    const int P = L.P, PP = L.PP, v = cx.v;
+    const size_t V = cx.V;
+    double *sh = cx.sh;
+    const int n = P + NA + NPHI;
+    const int nCov = n * (n + 1) / 2;
+    if (!wave_ensure_cov(cx))
+    {
+        FVB_WAVE_FOR(e, PP)
+        sh[L.Sig + e] = 0;
+        if (status == FVB_OK)
+            status = FVB_BAD_RESULT;
+        wave_sync();
+    }
+    {
+        double *dst = ka.out.mvn + v;
+        FVB_WAVE_FOR(e, nCov)
+        {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= e)
+                i++;
+            const int j = e - i * (i + 1) / 2;
+            double val = 0;
+            if (i < P)
+                val = sh[L.Sig + i * P + j];
+            else if (i < P + NA)
+            {
+                if (j >= P)
+                {
+#pragma unroll
+                    for (int a = 0; a < NA; a++)
+#pragma unroll
+                        for (int b = 0; b < NA; b++)
+                            if (a == i - P && b == j - P)
+                                val = st.acov[a][b];
+                }
+            }
+            else if (i == j)
+            {
+                const double b = sh[L.b + (i - P - NA)], c = sh[L.c + (i - P - NA)];
+                val = b * b * c;
+            }
+            dst[(size_t)e * V] = val;
+        }
+        FVB_WAVE_FOR(i, n)
+        {
+            double val = 0;
+            if (i < P)
+                val = sh[L.m + i];
+            else if (i < P + NA)
+            {
+#pragma unroll
+                for (int a = 0; a < NA; a++)
+                    if (a == i - P)
+                        val = st.am[a];
+            }
+            else
+                val = sh[L.b + (i - P - NA)] * sh[L.c + (i - P - NA)];
+            dst[(size_t)(nCov + i) * V] = val;
+        }
+        if (cx.lane == 0)
+            dst[(size_t)(nCov + n) * V] = 1.0;
+    }
+    if (cx.lane == 0)
+    {
+        if (ka.out.f_history && hist_len < ka.cfg.f_history_rows)
+            ka.out.f_history[(size_t)hist_len * V + v] = F;
+        hist_len++;
+        if (ka.out.f_history_len)
+            ka.out.f_history_len[v] = hist_len;
+        if (ka.out.free_energy)
+            ka.out.free_energy[v] = F;
+        if (ka.out.status)
+            ka.out.status[v] = status | (setup_failed ? 0x100 : 0);
+        if (ka.out.iterations)
+            ka.out.iterations[v] = it;
+    }
+}
+
 template <int NPHI, int NA, bool NEEDF>
 __global__ __launch_bounds__(64) void vb_wave_ar_kernel(const KernelArgs ka, const WaveLayout L)
 {
@@ -800,78 +884,7 @@ __global__ __launch_bounds__(64) void vb_wave_ar_kernel(const KernelArgs ka, con
 #undef FVB_AR_EVAL_F
     }
 
-    // ---- result MVN: MVNDist(fwd_post, Ar1cParams::OutputAsMVN()) (noisemodel_ar.cc:287-300) ----
-    if (!wave_ensure_cov(cx))
-    {
-        FVB_WAVE_FOR(e, PP)
-        sh[L.Sig + e] = 0;
-        if (status == FVB_OK)
-            status = FVB_BAD_RESULT;
-        wave_sync();
-    }
-    {
-        double *dst = ka.out.mvn + v;
-        FVB_WAVE_FOR(e, nCov)
-        {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= e)
-                i++;
-            const int j = e - i * (i + 1) / 2;
-            double val = 0;
-            if (i < P)
-                val = sh[L.Sig + i * P + j];
-            else if (i < P + NA)
-            {
-                if (j >= P)
-                {
-#pragma unroll
-                    for (int a = 0; a < NA; a++)
-#pragma unroll
-                        for (int b = 0; b < NA; b++)
-                            if (a == i - P && b == j - P)
-                                val = st.acov[a][b];
-                }
-            }
-            else if (i == j)
-            {
-                const double b = sh[L.b + (i - P - NA)], c = sh[L.c + (i - P - NA)];
-                val = b * b * c;
-            }
-            dst[(size_t)e * V] = val;
-        }
-        FVB_WAVE_FOR(i, n)
-        {
-            double val = 0;
-            if (i < P)
-                val = sh[L.m + i];
-            else if (i < P + NA)
-            {
-#pragma unroll
-                for (int a = 0; a < NA; a++)
-                    if (a == i - P)
-                        val = st.am[a];
-            }
-            else
-                val = sh[L.b + (i - P - NA)] * sh[L.c + (i - P - NA)];
-            dst[(size_t)(nCov + i) * V] = val;
-        }
-        if (cx.lane == 0)
-            dst[(size_t)(nCov + n) * V] = 1.0;
-    }
-    if (cx.lane == 0)
-    {
-        if (ka.out.f_history && hist_len < ka.cfg.f_history_rows)
-            ka.out.f_history[(size_t)hist_len * V + v] = F;
-        hist_len++;
-        if (ka.out.f_history_len)
-            ka.out.f_history_len[v] = hist_len;
-        if (ka.out.free_energy)
-            ka.out.free_energy[v] = F;
-        if (ka.out.status)
-            ka.out.status[v] = status | (setup_failed ? 0x100 : 0);
-        if (ka.out.iterations)
-            ka.out.iterations[v] = it;
-    }
+    ar_write_outputs<NPHI, NA>(ka, cx, st, status, setup_failed, F, it, hist_len);
 }
 
 #endif // __HIPCC__

@@ -163,3 +163,33 @@ def test_nonlinear_host_model_under_spatial_vb_with_a_masked_volume(plugin):
     assert np.allclose(host["mean_amp1"][sel], dev["mean_amp1"][sel], rtol=1e-5)
     assert np.allclose(host["mean_r1"][sel], dev["mean_r1"][sel], rtol=1e-5)
     assert np.allclose(host["finalMVN"][sel], dev["finalMVN"][sel], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv", ["maxits", "freduce"])
+def test_host_evaluated_model_with_ar1_noise(plugin, conv):
+    """noise=ar with a model that has no device body (Ar1cNoiseModel works with any FwdModel in the reference):
+    vb_hostmodel_ar.h carries every voxel from re-centre to re-centre with the AR(1) steps of the wave kernel;
+    against the device route of the same model, also with a detector that saves and reverts"""
+    rng = np.random.default_rng(6)
+    shape, T = (6, 5, 4), 40
+    t = np.arange(1, T + 1)
+    c = rng.uniform(-2, 2, shape + (3,))
+    e = rng.normal(0, 0.3, shape + (T,))
+    for k in range(1, T):  # AR(1) noise
+        e[..., k] += 0.4 * e[..., k - 1]
+    data = (c[..., 0:1] + c[..., 1:2] * t / 10 + c[..., 2:3] * (t / 10) ** 2 + e).astype(np.float32)
+    opts = {"degree": 2, "noise": "ar", "method": "vb", "max-iterations": 8, "convergence": conv, "save-mean": True, "save-mvn": True,
+            "save-free-energy": True, "save-noise-mean": True}
+    dev = fabber.run(data, dict(opts, model="poly"))
+    host = fabber.run(data, dict(opts, model="mypoly"), model_libs=[plugin])
+    assert "evaluated on the host" in host["log"]
+    for k in ("mean_c0", "mean_c1", "mean_c2", "noise_means"):
+        assert np.allclose(host[k], dev[k], rtol=2e-5, atol=1e-5), k
+    assert np.allclose(host["finalMVN"], dev["finalMVN"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(host["freeEnergy"], dev["freeEnergy"], rtol=1e-5)
+    # two interleaved echoes with the dual cross terms (the general AR form), built-in model forced onto the host route
+    opts2 = dict(opts, model="poly", **{"num-echoes": 2, "ar1-cross-terms": "dual"})
+    dev2 = fabber.run(data, opts2)
+    host2 = fabber.run(data, dict(opts2, **{"host-model": True}))
+    assert np.allclose(host2["finalMVN"], dev2["finalMVN"], rtol=1e-4, atol=1e-7)
