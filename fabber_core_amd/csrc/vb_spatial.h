@@ -336,14 +336,29 @@ __global__ __launch_bounds__(256) void vb_spatial_ak_partial_kernel(const Spatia
 template <int P>
 __global__ __launch_bounds__(64) void vb_spatial_ak_reduce_kernel(const SpatialArgs sa)
 {
+    // lane 2 k + which adds column (k, which) of partials [n_blocks][P][2] from the first segment to the last; the
+    // 64 lanes fetch the rows together, 512 doubles at a time through LDS (a lane reading its own column from
+    // memory pays a memory round trip every few segments: 77 us for the 512 segments of a 128^3 volume)
+    constexpr int CHUNK = 512;
+    __shared__ double rows[CHUNK];
     const int k = threadIdx.x >> 1, which = threadIdx.x & 1;
-    if (k >= P)
-        return;
+    const bool mine = k < P && is_spatial_type(sa.ka.cfg.prior_type[k < P ? k : 0]);
+    const int per_block = 2 * P;
+    const int blocks_per_chunk = CHUNK / per_block;
     double acc = 0;
-    if (is_spatial_type(sa.ka.cfg.prior_type[k]))
-        for (int b = 0; b < sa.n_blocks; b++)
-            acc += sa.partials[((size_t)b * P + k) * 2 + which];
-    sa.ak_sums[2 * k + which] = acc;
+    for (int b0 = 0; b0 < sa.n_blocks; b0 += blocks_per_chunk)
+    {
+        const int nb = (sa.n_blocks - b0 < blocks_per_chunk) ? sa.n_blocks - b0 : blocks_per_chunk;
+        for (int i = threadIdx.x; i < nb * per_block; i += 64)
+            rows[i] = sa.partials[(size_t)b0 * per_block + i];
+        __syncthreads();
+        if (mine)
+            for (int b = 0; b < nb; b++)
+                acc += rows[b * per_block + 2 * k + which];
+        __syncthreads();
+    }
+    if (k < P)
+        sa.ak_sums[2 * k + which] = mine ? acc : 0.0;
 }
 
 template <int P>

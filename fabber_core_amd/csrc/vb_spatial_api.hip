@@ -465,75 +465,78 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             lmax = (first || tmax[t] > lmax) ? tmax[t] : lmax;
             first = false;
         }
-    std::vector<int32_t> order(std::max(n_owned, 1));
-    level_begin.clear();
-    level_value.clear();
-    level_w[0] = 1;
-    level_w[1] = (int)cy;
-    level_w[2] = (int)cz;
-    if (lmax - lmin < (1LL << 22))
-    {
-        // counting sort (stable: voxels of a level stay in index order)
-        const size_t nl = (size_t)(lmax - lmin + 1);
-        std::vector<std::vector<int32_t> > count(nt, std::vector<int32_t>(nl, 0));
-        parallel([&](int t) {
-            int32_t *c = count[t].data();
-            for (int i = chunk(t); i < chunk(t + 1); i++)
-                c[(size_t)(level_of(i) - lmin)]++;
-        });
-        int32_t running = 0;
-        for (size_t l = 0; l < nl; l++)
+    // The level order (voxel ids sorted by level) is what the per-level launches walk; the slab form of the split
+    // sweep numbers the voxels itself (below) and does without it - 2.5 ms of a 128^3 run's set-up.
+    std::vector<int32_t> order(1);
+    auto build_level_order = [&]() {
+        order.assign(std::max(n_owned, 1), 0);
+        level_begin.clear();
+        level_value.clear();
+        level_w[0] = 1;
+        level_w[1] = (int)cy;
+        level_w[2] = (int)cz;
+        if (lmax - lmin < (1LL << 22))
         {
-            const int32_t begin = running;
-            for (int t = 0; t < nt; t++) // thread order = index order
+            // counting sort (stable: voxels of a level stay in index order)
+            const size_t nl = (size_t)(lmax - lmin + 1);
+            std::vector<std::vector<int32_t> > count(nt, std::vector<int32_t>(nl, 0));
+            parallel([&](int t) {
+                int32_t *c = count[t].data();
+                for (int i = chunk(t); i < chunk(t + 1); i++)
+                    c[(size_t)(level_of(i) - lmin)]++;
+            });
+            int32_t running = 0;
+            for (size_t l = 0; l < nl; l++)
             {
-                const int32_t n = count[t][l];
-                count[t][l] = running; // becomes this thread's first slot in level l
-                running += n;
+                const int32_t begin = running;
+                for (int t = 0; t < nt; t++) // thread order = index order
+                {
+                    const int32_t n = count[t][l];
+                    count[t][l] = running; // becomes this thread's first slot in level l
+                    running += n;
+                }
+                if (running > begin)
+                {
+                    level_begin.push_back(begin);
+                    level_value.push_back(lmin + (long long)l);
+                }
             }
-            if (running > begin)
-            {
-                level_begin.push_back(begin);
-                level_value.push_back(lmin + (long long)l);
-            }
+            level_begin.push_back(n_owned);
+            parallel([&](int t) {
+                int32_t *c = count[t].data();
+                for (int i = chunk(t); i < chunk(t + 1); i++)
+                    order[c[(size_t)(level_of(i) - lmin)]++] = owned_begin + i;
+            });
         }
-        level_begin.push_back(n_owned);
-        parallel([&](int t) {
-            int32_t *c = count[t].data();
-            for (int i = chunk(t); i < chunk(t + 1); i++)
-                order[c[(size_t)(level_of(i) - lmin)]++] = owned_begin + i;
-        });
-    }
-    else
-    {
-        std::vector<int32_t> idx(n_owned);
-        for (int i = 0; i < n_owned; i++)
-            idx[i] = i;
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level_of(a) < level_of(b); });
-        for (int i = 0; i < n_owned; i++)
+        else
         {
-            if (i == 0 || level_of(idx[i]) != level_of(idx[i - 1]))
+            std::vector<int32_t> idx(n_owned);
+            for (int i = 0; i < n_owned; i++)
+                idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return level_of(a) < level_of(b); });
+            for (int i = 0; i < n_owned; i++)
             {
-                level_begin.push_back(i);
-                level_value.push_back(level_of(idx[i]));
+                if (i == 0 || level_of(idx[i]) != level_of(idx[i - 1]))
+                {
+                    level_begin.push_back(i);
+                    level_value.push_back(level_of(idx[i]));
+                }
+                order[i] = owned_begin + idx[i];
             }
-            order[i] = owned_begin + idx[i];
+            level_begin.push_back(n_owned);
         }
-        level_begin.push_back(n_owned);
-    }
-    t_geometry_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-
-    // ---- level-major numbering for the split first sweep ----
+    };
+    // ---- numbering for the split first sweep ----
     int n_spatial = 0, spatial_param[FVB_MAX_PARAMS] = { 0 };
     for (int kk = 0; kk < P; kk++)
         if (cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M)
             spatial_param[n_spatial++] = kk;
-    fast = allow_fast && has_spatial && !second_neighbours && owned_begin == 0 && owned_end == V && n_owned > 0
-        && !getenv("FVB_SPATIAL_PER_LEVEL") && level_begin.size() <= 6000; // (the sweep keeps the level table in LDS)
+    const bool eligible = allow_fast && has_spatial && !second_neighbours && owned_begin == 0 && owned_end == V && n_owned > 0
+        && !getenv("FVB_SPATIAL_PER_LEVEL");
     std::vector<int32_t> pos_of, level_pos, level_count, slab_first;
     int n_pos = 0, sl_width = 64, sl_max_run = 0, sl_dz = 0;
     slab_form = false;
-    if (fast && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll")) && lmax - lmin < (1LL << 22))
+    if (eligible && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll")) && lmax - lmin < (1LL << 22))
     {
         // Slab-major numbering: a slab = dz z-planes, inside a slab the voxels level by level (index order in a
         // level). dz: as few planes as keep the slabs within the chip's workgroups (every slab is one resident
@@ -611,6 +614,9 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             }
         }
     }
+    if (!slab_form)
+        build_level_order();
+    fast = slab_form || (eligible && level_begin.size() <= 6000); // (the data-flow sweep keeps the level table in LDS)
     if (fast && !slab_form)
     {
         // level-major numbering for the data-flow sweep
@@ -631,6 +637,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         n_pos = (n_pos + 15) / 16 * 16;
         level_begin_counts = level_count;
     }
+
+    t_geometry_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 
     // ---- device memory ----
     // segments of the a_K sums: every z-plane of the owned voxels, cut every 4096 voxels from its first
@@ -1062,8 +1070,8 @@ int run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *d_data
     if ((rc = run.finish()) != 0)
         return rc;
     if (timing)
-        fprintf(stderr, "[fvb spatial] V=%d levels=%zu: geometry %.1f ms (neighbours %.1f), alloc+upload+setup %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
-            run.V, run.level_begin.size() - 1, run.t_geometry_ms, run.t_neighbours_ms, ms(t_start, t_open) - run.t_geometry_ms, ms(t_open, t_enq),
+        fprintf(stderr, "[fvb spatial] V=%d levels/runs=%zu: geometry %.1f ms (neighbours %.1f), alloc+upload+setup %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
+            run.V, run.slab_form ? run.level_begin_counts.size() : run.level_begin.size() - 1, run.t_geometry_ms, run.t_neighbours_ms, ms(t_start, t_open) - run.t_geometry_ms, ms(t_open, t_enq),
             ms(t_enq, now()));
     return 0;
 }
