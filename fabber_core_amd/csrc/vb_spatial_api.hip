@@ -848,7 +848,8 @@ int fvb_spatial_run::sweep_fast(int it)
     sa.it = it;
     sa.sw_serial++; // this sweep's number
     const int n_owned = owned_end - owned_begin;
-    hipLaunchKernelGGL(k.prep, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
+    // (a multiple of 8 workgroups: the kernel deals them out to the XCDs in contiguous eighths of the voxel list)
+    hipLaunchKernelGGL(k.prep, dim3((unsigned)(((n_owned + 63) / 64 + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
     const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
     if (slab_form)
     {
