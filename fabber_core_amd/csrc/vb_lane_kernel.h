@@ -1130,6 +1130,9 @@ __device__ __forceinline__ void save_posterior(const KernelArgs &ka, int v, cons
     constexpr int PT = P * (P + 1) / 2;
     const size_t V = (size_t)ka.cfg.n_voxels;
     double *p = ka.save + v;
+    // (the rows' addresses are formed here, where they are used: left to itself the compiler forms all of them
+    // once before the voxel loop - 27 pointers in 54 registers for P = 4, spilled and fetched back one by one)
+    asm volatile("" : "+v"(p));
     int r = 0;
 #pragma unroll
     for (int i = 0; i < P; i++)
@@ -1155,6 +1158,7 @@ __device__ __forceinline__ void restore_posterior(const KernelArgs &ka, int v, V
     constexpr int PT = P * (P + 1) / 2;
     const size_t V = (size_t)ka.cfg.n_voxels;
     const double *p = ka.save + v;
+    asm volatile("" : "+v"(p)); // (see save_posterior)
     int r = 0;
 #pragma unroll
     for (int i = 0; i < P; i++)
