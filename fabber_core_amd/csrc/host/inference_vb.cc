@@ -739,14 +739,20 @@ void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_con
         if (host_model && (want_fit || want_resid)) // inference.cc:181-243
         {
             const Matrix &coords = rundata.GetVoxelCoords();
+            const Matrix &supp = rundata.GetVoxelSuppData();
             const int nCov = (P + N) * (P + N + 1) / 2;
             ColumnVector tmp, means(P);
             for (int v = 0; v < V; v++)
             {
-                m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)));
+                if (supp.Ncols() == V) // as the voxel loop passes it (inference_vb.cc:104-115)
+                    m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)), ColumnVector(supp.Column(v + 1)));
+                else
+                    m_model->PassData(v + 1, ColumnVector(data.Column(v + 1)), ColumnVector(coords.Column(v + 1)));
                 for (int k = 0; k < P; k++)
                     means(k + 1) = m_result_image.at0(nCov + k, v);
                 m_model->EvaluateFabber(means, tmp, "");
+                if (tmp.Nrows() != T)
+                    throw FabberInternalError("The model's prediction has " + stringify(tmp.Nrows()) + " timepoints, the data " + stringify(T));
                 for (int t = 0; t < T; t++)
                 {
                     if (want_fit)

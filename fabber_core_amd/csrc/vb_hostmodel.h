@@ -48,8 +48,8 @@ struct HmArgs
     WaveLayout L;
     double *persist;          // [V][persist_doubles]: LDS block [L.b, L.part) of the voxel
     HmScalars *scalars;       // [V]
-    const double *lin;        // [n_active][T (P + 1)]: g then J, of the voxels with lin_slot >= 0
-    const int32_t *lin_slot;  // [V] index into lin, -1 = voxel is done
+    const double *lin;        // [batch][T (P + 1)]: g then J of the batch's voxels
+    const int32_t *batch_ids; // [batch] the voxels this launch works on (one workgroup each)
     void *ar_scalars;         // AR(1) noise: [V] HmArScalars<NPHI, NA> instead (vb_hostmodel_ar.h)
     double *means_out;        // [V][P] means the NEXT linearisation is wanted about
     int32_t *phase_out;       // [V]
@@ -118,10 +118,8 @@ __global__ __launch_bounds__(64) void vb_wave_step_kernel(const HmArgs ha)
     extern __shared__ double wave_lds[];
     const KernelArgs &ka = ha.ka;
     const WaveLayout &L = ha.L;
-    const int v = blockIdx.x;
-    const int slot = ha.lin_slot[v];
-    if (slot < 0)
-        return; // done earlier
+    const int slot = blockIdx.x; // this launch's batch: the voxel and its place in the batch's linearisations
+    const int v = ha.batch_ids[slot];
     WaveCtx cx;
     cx.L = L;
     cx.sh = wave_lds;

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -172,15 +174,25 @@ extern "C" int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const voi
     }
     FVB_HIP_CHECK(b_scalars.alloc(scalars_bytes * V));
     FVB_HIP_CHECK(hipMemset(b_scalars.p, 0, scalars_bytes * V)); // phase = HM_NEW
-    FVB_HIP_CHECK(b_lin.alloc(sizeof(double) * lin_stride * V));
-    FVB_HIP_CHECK(b_slot.alloc(sizeof(int32_t) * V));
+    // The voxels still running are worked through in batches: the linearisations of a batch (g and J, T (P + 1)
+    // doubles per voxel) are what the host and the device hold at a time, in two buffers each side, so that the
+    // host evaluates the model for the next batch while the device steps the current one. (One buffer for the whole
+    // volume - 4 GB per million voxels at T = 100, P = 4 - made real volumes fail at allocation.)
+    size_t batch_voxels = std::max<size_t>(1, std::min<size_t>(V, std::max<size_t>(4096, (size_t)(256u << 20) / (sizeof(double) * lin_stride))));
+    if (const char *forced = getenv("FVB_HOSTMODEL_BATCH")) // tests: several batches on small volumes
+        batch_voxels = std::max<size_t>(1, std::min<size_t>(V, (size_t)atol(forced)));
+    DevMem b_lin2, b_slot2;
+    FVB_HIP_CHECK(b_lin.alloc(sizeof(double) * lin_stride * batch_voxels));
+    FVB_HIP_CHECK(b_lin2.alloc(sizeof(double) * lin_stride * batch_voxels));
+    FVB_HIP_CHECK(b_slot.alloc(sizeof(int32_t) * batch_voxels));
+    FVB_HIP_CHECK(b_slot2.alloc(sizeof(int32_t) * batch_voxels));
     FVB_HIP_CHECK(b_means.alloc(sizeof(double) * (size_t)P * V));
     FVB_HIP_CHECK(b_phase.alloc(sizeof(int32_t) * V));
     ha.persist = (double *)b_persist.p;
     ha.scalars = (HmScalars *)b_scalars.p;
     ha.ar_scalars = b_scalars.p;
     ha.lin = (const double *)b_lin.p;
-    ha.lin_slot = (const int32_t *)b_slot.p;
+    ha.batch_ids = (const int32_t *)b_slot.p;
     ha.means_out = (double *)b_means.p;
     ha.phase_out = (int32_t *)b_phase.p;
 
@@ -188,41 +200,77 @@ extern "C" int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const voi
         FVB_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes));
 
     // host side of the ping-pong
-    std::vector<double> means((size_t)P * V), lin(lin_stride * V), active_means;
-    std::vector<int32_t> slot(V), phase(V, HM_NEW), ids;
+    std::vector<double> means((size_t)P * V), lin[2], active_means;
+    lin[0].resize(lin_stride * batch_voxels);
+    lin[1].resize(lin_stride * batch_voxels);
+    std::vector<int32_t> phase(V, HM_NEW), ids;
     {
         const int nCov = n * (n + 1) / 2;
         for (size_t v = 0; v < V; v++)
             for (int i = 0; i < P; i++)
                 means[v * P + i] = cfg->init_mvn[(size_t)(nCov + i) * V + v];
     }
+    hipStream_t stream;
+    FVB_HIP_CHECK(hipStreamCreate(&stream));
+    struct StreamGuard
+    {
+        hipStream_t s;
+        ~StreamGuard()
+        {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    } stream_guard = { stream };
+    hipEvent_t used[2]; // buffer pair i is free again when the launch that read it is over
+    FVB_HIP_CHECK(hipEventCreateWithFlags(&used[0], hipEventDisableTiming));
+    FVB_HIP_CHECK(hipEventCreateWithFlags(&used[1], hipEventDisableTiming));
+    struct EventGuard
+    {
+        hipEvent_t *e;
+        ~EventGuard()
+        {
+            (void)hipEventDestroy(e[0]);
+            (void)hipEventDestroy(e[1]);
+        }
+    } event_guard = { used };
+    void *dev_lin[2] = { b_lin.p, b_lin2.p }, *dev_ids[2] = { b_slot.p, b_slot2.p };
     // every iteration needs one step, a revert one more, trial / LM modes extra iterations
     const long max_steps = ((long)cfg->max_iterations + 2) * 12 + 8;
     for (long step = 0;; step++)
     {
         ids.clear();
         for (size_t v = 0; v < V; v++)
-        {
-            slot[v] = (phase[v] == HM_DONE) ? -1 : (int32_t)ids.size();
             if (phase[v] != HM_DONE)
                 ids.push_back((int32_t)v);
-        }
         if (ids.empty())
             break;
         if (step >= max_steps)
             return api_fail(-53, "host-model loop did not terminate");
-        active_means.resize(ids.size() * (size_t)P);
-        for (size_t a = 0; a < ids.size(); a++)
-            for (int i = 0; i < P; i++)
-                active_means[a * P + i] = means[(size_t)ids[a] * P + i];
-        // g [T] then J [T][P] per active voxel, about active_means[a][.] (Fabber space)
-        const int cb = linearise(user, (int32_t)ids.size(), ids.data(), active_means.data(), lin.data());
-        if (cb != 0)
-            return api_fail(-54, "the model's linearisation callback failed (code " + std::to_string(cb) + ")");
-        FVB_HIP_CHECK(hipMemcpy(b_lin.p, lin.data(), sizeof(double) * lin_stride * ids.size(), hipMemcpyHostToDevice));
-        FVB_HIP_CHECK(hipMemcpy(b_slot.p, slot.data(), sizeof(int32_t) * V, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(fn, dim3((unsigned)V), dim3(64), L.bytes, 0, ha);
-        FVB_HIP_CHECK(hipGetLastError());
+        int which = 0;
+        for (size_t b0 = 0; b0 < ids.size(); b0 += batch_voxels, which ^= 1)
+        {
+            const size_t nb = std::min(batch_voxels, ids.size() - b0);
+            active_means.resize(nb * (size_t)P);
+            for (size_t a = 0; a < nb; a++)
+                for (int i = 0; i < P; i++)
+                    active_means[a * P + i] = means[(size_t)ids[b0 + a] * P + i];
+            // (the launch that read this host / device buffer pair two batches ago has to be over; the host
+            // works on this batch's model evaluations while the device steps the previous batch)
+            if (b0 >= 2 * batch_voxels)
+                FVB_HIP_CHECK(hipEventSynchronize(used[which]));
+            // g [T] then J [T][P] per voxel of the batch, about active_means[a][.] (Fabber space)
+            const int cb = linearise(user, (int32_t)nb, ids.data() + b0, active_means.data(), lin[which].data());
+            if (cb != 0)
+                return api_fail(-54, "the model's linearisation callback failed (code " + std::to_string(cb) + ")");
+            FVB_HIP_CHECK(hipMemcpyAsync(dev_lin[which], lin[which].data(), sizeof(double) * lin_stride * nb, hipMemcpyHostToDevice, stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(dev_ids[which], ids.data() + b0, sizeof(int32_t) * nb, hipMemcpyHostToDevice, stream));
+            ha.lin = (const double *)dev_lin[which];
+            ha.batch_ids = (const int32_t *)dev_ids[which];
+            hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(64), L.bytes, stream, ha);
+            FVB_HIP_CHECK(hipGetLastError());
+            FVB_HIP_CHECK(hipEventRecord(used[which], stream));
+        }
+        FVB_HIP_CHECK(hipStreamSynchronize(stream));
         FVB_HIP_CHECK(hipMemcpy(phase.data(), b_phase.p, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
         FVB_HIP_CHECK(hipMemcpy(means.data(), b_means.p, sizeof(double) * (size_t)P * V, hipMemcpyDeviceToHost));
     }

@@ -29,10 +29,8 @@ __global__ __launch_bounds__(64) void vb_wave_ar_step_kernel(const HmArgs ha)
     extern __shared__ double wave_lds[];
     const KernelArgs &ka = ha.ka;
     const WaveLayout &L = ha.L;
-    const int v = blockIdx.x;
-    const int slot = ha.lin_slot[v];
-    if (slot < 0)
-        return; // done earlier
+    const int slot = blockIdx.x; // this launch's batch: the voxel and its place in the batch's linearisations
+    const int v = ha.batch_ids[slot];
     WaveCtx cx;
     cx.L = L;
     cx.sh = wave_lds;

@@ -193,3 +193,23 @@ def test_host_evaluated_model_with_ar1_noise(plugin, conv):
     dev2 = fabber.run(data, opts2)
     host2 = fabber.run(data, dict(opts2, **{"host-model": True}))
     assert np.allclose(host2["finalMVN"], dev2["finalMVN"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise", ["white", "ar"])
+def test_host_route_in_batches_is_the_host_route_in_one(plugin, noise, monkeypatch):
+    """the voxels still running are worked through in batches (two buffers each side, the host's next batch
+    overlapping the device's current one): 7 voxels per batch here, with a detector that makes voxels finish at
+    different steps - every output identical to the run with one batch"""
+    rng = np.random.default_rng(7)
+    shape, T = (5, 4, 3), 40
+    t = np.arange(T) * 0.04
+    amp = np.where(rng.random(shape) < 0.5, 1.0, 0.5)
+    data = (amp[..., None] * np.exp(-t) + rng.normal(0, 0.1, shape + (T,))).astype(np.float32)
+    opts = {"model": "exp", "num-exps": 1, "dt": 0.04, "noise": noise, "method": "vb", "convergence": "pointzeroone", "max-iterations": 20,
+            "save-mean": True, "save-mvn": True, "save-free-energy": True, "host-model": True}
+    one = fabber.run(data, opts)
+    monkeypatch.setenv("FVB_HOSTMODEL_BATCH", "7")
+    many = fabber.run(data, opts)
+    for k in ("finalMVN", "freeEnergy", "mean_amp1", "mean_r1"):
+        assert np.array_equal(one[k], many[k]), k
