@@ -192,17 +192,23 @@ struct DevMem
 struct GeomScan
 {
     int32_t xmax, ymax, cmin, bad_order;
+    int32_t zmin, zmax, lmin, lmax; // z and x + y + z: what the slab numbering of the split sweep needs
 };
 
 __global__ __launch_bounds__(256) void geom_scan_kernel(const int32_t *coords, int V, GeomScan *out)
 {
     const int32_t *X = coords, *Y = coords + V, *Z = coords + 2 * (size_t)V;
     int xmax = 0, ymax = 0, cmin = 0, bad = 0;
+    int zmin = INT_MAX, zmax = INT_MIN, lmin = INT_MAX, lmax = INT_MIN;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x)
     {
         xmax = max(xmax, X[v]);
         ymax = max(ymax, Y[v]);
         cmin = min(cmin, min(X[v], min(Y[v], Z[v])));
+        zmin = min(zmin, Z[v]);
+        zmax = max(zmax, Z[v]);
+        lmin = min(lmin, X[v] + Y[v] + Z[v]);
+        lmax = max(lmax, X[v] + Y[v] + Z[v]);
         if (v + 1 < V) // CheckCoordMatrixCorrectlyOrdered, inference_vb.cc:769-793
         {
             const int dx = X[v + 1] - X[v], dy = Y[v + 1] - Y[v], dz = Z[v + 1] - Z[v];
@@ -213,8 +219,34 @@ __global__ __launch_bounds__(256) void geom_scan_kernel(const int32_t *coords, i
     atomicMax(&out->xmax, xmax);
     atomicMax(&out->ymax, ymax);
     atomicMin(&out->cmin, cmin);
+    atomicMin(&out->zmin, zmin);
+    atomicMax(&out->zmax, zmax);
+    atomicMin(&out->lmin, lmin);
+    atomicMax(&out->lmax, lmax);
     if (bad)
         atomicOr(&out->bad_order, 1);
+}
+
+// Slab-major numbering of the split sweep on the device (vb_spatial.h, "slab form"): key = (slab, level) of a voxel;
+// a histogram, the prefix sums (on the host: a few ten thousand keys) and one more pass that hands out the positions
+// of a key's run in arrival order - which voxel of a run gets which of its positions changes no result.
+__device__ __forceinline__ int slab_key(const int32_t *coords, int V, int v, int zmin, int dz, int lmin, int nl)
+{
+    const int x = coords[v], y = coords[(size_t)V + v], z = coords[2 * (size_t)V + v];
+    return ((z - zmin) / dz) * nl + (x + y + z - lmin);
+}
+__global__ __launch_bounds__(256) void slab_count_kernel(const int32_t *coords, int V, int zmin, int dz, int lmin, int nl, int32_t *count)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V)
+        atomicAdd(count + slab_key(coords, V, v, zmin, dz, lmin, nl), 1);
+}
+__global__ __launch_bounds__(256) void slab_place_kernel(const int32_t *coords, int V, int zmin, int dz, int lmin, int nl, int32_t *next,
+    int32_t *pos_of)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V)
+        pos_of[v] = atomicAdd(next + slab_key(coords, V, v, zmin, dz, lmin, nl), 1);
 }
 
 __global__ __launch_bounds__(256) void geom_dense_kernel(const int32_t *coords, int V, int xsize, int ysize, long long base,
@@ -263,7 +295,8 @@ __global__ __launch_bounds__(256) void geom_neighbours_kernel(const int32_t *coo
 }
 
 // Returns 0 (d_nn filled), 1 (geometry not suited: use the host path) or a negative error code.
-int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d_nn, hipStream_t stream, std::string &err)
+int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d_nn, hipStream_t stream, std::string &err,
+    DevMem *keep_coords = nullptr, GeomScan *scan_out = nullptr)
 {
 #define FVB_GEOM_CHECK(expr)                                                                                 \
     do                                                                                                       \
@@ -279,7 +312,9 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
     FVB_GEOM_CHECK(d_coords.alloc(sizeof(int32_t) * 3 * (size_t)V, stream));
     FVB_GEOM_CHECK(d_scan.alloc(sizeof(GeomScan), stream));
     FVB_GEOM_CHECK(hipMemcpyAsync(d_coords.p, h_coords, sizeof(int32_t) * 3 * (size_t)V, hipMemcpyHostToDevice, stream));
-    FVB_GEOM_CHECK(hipMemsetAsync(d_scan.p, 0, sizeof(GeomScan), stream));
+    GeomScan scan0 = { 0, 0, 0, 0, INT_MAX, INT_MIN, INT_MAX, INT_MIN };
+    FVB_GEOM_CHECK(hipMemcpyAsync(d_scan.p, &scan0, sizeof(GeomScan), hipMemcpyHostToDevice, stream));
+    FVB_GEOM_CHECK(hipStreamSynchronize(stream)); // (scan0 is a local)
     const unsigned blocks = (unsigned)std::min(1024, (V + 255) / 256);
     hipLaunchKernelGGL(geom_scan_kernel, dim3(blocks), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, (GeomScan *)d_scan.p);
     GeomScan scan;
@@ -309,6 +344,13 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
     FVB_GEOM_CHECK(hipGetLastError());
     FVB_GEOM_CHECK(hipStreamSynchronize(stream)); // the temporaries are freed on return
 #undef FVB_GEOM_CHECK
+    if (scan_out)
+        *scan_out = scan;
+    if (keep_coords) // the caller goes on with the co-ordinates on the device (slab numbering)
+    {
+        std::swap(keep_coords->p, d_coords.p);
+        std::swap(keep_coords->stream, d_coords.stream);
+    }
     return 0;
 }
 
@@ -396,8 +438,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     const auto t_start = std::chrono::steady_clock::now();
     FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6, stream));
     std::string err;
+    DevMem d_coords;
+    GeomScan scan;
     const int on_device = (V > 0 && !getenv("FVB_SPATIAL_HOST_GEOMETRY"))
-        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err) : 1;
+        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err, &d_coords, &scan) : 1;
     if (on_device < 0)
         return api_fail(on_device, err);
     if (on_device == 1)
@@ -543,12 +587,21 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         // workgroup): one plane per slab up to 192 planes. Thicker slabs mean fewer hand-overs between workgroups
         // (2.4 us each, one after the other) but longer runs and fewer groups per workgroup to hide the records'
         // latency: measured at 128^3, 0.52 ms per sweep with dz = 1, 0.55 with 2, 0.87 with 4.
+        // (with the co-ordinates on the device - the usual case - the numbering is three small kernels there; the
+        // host does it with its threads otherwise: 3 ms at 128^3 against 0.2)
+        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING");
         int zmin = Z[owned_begin], zmax = Z[owned_begin];
-        for (int v = owned_begin; v < owned_end; v++)
+        if (on_dev)
         {
-            zmin = std::min(zmin, (int)Z[v]);
-            zmax = std::max(zmax, (int)Z[v]);
+            zmin = scan.zmin;
+            zmax = scan.zmax;
         }
+        else
+            for (int v = owned_begin; v < owned_end; v++)
+            {
+                zmin = std::min(zmin, (int)Z[v]);
+                zmax = std::max(zmax, (int)Z[v]);
+            }
         const long long nz = (long long)zmax - zmin + 1;
         long long dz = std::max(1LL, (nz + 191) / 192);
         if (const char *forced = getenv("FVB_SPATIAL_SLAB_DZ"))
@@ -561,12 +614,25 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             auto key_of = [&](int i) -> size_t {
                 return (size_t)((Z[owned_begin + i] - zmin) / dz) * nl + (size_t)(level_of(i) - lmin);
             };
-            std::vector<std::vector<int32_t> > count(nt, std::vector<int32_t>(nk, 0));
-            parallel([&](int t) {
-                int32_t *c = count[t].data();
-                for (int i = chunk(t); i < chunk(t + 1); i++)
-                    c[key_of(i)]++;
-            });
+            const int nth = on_dev ? 1 : nt;
+            std::vector<std::vector<int32_t> > count(nth, std::vector<int32_t>(nk, 0));
+            DevMem d_keys;
+            const unsigned vgrid = (unsigned)((V + 255) / 256);
+            if (on_dev)
+            {
+                FVB_HIP_CHECK(d_keys.alloc(sizeof(int32_t) * nk, stream));
+                FVB_HIP_CHECK(hipMemsetAsync(d_keys.p, 0, sizeof(int32_t) * nk, stream));
+                hipLaunchKernelGGL(slab_count_kernel, dim3(vgrid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, zmin, (int)dz,
+                    (int)lmin, (int)nl, (int32_t *)d_keys.p);
+                FVB_HIP_CHECK(hipMemcpyAsync(count[0].data(), d_keys.p, sizeof(int32_t) * nk, hipMemcpyDeviceToHost, stream));
+                FVB_HIP_CHECK(hipStreamSynchronize(stream));
+            }
+            else
+                parallel([&](int t) {
+                    int32_t *c = count[t].data();
+                    for (int i = chunk(t); i < chunk(t + 1); i++)
+                        c[key_of(i)]++;
+                });
             slab_first.assign((size_t)n_slabs + 1, 0);
             int32_t running = 0;
             for (size_t key = 0; key < nk; key++)
@@ -574,7 +640,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 if (key % nl == 0)
                     slab_first[key / nl] = (int32_t)level_pos.size();
                 const int32_t begin = running;
-                for (int t = 0; t < nt; t++) // thread order = index order
+                for (int t = 0; t < nth; t++) // thread order = index order
                 {
                     const int32_t n = count[t][key];
                     count[t][key] = running;
@@ -590,12 +656,25 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             slab_first[(size_t)n_slabs] = (int32_t)level_pos.size();
             if (sl_max_run <= 8192 && n_slabs <= 224)
             {
-                pos_of.assign((size_t)V, 0);
-                parallel([&](int t) {
-                    int32_t *c = count[t].data();
-                    for (int i = chunk(t); i < chunk(t + 1); i++)
-                        pos_of[(size_t)owned_begin + i] = c[key_of(i)]++;
-                });
+                if (on_dev)
+                {
+                    // count[0] holds every key's first position now: hand the positions out on the device
+                    FVB_HIP_CHECK(d_pos_of.alloc(sizeof(int32_t) * (size_t)V, stream));
+                    FVB_HIP_CHECK(hipMemcpyAsync(d_keys.p, count[0].data(), sizeof(int32_t) * nk, hipMemcpyHostToDevice, stream));
+                    hipLaunchKernelGGL(slab_place_kernel, dim3(vgrid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, zmin, (int)dz,
+                        (int)lmin, (int)nl, (int32_t *)d_keys.p, (int32_t *)d_pos_of.p);
+                    FVB_HIP_CHECK(hipGetLastError());
+                    FVB_HIP_CHECK(hipStreamSynchronize(stream)); // (count[0] and d_keys go out of scope)
+                }
+                else
+                {
+                    pos_of.assign((size_t)V, 0);
+                    parallel([&](int t) {
+                        int32_t *c = count[t].data();
+                        for (int i = chunk(t); i < chunk(t + 1); i++)
+                            pos_of[(size_t)owned_begin + i] = c[key_of(i)]++;
+                    });
+                }
                 n_pos = (n_owned + 15) / 16 * 16;
                 // lanes per run: the next power of two from 64 that holds the longest run, 1024 at most
                 while (sl_width < sl_max_run && sl_width < 1024)
@@ -697,10 +776,13 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     if (fast)
     {
         const size_t NP = (size_t)n_pos, ns = (size_t)n_spatial;
-        FVB_HIP_CHECK(d_pos_of.alloc(sizeof(int32_t) * (size_t)V, stream));
+        if (!d_pos_of.p)
+        {
+            FVB_HIP_CHECK(d_pos_of.alloc(sizeof(int32_t) * (size_t)V, stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(d_pos_of.p, pos_of.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
+        }
         FVB_HIP_CHECK(d_level_pos.alloc(sizeof(int32_t) * level_pos.size(), stream));
         FVB_HIP_CHECK(d_level_count.alloc(sizeof(int32_t) * level_count.size(), stream));
-        FVB_HIP_CHECK(hipMemcpyAsync(d_pos_of.p, pos_of.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_pos.p, level_pos.data(), sizeof(int32_t) * level_pos.size(), hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_count.p, level_count.data(), sizeof(int32_t) * level_count.size(), hipMemcpyHostToDevice, stream));
         // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; slab form: nbr [ns][6][NP]

@@ -419,7 +419,9 @@ def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch)
     # hand-over between slabs; the default picks the thickness from the volume) and the data-flow sweep of round 2
     forms = {}
     for name, env in (("default", {}), ("slabs of 1", {"FVB_SPATIAL_SLAB_DZ": "1"}), ("slabs of 2", {"FVB_SPATIAL_SLAB_DZ": "2"}),
-                      ("slabs of 3", {"FVB_SPATIAL_SLAB_DZ": "3"}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"})):
+                      ("slabs of 3", {"FVB_SPATIAL_SLAB_DZ": "3"}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"}),
+                      ("slab numbering on the host", {"FVB_SPATIAL_HOST_NUMBERING": "1"}),
+                      ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         forms[name] = hiplib.run_spatial_host(h, sp, y)
