@@ -384,6 +384,18 @@ struct fvb_spatial_run
     int fast_failed(bool &failed);
     // host-evaluated models: the linearisations the set-up re-centre reads (see HostLin below)
     const double *lin_cur = nullptr, *lin_next = nullptr;
+    hipStream_t setup_stream = nullptr;
+    hipEvent_t setup_done = nullptr;
+    ~fvb_spatial_run()
+    {
+        if (setup_stream)
+        {
+            (void)hipStreamSynchronize(setup_stream); // (before the buffers its kernel writes are given back)
+            (void)hipStreamDestroy(setup_stream);
+        }
+        if (setup_done)
+            (void)hipEventDestroy(setup_done);
+    }
 
     int open(const fvb_config *cfg_, const fvb_spatial *sp_, const void *d_data, const fvb_outputs *d_out, hipStream_t stream_);
     int ak_sums(double *host_sums);
@@ -433,6 +445,46 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     if (!k.setup)
         return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
+
+    // ---- Vb::SetupPerVoxelDists for every local voxel (ghosts included: their initial means are what the
+    // neighbouring slab starts from too) needs the series and the options only: it runs on a stream of its own
+    // while the host and this run's stream work out the geometry ----
+    FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V, stream));
+    FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V, stream));
+    int n_unmasked = cfg.n_times;
+    if (cfg.phi_index) // (a device pointer here: read it back once)
+    {
+        std::vector<uint8_t> h(cfg.n_times);
+        FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg.phi_index, h.size(), hipMemcpyDeviceToHost, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream));
+        n_unmasked = 0;
+        for (int t = 0; t < cfg.n_times; t++)
+            n_unmasked += (h[t] != 255);
+    }
+    {
+        SpatialArgs early;
+        memset(&early, 0, sizeof(early));
+        early.lin_cur = lin_cur;
+        early.lin_next = lin_next;
+        early.ka.cfg = cfg;
+        early.ka.out = *d_out;
+        early.ka.data = d_data;
+        early.ka.n_unmasked = n_unmasked;
+        early.ka.residual_mode = api_residual_mode();
+        early.ka.residual_tol = api_residual_tol();
+        early.state = (double *)d_state.p;
+        early.status = (int32_t *)d_status.p;
+        early.owned_begin = owned_begin;
+        early.owned_end = owned_end;
+        FVB_HIP_CHECK(hipStreamCreateWithFlags(&setup_stream, hipStreamNonBlocking));
+        FVB_HIP_CHECK(hipEventCreateWithFlags(&setup_done, hipEventDisableTiming));
+        // (the two buffers were allocated in `stream`'s order; the series is the caller's, complete in `stream`'s order too)
+        FVB_HIP_CHECK(hipEventRecord(setup_done, stream));
+        FVB_HIP_CHECK(hipStreamWaitEvent(setup_stream, setup_done, 0));
+        hipLaunchKernelGGL(k.setup, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, setup_stream, early);
+        FVB_HIP_CHECK(hipGetLastError());
+        FVB_HIP_CHECK(hipEventRecord(setup_done, setup_stream));
+    }
 
     // ---- geometry: neighbour table on the device where the geometry allows, else on the host ----
     const auto t_start = std::chrono::steady_clock::now();
@@ -728,7 +780,6 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     seg_start.push_back(owned_end);
     const int n_blocks = (int)seg_start.size() - 1;
     n_segments = n_blocks;
-    FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V, stream));
     FVB_HIP_CHECK(d_order.alloc(sizeof(int32_t) * order.size(), stream));
     FVB_HIP_CHECK(d_aK.alloc(sizeof(double) * FVB_MAX_PARAMS, stream));
     FVB_HIP_CHECK(d_sums.alloc(sizeof(double) * FVB_MAX_PARAMS * 2, stream));
@@ -736,7 +787,6 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     FVB_HIP_CHECK(d_seg_start.alloc(sizeof(int32_t) * seg_start.size(), stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_seg_start.p, seg_start.data(), sizeof(int32_t) * seg_start.size(), hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(d_fprior.alloc(sizeof(double), stream));
-    FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V, stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, stream));
     double aK0[FVB_MAX_PARAMS];
     for (int i = 0; i < FVB_MAX_PARAMS; i++)
@@ -833,27 +883,14 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sw_level_count = (const int32_t *)d_level_count.p;
         sa.n_levels = (int32_t)level_pos.size();
     }
-    // number of unmasked timepoints: phi_index is a device pointer here, read it back once
-    int n_unmasked = cfg.n_times;
-    if (cfg.phi_index)
-    {
-        std::vector<uint8_t> h(cfg.n_times);
-        FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg.phi_index, h.size(), hipMemcpyDeviceToHost, stream));
-        FVB_HIP_CHECK(hipStreamSynchronize(stream));
-        n_unmasked = 0;
-        for (int t = 0; t < cfg.n_times; t++)
-            n_unmasked += (h[t] != 255);
-    }
     sa.ka.n_unmasked = n_unmasked;
     // the argument block the per-level launches read (nothing in it changes per launch)
     FVB_HIP_CHECK(d_sa.alloc(sizeof(SpatialArgs), stream));
     FVB_HIP_CHECK(hipMemcpyAsync(d_sa.p, &sa, sizeof(SpatialArgs), hipMemcpyHostToDevice, stream));
     FVB_HIP_CHECK(hipStreamSynchronize(stream)); // `sa`, nn, order are pageable host memory
 
-    // Vb::SetupPerVoxelDists for every local voxel, ghosts included (their initial means are what
-    // the neighbouring slab starts from too)
-    hipLaunchKernelGGL(k.setup, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, stream, sa);
-    FVB_HIP_CHECK(hipGetLastError());
+    // everything after this waits for the set-up kernel (started at the top)
+    FVB_HIP_CHECK(hipStreamWaitEvent(stream, setup_done, 0));
     return 0;
 }
 
