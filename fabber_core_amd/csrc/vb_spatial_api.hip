@@ -638,7 +638,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         // level). dz: as few planes as keep the slabs within the chip's workgroups (every slab is one resident
         // workgroup): one plane per slab up to 192 planes. Thicker slabs mean fewer hand-overs between workgroups
         // (2.4 us each, one after the other) but longer runs and fewer groups per workgroup to hide the records'
-        // latency: measured at 128^3, 0.52 ms per sweep with dz = 1, 0.55 with 2, 0.87 with 4.
+        // latency: measured at 128^3, 0.51 ms per sweep with dz = 1, 0.65 with 2, 0.94 with 3, 1.04 with 4.
         // (with the co-ordinates on the device - the usual case - the numbering is three small kernels there; the
         // host does it with its threads otherwise: 3 ms at 128^3 against 0.2)
         const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING");
