@@ -594,7 +594,14 @@ void Vb::DoCalculations(FabberRunData &rundata)
         LOG << "Vb::Spatial calculations on the MI355X engine, " << m_nvoxels << " voxels x " << cfg.n_times
             << " timepoints, " << cfg.max_iterations << " iterations" << endl;
         s_progress_rundata = &rundata;
-        if (m_store->has_device_model)
+        if (m_store->has_device_model && devices_opt != "")
+        {
+            // devices=all | devices=0,1,...: z-slabs of the volume on several GPUs, pipelined first sweep
+            LOG << "Vb::devices=" << devices_opt << ": the volume is cut into z-slabs" << endl;
+            rc = fabber_vb_run_spatial_host_multi(&cfg, &sp, data.Store(), &out, device_list.empty() ? NULL : device_list.data(),
+                (int32_t)device_list.size(), spatial_progress);
+        }
+        else if (m_store->has_device_model)
             rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
         else
         {

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <vector>
@@ -173,8 +175,13 @@ struct DevMem
     hipStream_t stream = nullptr;
     ~DevMem()
     {
+        reset();
+    }
+    void reset()
+    {
         if (p)
             (void)hipFreeAsync(p, stream);
+        p = nullptr;
     }
     hipError_t alloc(size_t bytes, hipStream_t s = nullptr)
     {
@@ -1441,6 +1448,344 @@ static int32_t run_spatial_host_impl(const fvb_config *cfg, const fvb_spatial *s
         FVB_HIP_CHECK(hipMemcpy(out->status, dout.status, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
     if (dout.iterations)
         FVB_HIP_CHECK(hipMemcpy(out->iterations, dout.iterations, sizeof(int32_t) * V, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- spatial VB of one volume on several devices, driven by this one process ---------------------------------
+// The decomposition and the schedule of fabber_core_amd/spatial_mgpu.py (one process per GPU over
+// torch.distributed) inside the engine: z-slabs with ghost planes, the first sweep as a pipeline over chunks
+// of 16 global levels (slab r sweeps chunk c at tick c + r and hands its top planes to slab r + 1 after every
+// tick), the a_K sums added over the segments of the voxel list in voxel order, the prior term of the last
+// voxel from the last slab, the second sweep, the exchange of the boundary planes both ways. The result is the
+// single-device run bit for bit (tests/test_spatial_mgpu.py). Planes travel device to device
+// (hipMemcpyPeer between staging buffers; a device listed twice is a copy on itself).
+namespace
+{
+struct SlabRun
+{
+    int dev = 0, g0 = 0, b = 0, e = 0, g1 = 0; // local list = global voxels [g0, g1), owned [b, e)
+    hipStream_t stream = nullptr;
+    fvb_config d;
+    fvb_spatial sp;
+    fvb_outputs dout;
+    std::vector<int32_t> coords;
+    DevMem b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_status, b_it, stage_means, stage_status;
+    fvb_spatial_run *run = nullptr;
+    ~SlabRun()
+    {
+        (void)hipSetDevice(dev);
+        delete run; // (its buffers go back to this device's pool in its stream's order)
+        DevMem *mine[] = { &b_data, &b_design, &b_phi, &b_init, &b_mvn, &b_f, &b_status, &b_it, &stage_means, &stage_status };
+        for (DevMem *m : mine) // ... and this slab's, before the stream they are ordered on goes
+            m->reset();
+        for (DevMem &m : b_img)
+            m.reset();
+        if (stream)
+        {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+    }
+};
+
+// means and status of n voxels: slab `from`, local index v_from -> slab `to`, local index v_to
+int slab_transfer(SlabRun &from, int v_from, SlabRun &to, int v_to, int n, int P)
+{
+    if (n <= 0)
+        return 0;
+    FVB_HIP_CHECK(hipSetDevice(from.dev));
+    int rc = from.run->copy_means(v_from, n, (double *)from.stage_means.p, (int32_t *)from.stage_status.p, false);
+    if (rc)
+        return rc;
+    FVB_HIP_CHECK(hipMemcpyPeer(to.stage_means.p, to.dev, from.stage_means.p, from.dev, sizeof(double) * (size_t)P * n));
+    FVB_HIP_CHECK(hipMemcpyPeer(to.stage_status.p, to.dev, from.stage_status.p, from.dev, sizeof(int32_t) * (size_t)n));
+    FVB_HIP_CHECK(hipSetDevice(to.dev));
+    return to.run->copy_means(v_to, n, (double *)to.stage_means.p, (int32_t *)to.stage_status.p, true);
+}
+} // namespace
+
+int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int))
+{
+    int rc = api_validate(cfg, true);
+    if (rc)
+        return rc;
+    if (!sp || !sp->coords)
+        return api_fail(-42, "spatial description / coordinates missing");
+    if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
+        return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
+    if (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis != 1)
+        return api_fail(-44, "spatial VB is built for white noise with one noise parameter");
+    if (cfg->model == FVB_MODEL_HOSTJAC)
+        return api_fail(-56, "a model evaluated on the host runs spatial VB on one device (fabber_vb_run_spatial_hostmodel_host)");
+    if (!out || !out->mvn)
+        return api_fail(-20, "outputs.mvn is required");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
+        return api_fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
+    std::vector<int> devs;
+    if (devices)
+    {
+        if (n_devices <= 0)
+            return api_fail(-31, "empty device list");
+        for (int i = 0; i < n_devices; i++)
+        {
+            if (devices[i] < 0 || devices[i] >= visible)
+                return api_fail(-31, "device index " + std::to_string(devices[i]) + " out of range (" + std::to_string(visible) + " visible)");
+            devs.push_back(devices[i]);
+        }
+    }
+    else
+        for (int i = 0; i < visible; i++)
+            devs.push_back(i);
+    const int V = cfg->n_voxels, T = cfg->n_times, P = cfg->n_params;
+    if (V == 0)
+        return 0;
+    if (!data)
+        return api_fail(-21, "data is NULL");
+    const int32_t *X = sp->coords, *Y = sp->coords + V, *Z = sp->coords + 2 * (size_t)V;
+    bool second = false, has_spatial = false;
+    for (int k = 0; k < P; k++)
+    {
+        second |= (cfg->prior_type[k] == FVB_PRIOR_SPATIAL_P || cfg->prior_type[k] == FVB_PRIOR_SPATIAL_p);
+        has_spatial |= cfg->prior_type[k] >= FVB_PRIOR_SPATIAL_M;
+    }
+    const int halo = second ? 2 : 1;
+    // ---- the slabs: cuts on z-plane boundaries, balanced by voxel count; fewer slabs if the planes do not go round ----
+    std::vector<int> plane_start;
+    for (int v = 0; v < V; v++)
+    {
+        if (v > 0 && Z[v] < Z[v - 1])
+            return api_fail(-41, "Coordinate matrix must be in correct order to use adjacency-based priors.");
+        if (v == 0 || Z[v] != Z[v - 1])
+            plane_start.push_back(v);
+    }
+    int world = (int)std::min<size_t>(devs.size(), std::max<size_t>(1, plane_start.size() / (size_t)(2 * halo)));
+    if (world <= 1)
+        return fabber_vb_run_spatial_host(cfg, sp, data, out, devs[0], progress_cb);
+    std::vector<int> bounds(1, 0);
+    for (int r = 1; r < world; r++)
+    {
+        const double want = (double)V * r / world;
+        int best = plane_start[1];
+        for (int s0 : plane_start)
+            if (s0 > bounds.back() && std::fabs(s0 - want) < std::fabs(best - want))
+                best = s0;
+        if (best <= bounds.back())
+            best = *std::upper_bound(plane_start.begin(), plane_start.end(), bounds.back());
+        bounds.push_back(best);
+    }
+    bounds.push_back(V);
+    std::vector<std::unique_ptr<SlabRun> > slabs;
+    for (int r = 0; r < world; r++)
+    {
+        std::unique_ptr<SlabRun> sl(new SlabRun);
+        sl->dev = devs[r];
+        sl->b = bounds[r];
+        sl->e = bounds[r + 1];
+        sl->g0 = sl->b;
+        sl->g1 = sl->e;
+        if (r > 0)
+            sl->g0 = (int)(std::lower_bound(Z, Z + V, Z[sl->b] - halo) - Z);
+        if (r < world - 1)
+            sl->g1 = (int)(std::upper_bound(Z, Z + V, Z[sl->e - 1] + halo) - Z);
+        if ((r > 0 && sl->g0 < bounds[r - 1]) || (r < world - 1 && sl->g1 > bounds[r + 2]))
+            return api_fail(-48, "a slab is thinner than the halo of its neighbour: use fewer devices for this volume");
+        slabs.push_back(std::move(sl));
+    }
+    // ---- per slab: its part of the problem on its device, a run handle ----
+    const int n = P + 1, rows = n * (n + 1) / 2 + n + 1;
+    const size_t esz = cfg->data_f64 ? 8 : 4;
+    int max_halo = 1;
+    for (int r = 0; r < world; r++)
+        max_halo = std::max(max_halo, std::max(slabs[r]->b - slabs[r]->g0, slabs[r]->g1 - slabs[r]->e));
+    for (int r = 0; r < world; r++)
+    {
+        SlabRun &sl = *slabs[r];
+        const size_t Vl = (size_t)(sl.g1 - sl.g0);
+        FVB_HIP_CHECK(hipSetDevice(sl.dev));
+        FVB_HIP_CHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        hipStream_t st = sl.stream;
+        auto upload_rows = [&](void *dst, const void *src, size_t elem, size_t nrows) {
+            return hipMemcpy2DAsync(dst, Vl * elem, (const char *)src + (size_t)sl.g0 * elem, (size_t)V * elem, Vl * elem, nrows,
+                hipMemcpyHostToDevice, st);
+        };
+        sl.d = *cfg;
+        sl.d.n_voxels = (int32_t)Vl;
+        FVB_HIP_CHECK(sl.b_data.alloc((size_t)T * Vl * esz, st));
+        FVB_HIP_CHECK(upload_rows(sl.b_data.p, data, esz, (size_t)T));
+        if (cfg->design)
+        {
+            FVB_HIP_CHECK(sl.b_design.alloc(sizeof(double) * (size_t)T * P, st));
+            FVB_HIP_CHECK(hipMemcpyAsync(sl.b_design.p, cfg->design, sizeof(double) * (size_t)T * P, hipMemcpyHostToDevice, st));
+            sl.d.design = (const double *)sl.b_design.p;
+        }
+        if (cfg->phi_index)
+        {
+            FVB_HIP_CHECK(sl.b_phi.alloc((size_t)T, st));
+            FVB_HIP_CHECK(hipMemcpyAsync(sl.b_phi.p, cfg->phi_index, (size_t)T, hipMemcpyHostToDevice, st));
+            sl.d.phi_index = (const uint8_t *)sl.b_phi.p;
+        }
+        if (cfg->init_mvn)
+        {
+            FVB_HIP_CHECK(sl.b_init.alloc(sizeof(double) * rows * Vl, st));
+            FVB_HIP_CHECK(upload_rows(sl.b_init.p, cfg->init_mvn, sizeof(double), (size_t)rows));
+            sl.d.init_mvn = (const double *)sl.b_init.p;
+        }
+        for (int k = 0; k < P; k++)
+            if (cfg->image_prior[k])
+            {
+                FVB_HIP_CHECK(sl.b_img[k].alloc(sizeof(double) * Vl, st));
+                FVB_HIP_CHECK(upload_rows(sl.b_img[k].p, cfg->image_prior[k], sizeof(double), 1));
+                sl.d.image_prior[k] = (const double *)sl.b_img[k].p;
+            }
+        memset(&sl.dout, 0, sizeof(sl.dout));
+        FVB_HIP_CHECK(sl.b_mvn.alloc(sizeof(double) * rows * Vl, st));
+        sl.dout.mvn = (double *)sl.b_mvn.p;
+        if (out->free_energy)
+        {
+            FVB_HIP_CHECK(sl.b_f.alloc(sizeof(double) * Vl, st));
+            FVB_HIP_CHECK(hipMemsetAsync(sl.b_f.p, 0xff, sizeof(double) * Vl, st)); // NaN (see fabber_vb_run_spatial_host)
+            sl.dout.free_energy = (double *)sl.b_f.p;
+        }
+        if (out->status)
+        {
+            FVB_HIP_CHECK(sl.b_status.alloc(sizeof(int32_t) * Vl, st));
+            sl.dout.status = (int32_t *)sl.b_status.p;
+        }
+        if (out->iterations)
+        {
+            FVB_HIP_CHECK(sl.b_it.alloc(sizeof(int32_t) * Vl, st));
+            sl.dout.iterations = (int32_t *)sl.b_it.p;
+        }
+        FVB_HIP_CHECK(sl.stage_means.alloc(sizeof(double) * (size_t)P * max_halo, st));
+        FVB_HIP_CHECK(sl.stage_status.alloc(sizeof(int32_t) * (size_t)max_halo, st));
+        FVB_HIP_CHECK(hipStreamSynchronize(st)); // (the uploads read pageable host memory)
+        sl.coords.resize(3 * Vl);
+        for (int dim = 0; dim < 3; dim++)
+            std::copy(sp->coords + (size_t)dim * V + sl.g0, sp->coords + (size_t)dim * V + sl.g1, sl.coords.begin() + (size_t)dim * Vl);
+        sl.sp = *sp;
+        sl.sp.coords = sl.coords.data();
+        sl.sp.owned_begin = sl.b - sl.g0;
+        sl.sp.owned_end = sl.e - sl.g0;
+        sl.sp.n_voxels_global = V;
+        sl.run = new fvb_spatial_run;
+        if ((rc = sl.run->open(&sl.d, &sl.sp, sl.b_data.p, &sl.dout, st)) != 0)
+            return rc;
+    }
+    // ---- the global level range and the pipeline's ticks ----
+    const long long w0 = slabs[0]->run->level_w[0], w1 = slabs[0]->run->level_w[1], w2 = slabs[0]->run->level_w[2];
+    long long lmin = LLONG_MAX, lmax = LLONG_MIN;
+    for (int v = 0; v < V; v++)
+    {
+        const long long l = w0 * X[v] + w1 * Y[v] + w2 * Z[v];
+        lmin = std::min(lmin, l);
+        lmax = std::max(lmax, l);
+    }
+    const long long chunk_levels = 16;
+    const long long nchunks = std::max(1LL, (lmax - lmin + chunk_levels) / chunk_levels);
+    std::vector<double> partials, sums((size_t)P * 2);
+    for (int it = 0; it < cfg->max_iterations; it++)
+    {
+        if (progress_cb)
+            progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
+        if (has_spatial && (it > 0 || sp->update_first_iter))
+        {
+            // a_K: every slab's segment sums, added in the order of the voxel list (vb_spatial_ak_reduce_kernel's)
+            std::fill(sums.begin(), sums.end(), 0.0);
+            for (int r = 0; r < world; r++)
+            {
+                SlabRun &sl = *slabs[r];
+                FVB_HIP_CHECK(hipSetDevice(sl.dev));
+                partials.assign((size_t)std::max(sl.run->n_segments, 1) * P * 2, 0.0);
+                if ((rc = sl.run->ak_segment_sums(partials.data())) != 0)
+                    return rc;
+                for (int seg = 0; seg < sl.run->n_segments; seg++)
+                    for (int j = 0; j < 2 * P; j++)
+                        sums[j] = sums[j] + partials[(size_t)seg * 2 * P + j];
+            }
+            for (int r = 0; r < world; r++)
+            {
+                FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                if ((rc = slabs[r]->run->set_ak_sums(sums.data())) != 0)
+                    return rc;
+            }
+        }
+        for (long long tick = 0; tick < nchunks + world - 1; tick++)
+        {
+            for (int r = 0; r < world; r++)
+            {
+                const long long c = tick - r;
+                if (c < 0 || c >= nchunks)
+                    continue;
+                FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                if ((rc = slabs[r]->run->sweep_levels(it, lmin + c * chunk_levels, lmin + (c + 1) * chunk_levels)) != 0)
+                    return rc;
+            }
+            if (!has_spatial)
+                continue;
+            for (int r = 0; r + 1 < world; r++) // whoever swept hands its top planes up
+            {
+                const long long c = tick - r;
+                if (c < 0 || c >= nchunks)
+                    continue;
+                SlabRun &lo = *slabs[r], &hi = *slabs[r + 1];
+                const int from = std::max(lo.b, hi.g0);
+                if ((rc = slab_transfer(lo, from - lo.g0, hi, from - hi.g0, lo.e - from, P)) != 0)
+                    return rc;
+            }
+        }
+        if (cfg->need_f) // the F term of the priors of the LAST voxel of the sweep is the last slab's (inference_vb.cc:612,689,702)
+        {
+            double fp = 0;
+            FVB_HIP_CHECK(hipSetDevice(slabs[world - 1]->dev));
+            if ((rc = fabber_vb_spatial_fprior(slabs[world - 1]->run, &fp, 0)) != 0)
+                return rc;
+            for (int r = 0; r + 1 < world; r++)
+            {
+                FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                if ((rc = fabber_vb_spatial_fprior(slabs[r]->run, &fp, 1)) != 0)
+                    return rc;
+            }
+        }
+        for (int r = 0; r < world; r++)
+        {
+            FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+            if ((rc = slabs[r]->run->sweep_noise(it)) != 0)
+                return rc;
+        }
+        if (has_spatial)
+            for (int r = 0; r + 1 < world; r++) // boundary planes both ways
+            {
+                SlabRun &lo = *slabs[r], &hi = *slabs[r + 1];
+                const int up_from = std::max(lo.b, hi.g0);
+                if ((rc = slab_transfer(lo, up_from - lo.g0, hi, up_from - hi.g0, lo.e - up_from, P)) != 0)
+                    return rc;
+                const int down_to = std::min(hi.e, lo.g1);
+                if ((rc = slab_transfer(hi, hi.b - hi.g0, lo, hi.b - lo.g0, down_to - hi.b, P)) != 0)
+                    return rc;
+            }
+    }
+    // ---- results: every slab packs its voxels, the owned ones go to the caller's images ----
+    for (int r = 0; r < world; r++)
+    {
+        SlabRun &sl = *slabs[r];
+        FVB_HIP_CHECK(hipSetDevice(sl.dev));
+        if ((rc = sl.run->finish()) != 0)
+            return rc;
+        const size_t Vl = (size_t)(sl.g1 - sl.g0), own = (size_t)(sl.e - sl.b), skip = (size_t)(sl.b - sl.g0);
+        auto download_rows = [&](void *dst, const void *src, size_t elem, size_t nrows) {
+            return hipMemcpy2D((char *)dst + (size_t)sl.b * elem, (size_t)V * elem, (const char *)src + skip * elem, Vl * elem, own * elem, nrows,
+                hipMemcpyDeviceToHost);
+        };
+        FVB_HIP_CHECK(download_rows(out->mvn, sl.dout.mvn, sizeof(double), (size_t)rows));
+        if (sl.dout.free_energy)
+            FVB_HIP_CHECK(download_rows(out->free_energy, sl.dout.free_energy, sizeof(double), 1));
+        if (sl.dout.status)
+            FVB_HIP_CHECK(download_rows(out->status, sl.dout.status, sizeof(int32_t), 1));
+        if (sl.dout.iterations)
+            FVB_HIP_CHECK(download_rows(out->iterations, sl.dout.iterations, sizeof(int32_t), 1));
+    }
     return 0;
 }
 

@@ -234,8 +234,10 @@ def ldl_inverse(a):
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int)
 
 
-def run_spatial_host(holder, spatial, data, device=0, progress_cb=None):
-    """Spatial VB on the GPU from host arrays. spatial: vbabi.SpatialHolder."""
+def run_spatial_host(holder, spatial, data, device=0, progress_cb=None, devices=None):
+    """Spatial VB on the GPU from host arrays. spatial: vbabi.SpatialHolder. devices: "all" or a list of device
+    indices - z-slabs of the one volume on several devices, driven by this process
+    (fabber_vb_run_spatial_host_multi)."""
     cfg = holder.cfg
     data = _prepare_data(holder, data)
     V = cfg.n_voxels
@@ -253,8 +255,16 @@ def run_spatial_host(holder, spatial, data, device=0, progress_cb=None):
     L.fabber_vb_run_spatial_host.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbSpatial), C.c_void_p,
                                              C.POINTER(vbabi.FvbOutputs), C.c_int32, C.c_void_p]
     cb = PROGRESS_CB(progress_cb) if progress_cb else None
-    _check(L.fabber_vb_run_spatial_host(C.byref(cfg), C.byref(spatial.sp), data.ctypes.data, C.byref(out), device,
-                                        C.cast(cb, C.c_void_p) if cb else None))
+    if devices is not None:
+        L.fabber_vb_run_spatial_host_multi.restype = C.c_int32
+        L.fabber_vb_run_spatial_host_multi.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbSpatial), C.c_void_p,
+                                                       C.POINTER(vbabi.FvbOutputs), C.c_void_p, C.c_int32, C.c_void_p]
+        ids = None if devices == "all" else (C.c_int32 * len(devices))(*devices)
+        _check(L.fabber_vb_run_spatial_host_multi(C.byref(cfg), C.byref(spatial.sp), data.ctypes.data, C.byref(out), ids,
+                                                  0 if ids is None else len(devices), C.cast(cb, C.c_void_p) if cb else None))
+    else:
+        _check(L.fabber_vb_run_spatial_host(C.byref(cfg), C.byref(spatial.sp), data.ctypes.data, C.byref(out), device,
+                                            C.cast(cb, C.c_void_p) if cb else None))
     arrs["setup_failed"] = (arrs["status"] & 0x100) != 0
     arrs["status"] = arrs["status"] & 0xFF
     return arrs

@@ -351,6 +351,19 @@ int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const void *data, co
     fvb_linearise_fn linearise, void *user);
 
 /*
+ * fabber_vb_run_spatial_host on several devices of the node, driven by the calling process: the volume is cut
+ * into z-slabs (cuts on plane boundaries, balanced by voxel count; ghost planes each side: one, two with priors
+ * of type P / p), slab r on devices[r] (NULL / 0 = every visible device; a device may be listed several times).
+ * The first sweep keeps the reference's order across the cuts - the slabs step through the SAME global levels as a
+ * pipeline, slab r one chunk of levels behind slab r - 1, boundary planes handed upwards device to device after
+ * every chunk -, the a_K sums are added over the segments of the voxel list in voxel order: the images are those of
+ * the one-device run bit for bit. Fewer slabs than devices where the volume has too few planes. Host pointers
+ * throughout; models evaluated on the host are not taken (-56).
+ */
+int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int));
+
+/*
  * Spatial VB (Vb::DoCalculationsSpatial, inference_vb.cc:578-767) with such a model: any FwdModel of a model
  * library under method=spatialvb, as in the reference. The two places of the loop that run the model - the
  * set-up re-centre (:235) and the re-centre that ends every iteration's second sweep (:695) - call `linearise`

@@ -275,3 +275,49 @@ def test_slabs_with_free_energy_ard_and_a_failing_voxel(tmp_path):
     for k in ("mvn", "status", "free_energy"):
         got = np.concatenate([p[k] for p in parts], axis=-1)
         assert np.array_equal(got, ref[k], equal_nan=True), k
+
+
+# ---- the same decomposition inside the engine: one process, several devices (fabber_vb_run_spatial_host_multi) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ,slabs", [("M", 2), ("P", 2), ("M", 3), ("M", 5)])
+def test_engine_slabs_against_the_single_device_run(typ, slabs):
+    """devices = the one GPU listed 2, 3, 5 times (a device copies to itself where two GPUs would copy to each
+    other): z-slabs with ghost planes, pipelined first sweep, device-to-device hand-over of the boundary planes -
+    every output identical to the one-device run, first- and second-neighbour priors"""
+    h, sp, y = spatial_problem(typ)
+    ref = hiplib.run_spatial_host(h, sp, y)
+    got = hiplib.run_spatial_host(h, sp, y, devices=[0] * slabs)
+    assert np.all(got["status"] == 0) and np.all(got["iterations"] == 8)
+    for k in ("mvn", "status", "iterations"):
+        assert np.array_equal(got[k], ref[k]), (typ, slabs, k)
+
+
+@pytest.mark.gpu
+def test_engine_slabs_with_free_energy_ard_and_a_failing_voxel():
+    h, sp, y = ard_problem()
+    ref = hiplib.run_spatial_host(h, sp, y)
+    got = hiplib.run_spatial_host(h, sp, y, devices=[0, 0])
+    assert np.count_nonzero(ref["status"]) == 1
+    for k in ("mvn", "status", "free_energy", "iterations"):
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    # "all" on the one-GPU box is one slab: the single-device entry point itself
+    alone = hiplib.run_spatial_host(h, sp, y, devices="all")
+    assert np.array_equal(alone["mvn"], ref["mvn"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_devices_option_with_spatialvb():
+    """`devices=0,0` through fabber_dorun with method=spatialvb: the images of the run without it"""
+    from fabber_core_amd import fabber
+    rng = np.random.default_rng(8)
+    shape, T = (7, 6, 8), 16
+    t = np.arange(1, T + 1)
+    c0 = 2.0 + np.sin(np.arange(shape[0])[:, None, None] / 2.0) + np.zeros(shape)
+    data = (c0[..., None] + 0.3 * t + rng.normal(0, 0.2, shape + (T,))).astype(np.float32)
+    opts = {"model": "poly", "degree": 1, "noise": "white", "method": "spatialvb", "max-iterations": 5, "param-spatial-priors": "MN",
+            "save-mean": True, "save-mvn": True}
+    one = fabber.run(data, opts)
+    two = fabber.run(data, dict(opts, devices="0,0"))
+    assert "z-slabs" in two["log"]
+    for k in ("finalMVN", "mean_c0", "mean_c1"):
+        assert np.array_equal(one[k], two[k]), k
