@@ -194,12 +194,36 @@ def bench_single_process(args):
     rate a fabber_dorun caller with devices=all sees, not the device-resident headline."""
     from fabber_core_amd import hiplib
     w = WORKLOADS[args.workload]
-    if w.get("kind") == "spatial":
-        raise SystemExit("--single-process shards voxelwise VB; spatial VB runs on one device")
     n = args.gpus
     visible = hiplib.device_count()
     if visible < n:
         raise SystemExit("--gpus %d but only %d device(s) visible" % (n, visible))
+    if w.get("kind") == "spatial":
+        # C5 on N devices of the node: z-slabs of the ONE volume (strong scaling), pipelined first sweep, boundary
+        # planes device to device (fabber_vb_run_spatial_host_multi); host buffers in and out
+        import cases
+        from fabber_core_amd import vbabi
+        g = args.grid or w["grid"]
+        holder, coords, y, _ = cases.c5_problem((g, g, g), max_iterations=w["its"], need_f=bool(args.need_f))
+        sp = vbabi.SpatialHolder(coords)
+        V = holder.cfg.n_voxels
+        devices = list(range(n))
+        for _ in range(args.warmup):
+            hiplib.run_spatial_host(holder, sp, y, devices=devices)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = hiplib.run_spatial_host(holder, sp, y, devices=devices)
+        elapsed = time.perf_counter() - t0
+        result = {"metric": "voxels/sec to VB convergence", "value": V * args.steps / elapsed, "unit": "voxels/s", "n_gpus": n,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                  "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                  "config": {"workload": w["desc"], "total_voxels": V, "timepoints": w["T"], "params": holder.cfg.n_params,
+                             "iterations": w["its"], "need_f": bool(args.need_f),
+                             "parallelism": "one process, fabber_vb_run_spatial_host_multi: %d z-slab(s), host buffers (PCIe-inclusive)" % n,
+                             "input_dtype": "f32", "bad_voxels": int(np.count_nonzero(res["status"]))},
+                  "roofline": None, "cpu_baseline": None}
+        print(json.dumps(result), flush=True)
+        return result
     V = (args.voxels or w["voxels"]) * n
     holder, y = make_problem(w, V, 20260103, bool(args.need_f))
     devices = list(range(n))
