@@ -1458,7 +1458,7 @@ static int32_t run_spatial_host_impl(const fvb_config *cfg, const fvb_spatial *s
 // tick), the a_K sums added over the segments of the voxel list in voxel order, the prior term of the last
 // voxel from the last slab, the second sweep, the exchange of the boundary planes both ways. The result is the
 // single-device run bit for bit (tests/test_spatial_mgpu.py). Planes travel device to device
-// (hipMemcpyPeer between staging buffers; a device listed twice is a copy on itself).
+// (hipMemcpyPeerAsync between staging buffers; a device listed twice is a copy on itself).
 namespace
 {
 struct SlabRun
@@ -1497,9 +1497,11 @@ int slab_transfer(SlabRun &from, int v_from, SlabRun &to, int v_to, int n, int P
     int rc = from.run->copy_means(v_from, n, (double *)from.stage_means.p, (int32_t *)from.stage_status.p, false);
     if (rc)
         return rc;
-    FVB_HIP_CHECK(hipMemcpyPeer(to.stage_means.p, to.dev, from.stage_means.p, from.dev, sizeof(double) * (size_t)P * n));
-    FVB_HIP_CHECK(hipMemcpyPeer(to.stage_status.p, to.dev, from.stage_status.p, from.dev, sizeof(int32_t) * (size_t)n));
+    // (in the receiving slab's stream: ordered before the copy into its state, which ends with a wait for that
+    // stream - so the sender's staging buffer is free again on return; the sender's copy above has completed)
     FVB_HIP_CHECK(hipSetDevice(to.dev));
+    FVB_HIP_CHECK(hipMemcpyPeerAsync(to.stage_means.p, to.dev, from.stage_means.p, from.dev, sizeof(double) * (size_t)P * n, to.stream));
+    FVB_HIP_CHECK(hipMemcpyPeerAsync(to.stage_status.p, to.dev, from.stage_status.p, from.dev, sizeof(int32_t) * (size_t)n, to.stream));
     return to.run->copy_means(v_to, n, (double *)to.stage_means.p, (int32_t *)to.stage_status.p, true);
 }
 } // namespace
@@ -1682,7 +1684,9 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         lmin = std::min(lmin, l);
         lmax = std::max(lmax, l);
     }
-    const long long chunk_levels = 16;
+    long long chunk_levels = 16;
+    if (const char *forced = getenv("FVB_SPATIAL_CHUNK_LEVELS")) // tests: other cuts of the level range
+        chunk_levels = std::max(1, atoi(forced));
     const long long nchunks = std::max(1LL, (lmax - lmin + chunk_levels) / chunk_levels);
     std::vector<double> partials, sums((size_t)P * 2);
     for (int it = 0; it < cfg->max_iterations; it++)

@@ -321,3 +321,20 @@ def test_devices_option_with_spatialvb():
     assert "z-slabs" in two["log"]
     for k in ("finalMVN", "mean_c0", "mean_c1"):
         assert np.array_equal(one[k], two[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slabs", [4, 8])
+def test_engine_slabs_at_a_size_where_the_streams_overlap(slabs, monkeypatch):
+    """64^3 bi-exponential volume (configs[4]'s model and prior), 3 iterations: with this much work in flight on
+    every slab's stream a hand-over that is not ordered against them shows (it did: hipMemcpyPeer does not wait
+    for non-blocking streams); also with the level range cut into chunks of 10"""
+    import cases
+    h, coords, y, _ = cases.c5_problem((64, 64, 64), max_iterations=3)
+    sp = vbabi.SpatialHolder(coords)
+    ref = hiplib.run_spatial_host(h, sp, y)
+    got = hiplib.run_spatial_host(h, sp, y, devices=[0] * slabs)
+    assert np.array_equal(got["mvn"], ref["mvn"], equal_nan=True) and np.array_equal(got["status"], ref["status"])
+    monkeypatch.setenv("FVB_SPATIAL_CHUNK_LEVELS", "10")
+    got = hiplib.run_spatial_host(h, sp, y, devices=[0] * slabs)
+    assert np.array_equal(got["mvn"], ref["mvn"], equal_nan=True)
