@@ -112,7 +112,12 @@ LaneKernelInfo select_lane(const fvb_config *cfg)
 {
     if (g_variant == 2 || (cfg->n_phis != 1 && (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis > 4)))
         return LaneKernelInfo{ nullptr, 0, nullptr };
-    if (g_variant == 0 && cfg->noise == FVB_NOISE_WHITE && cfg->n_voxels < WAVE_KERNEL_BELOW_VOXELS
+    // ... for models whose re-linearisation is long enough to be worth sharing out over 64 lanes: T (2P + 1) model
+    // evaluations per pass, an exponential counted twice. Below ~400 of them (C1: a quadratic over 10 timepoints = 70)
+    // the wave kernel's per-iteration synchronisation outweighs what it shares, whatever the voxel count: 512 voxels
+    // of C1 take 0.058 ms on the lane kernel against 0.105 ms.
+    const double evaluations = (double)cfg->n_times * (2 * cfg->n_params + 1) * (cfg->model == FVB_MODEL_EXP ? 2.0 : 1.0);
+    if (g_variant == 0 && cfg->noise == FVB_NOISE_WHITE && cfg->n_voxels < WAVE_KERNEL_BELOW_VOXELS && evaluations >= 400
         && wave_layout(cfg->n_times, cfg->n_params, cfg->n_phis).bytes <= 160 * 1024)
         return LaneKernelInfo{ nullptr, 0, nullptr };
     const bool need_f = cfg->need_f != 0;
