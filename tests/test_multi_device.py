@@ -88,3 +88,23 @@ def test_devices_option_through_the_c_api():
         assert "devices=" + devices in got["log"]
     with pytest.raises(Exception, match="devices"):
         fabber.run(data, dict(opts, devices="0,,1"))
+
+
+def test_several_noise_precisions_are_cut_with_the_blocks():
+    """noise-pattern on the lane kernel with per-precision moments, the voxel list cut into blocks"""
+    rng = np.random.default_rng(12)
+    h, y = cases.poly_problem(5000, 24, 2, seed=13, noise_pattern="123", max_iterations=6, need_f=True)
+    y = y.astype(np.float64) + rng.normal(0, 0.05, y.shape) * (1 + np.arange(24)[:, None] % 3)
+    assert hiplib.kernel_name(h) == "lane_phis<poly,3,4>"
+    same(hiplib.run_host(h, y), hiplib.run_host(h, y, devices=[0, 0, 0]))
+
+
+def test_cached_device_memory_can_be_given_back():
+    """the engine's work buffers come from the device's memory pool, which keeps them between runs;
+    fabber_vb_release_cached_memory returns them - and the next run allocates again"""
+    h, y = cases.exp_problem(8192, 50, 1, 0.04, seed=3, max_iterations=5)
+    first = hiplib.run_host(h, y)
+    lib = hiplib.lib()
+    lib.fabber_vb_release_cached_memory.restype = None
+    lib.fabber_vb_release_cached_memory()
+    same(first, hiplib.run_host(h, y))
