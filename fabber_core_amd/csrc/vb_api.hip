@@ -27,7 +27,7 @@ thread_local std::string g_last_error;
 int g_variant = 0; // 0 auto, 1 lane, 2 wave
 int g_residual_mode = 0; // 0 adaptive, 1 always exact, 2 moments only
 // linearisations of a run that evaluate the model pointwise (vb_lane_kernel.h); the environment variable is an experiment switch
-int g_precise_passes = getenv("FVB_PRECISE_PASSES") ? atoi(getenv("FVB_PRECISE_PASSES")) : 2;
+int g_precise_passes = getenv("FVB_PRECISE_PASSES") ? atoi(getenv("FVB_PRECISE_PASSES")) : -1; // -1: by model, see run_device_as
 bool g_tiled = getenv("FVB_NO_TILES") == nullptr; // experiment switch: FVB_NO_TILES=1 keeps the in-place (strided) feed
 double g_residual_tol = 1e-10; // moments value keeps >= 6 significant digits where it is used
 
@@ -416,7 +416,12 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
     ka.n_unmasked = n_unmasked;
     ka.residual_mode = g_residual_mode;
     ka.residual_tol = g_residual_tol;
-    ka.precise_passes = g_precise_passes;
+    // The first linearisations of a run evaluate the model pointwise (vb_lane_kernel.h, recentre): two where the
+    // model has several exponentials - they start with identical rates, J'J is singular to rounding and what the
+    // first passes round is amplified for iterations (measured against the binary128 ground truth) -,
+    // one for a single exponential (20 000 voxels of C2 against the oracle: median 1.5e-10 and 99th percentile
+    // 1.1e-8 with one as with two, maximum 1.5e-6 against 1.1e-6, two CPU builds 8.3e-7 apart; 8 % of C2's time).
+    ka.precise_passes = g_precise_passes >= 0 ? g_precise_passes : ((cfg->model == FVB_MODEL_EXP && cfg->n_params >= 4) ? 2 : 1);
 
     fvb_config choice = *cfg;
     choice.n_voxels = kernel_voxels;
