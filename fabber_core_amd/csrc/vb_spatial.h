@@ -591,11 +591,13 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
 // inverse Sigma and every entry of eq (20)'s right-hand side except mu0_k's are known for all voxels at
 // once. The sweep that has to respect the reference's voxel order shrinks to
 //        m_k(v) = sum_j Sigma_kj rhs_j,   rhs_k = fma(prec0_k, mu0_k, base_k)
-// a dozen multiply-adds per voxel on values laid out level-major. Three steps per iteration:
+// a dozen multiply-adds per voxel on records laid out in the order of the sweep. Three steps per iteration:
 //   vb_spatial_prep_kernel   all voxels in parallel: priors, Lambda, Sigma, right-hand sides -> sweep records
-//   vb_spatial_sweep_kernel  ONE launch: a few workgroups walk the levels in order with a counter barrier
-//                            between levels (means handed over with sc1 stores / loads, MI355X_MICROARCH.md
-//                            "Valid forms", row 1) and update the spatial parameters' means in place
+//   the ordered part         ONE launch that updates the spatial parameters' means in place:
+//     vb_spatial_slab_sweep_kernel  (what runs) a workgroup per z-slab, the previous level's means in LDS, an
+//                            inbox hand-over between slabs - further down
+//     vb_spatial_sweep_kernel       (FVB_SPATIAL_SWEEP=poll) every lane walks the levels and polls exactly the
+//                            neighbours it needs through device-scope granules, no barrier
 //   vb_spatial_noise_kernel  (FAST) first completes the other means from the sweep's result - the same
 //                            theta_rhs / theta_mean sequence update_theta runs, so the posterior is the
 //                            per-level kernels' bit for bit - then carries on with the second sweep
