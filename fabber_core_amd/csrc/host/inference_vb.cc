@@ -603,7 +603,16 @@ void Vb::DoCalculations(FabberRunData &rundata)
         }
         else if (m_store->has_device_model)
             rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
-        else
+        if (m_store->has_device_model && rc == -40)
+        {
+            // no spatial kernels were built for this model with this many parameters: the model's own host code
+            // does the re-centres instead (up to 8 parameters)
+            LOG << "Vb::no device kernels for spatial VB with " << cfg.n_params << " parameters of this model" << endl;
+            m_store->has_device_model = false;
+            cfg.model = FVB_MODEL_HOSTJAC;
+            cfg.design = NULL;
+        }
+        if (!m_store->has_device_model)
         {
             // any FwdModel under spatial VB, as in the reference: the model's two re-centres per iteration
             // run here on the host, the sweeps on the device (fabber_vb_run_spatial_hostmodel_host)

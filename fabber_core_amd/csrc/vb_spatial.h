@@ -1435,6 +1435,7 @@ struct SpatialKernels
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
 SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
+SpatialKernels get_spatial_kernels_more(int model, int P, bool need_f); // the larger parameter counts of the three above
 SpatialKernels get_spatial_kernels_host(int P, bool need_f); // models evaluated on the host (HostLinModel)
 
 #define FVB_SPATIAL_CASE(MODEL, TAG, PP)                                                                     \

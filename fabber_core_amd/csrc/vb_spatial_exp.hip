@@ -10,7 +10,7 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f)
         FVB_SPATIAL_CASE(ExpModel, "exp", 2)
         FVB_SPATIAL_CASE(ExpModel, "exp", 4)
     default:
-        return SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+        return get_spatial_kernels_more(FVB_MODEL_EXP, P, need_f); // vb_spatial_more.hip
     }
 }
 } // namespace fvb

@@ -14,7 +14,7 @@ SpatialKernels get_spatial_kernels_linear(int P, bool need_f)
         FVB_SPATIAL_CASE(LinearModel, "linear", 5)
         FVB_SPATIAL_CASE(LinearModel, "linear", 6)
     default:
-        return SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+        return get_spatial_kernels_more(FVB_MODEL_LINEAR, P, need_f); // vb_spatial_more.hip
     }
 }
 } // namespace fvb

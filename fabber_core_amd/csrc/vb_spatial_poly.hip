@@ -12,7 +12,7 @@ SpatialKernels get_spatial_kernels_poly(int P, bool need_f)
         FVB_SPATIAL_CASE(PolyModel, "poly", 3)
         FVB_SPATIAL_CASE(PolyModel, "poly", 4)
     default:
-        return SpatialKernels{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
+        return get_spatial_kernels_more(FVB_MODEL_POLY, P, need_f); // vb_spatial_more.hip
     }
 }
 } // namespace fvb

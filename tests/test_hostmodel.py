@@ -213,3 +213,19 @@ def test_host_route_in_batches_is_the_host_route_in_one(plugin, noise, monkeypat
     many = fabber.run(data, opts)
     for k in ("finalMVN", "freeEnergy", "mean_amp1", "mean_r1"):
         assert np.array_equal(one[k], many[k]), k
+
+
+@pytest.mark.gpu
+def test_spatial_vb_without_device_kernels_falls_back_to_the_host_model():
+    """no spatial kernels are built for a polynomial of degree 6 (7 parameters): fabber_dorun lets the model's host
+    code do the re-centres instead of refusing; against the same run with host-model set"""
+    rng = np.random.default_rng(9)
+    shape, T = (6, 5, 4), 16
+    t = np.arange(1, T + 1) / 8.0
+    data = (1.0 + 0.5 * t - 0.3 * t ** 2 + rng.normal(0, 0.05, shape + (T,))).astype(np.float32)
+    opts = {"model": "poly", "degree": 6, "noise": "white", "method": "spatialvb", "max-iterations": 3, "param-spatial-priors": "M+",
+            "save-mean": True, "save-mvn": True}
+    auto = fabber.run(data, opts)
+    assert "no device kernels for spatial VB" in auto["log"]
+    forced = fabber.run(data, dict(opts, **{"host-model": True}))
+    assert np.array_equal(auto["finalMVN"], forced["finalMVN"])

@@ -451,3 +451,41 @@ def test_slab_sweep_with_runs_longer_than_a_workgroup(monkeypatch):
     per_level = hiplib.run_spatial_host(h, sp, y)
     for k in ("mvn", "status", "iterations"):
         assert np.array_equal(slab[k], per_level[k], equal_nan=True) and np.array_equal(wide[k], per_level[k], equal_nan=True), k
+
+
+@gpu
+@pytest.mark.parametrize("what", ["poly degree 4", "three exponentials", "seven regressors"])
+def test_larger_parameter_counts_under_spatial_vb(what):
+    """vb_spatial_more.hip: 5 - 8 parameters of the built-in models (the slab sweep with one spatial parameter among
+    them), against the oracle"""
+    mask, coords = masked_volume((9, 8, 6), seed=51, keep=0.9)
+    V = coords.shape[1]
+    rng = np.random.default_rng(52)
+    smooth = 1.0 + 0.3 * np.sin(coords[0] / 2.0) + 0.2 * np.cos(coords[1] / 3.0)
+    if what == "poly degree 4":
+        T = 14
+        t = np.arange(1, T + 1) / 4.0
+        y = smooth[None, :] + 0.5 * t[:, None] - 0.2 * t[:, None] ** 2 + 0.03 * t[:, None] ** 3 + rng.normal(0, 0.05, (T, V))
+        h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=4, max_iterations=4, param_overrides={"c0": dict(type="M")})
+        tol = dict(allow_floor=True)  # (monomials up to t^4)
+    elif what == "three exponentials":
+        T = 60
+        t = np.arange(T) * 0.03
+        y = smooth[None, :] * np.exp(-0.7 * t[:, None]) + 0.6 * np.exp(-3.0 * t[:, None]) + 0.3 * np.exp(-9.0 * t[:, None]) + rng.normal(0, 0.03, (T, V))
+        h = vbabi.build_config(vbabi.MODEL_EXP, V, T, num_exps=3, dt=0.03, max_iterations=2, param_overrides={"amp1": dict(type="M")})
+        tol = None  # chaotic like the bi-exponential fit: population
+    else:
+        T = 40
+        tt = (np.arange(T) + 0.5) / T
+        X = np.stack([np.cos(np.pi * k * tt) for k in range(7)], axis=1)
+        coef = rng.uniform(-1, 1, (7, V))
+        coef[0] = smooth
+        y = X @ coef + rng.normal(0, 0.05, (T, V))
+        h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, max_iterations=5, param_overrides={"Parameter_1": dict(type="M")})
+        tol = dict()
+    sp = vbabi.SpatialHolder(coords)
+    cpu, cpu2, got = oracle.run_spatial(h, sp, y), oracle.run_spatial_fma(h, sp, y), hiplib.run_spatial_host(h, sp, y)
+    if tol is None:
+        parity.population(h, cpu, got, parity.population_stats(h, cpu, cpu2), what=what)
+    else:
+        parity.strict(h, cpu, got, what=what, cpu2=cpu2, **tol)
