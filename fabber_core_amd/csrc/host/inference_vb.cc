@@ -276,9 +276,31 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
     // ---- noise ----
     m_noise->ConfigureEngine(cfg, cfg.n_times, st.phi_index);
     cfg.phi_index = st.phi_index.empty() ? NULL : st.phi_index.data();
+    // noise-initial-prior / noise-initial-posterior: ONE distribution from a matrix file for every voxel
+    // (Vb::InitializeNoiseFromParam, inference_vb.cc:132-142 -> NoiseParams::InputFromMVN); for white noise that is
+    // a Gamma per precision from its mean and variance (noisemodel_white.cc:70-79, dist_gamma.cc:29-33)
     for (const char *key : { "noise-initial-prior", "noise-initial-posterior" })
-        if (rundata.GetStringDefault(key, "modeldefault") != "modeldefault")
-            throw InvalidOptionValue(key, rundata.GetStringDefault(key, ""), "Loading noise distributions from file is not supported yet");
+    {
+        const string filename = rundata.GetStringDefault(key, "modeldefault");
+        if (filename == "modeldefault")
+            continue;
+        if (cfg.noise != FVB_NOISE_WHITE)
+            throw InvalidOptionValue(key, filename, "Loading the AR(1) noise distributions from file is not supported by the MI355X engine");
+        LOG << "VbInferenceTechnique::Loading " << key << " distribution from " << filename << endl;
+        MVNDist dist(filename, m_log);
+        if (dist.GetSize() != cfg.n_phis)
+            throw InvalidOptionValue(key, filename, "The distribution has " + stringify(dist.GetSize()) + " entries, the noise model "
+                    + stringify(cfg.n_phis) + " precisions");
+        const NEWMAT::SymmetricMatrix &cov = dist.GetCovariance();
+        const bool prior = string(key) == "noise-initial-prior";
+        for (int i = 0; i < cfg.n_phis; i++)
+        {
+            const double b = cov(i + 1, i + 1) / dist.means(i + 1); // GammaDist::SetMeanVariance
+            const double c = dist.means(i + 1) / b;
+            (prior ? cfg.noise_prior_b : cfg.noise_post_b)[i] = b;
+            (prior ? cfg.noise_prior_c : cfg.noise_post_c)[i] = c;
+        }
+    }
 
     // ---- convergence ----
     std::unique_ptr<ConvergenceDetector> conv(

@@ -375,3 +375,30 @@ def test_progress_callback_and_unused_option_warning():
                      progress_cb=lambda v, n: calls.append((v, n)))
     assert calls[0] == (0, 8) and calls[-1] == (8, 8)
     assert "Unused option specified: bogus-option" in out["log"]
+
+
+@pytest.mark.gpu
+def test_noise_distributions_from_matrix_files(tmp_path):
+    """noise-initial-prior / noise-initial-posterior (Vb::InitializeNoiseFromParam, inference_vb.cc:132-142): one MVN
+    file for every voxel, a Gamma per precision from its mean and variance. prior-noise-stddev=0.5 is the Gamma with
+    c = 0.5, b = 8 as prior AND initial posterior (noisemodel_white.cc:151-162): mean 4, variance 32 - the same run
+    from files."""
+    rng = np.random.default_rng(10)
+    shape, T = (5, 4, 3), 20
+    t = np.arange(1, T + 1)
+    data = (2.0 + 0.3 * t + rng.normal(0, 0.5, shape + (T,))).astype(np.float32)
+    opts = {"model": "poly", "degree": 1, "noise": "white", "method": "vb", "max-iterations": 6, "save-mean": True, "save-mvn": True,
+            "save-noise-mean": True}
+    by_option = fabber.run(data, dict(opts, **{"prior-noise-stddev": 0.5}))
+    f = tmp_path / "noise_mvn.mat"
+    f.write_text("32 4\n4 1\n")
+    by_file = fabber.run(data, dict(opts, **{"noise-initial-prior": str(f), "noise-initial-posterior": str(f)}))
+    assert "Loading noise-initial-prior distribution" in by_file["log"]
+    assert np.allclose(by_file["finalMVN"], by_option["finalMVN"], rtol=1e-12, atol=0)
+    default = fabber.run(data, opts)
+    assert np.abs(default["noise_means"] - by_file["noise_means"]).max() > 1e-3
+    # only the prior from the file: a different run again
+    only_prior = fabber.run(data, dict(opts, **{"noise-initial-prior": str(f)}))
+    assert np.abs(only_prior["finalMVN"] - by_file["finalMVN"]).max() > 0
+    with pytest.raises(fabber.FabberError):
+        fabber.run(data, dict(opts, noise="ar", **{"noise-initial-prior": str(f)}))
