@@ -10,7 +10,10 @@
 #include "rundata_array.h"
 #include "setup.h"
 
+#include "../../../include/fabber_vb.h"
+
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <sstream>
 #include <string.h>
@@ -78,6 +81,8 @@ FwdModel *configured_model(FabberRunDataArray *rundata, EasyLog *log)
 }
 }
 
+static std::atomic<int> g_live_handles(0);
+
 extern "C" {
 
 void *fabber_new(char *err_buf)
@@ -85,7 +90,9 @@ void *fabber_new(char *err_buf)
     try
     {
         FabberSetup::SetupDefaults();
-        return new FabberRunDataArray(false);
+        void *fab = new FabberRunDataArray(false);
+        ++g_live_handles;
+        return fab;
     }
     catch (...)
     {
@@ -126,6 +133,10 @@ void fabber_destroy(void *fab)
     {
         FabberSetup::Destroy();
         delete ctx(fab);
+        // the engine keeps its device work buffers between runs (a private memory pool per device); when the last
+        // handle of the process goes, so do they
+        if (--g_live_handles == 0)
+            fabber_vb_release_cached_memory();
     }
 }
 

@@ -132,6 +132,7 @@ static OptionSpec VB_OPTIONS[] = {
     { "spatial-speed", OPT_STR, "Restrict speed of spatial smoothing", OPT_NONREQ, "-1" },
     { "param-spatial-priors", OPT_STR, "Type of spatial priors for each parameter, as a sequence of characters. N=nonspatial, M=Markov random field, P=Penny, A=ARD", OPT_NONREQ, "N+" },
     { "locked-linear-from-mvn", OPT_MVN, "MVN file containing fixed centres for linearization", OPT_NONREQ, "" },
+    { "spatial-slabs", OPT_BOOL, "With devices=: cut a spatial VB volume into z-slabs over the listed devices (exact, slower than one device; for volumes beyond one device's memory)", OPT_NONREQ, "" },
     { "" },
 };
 
@@ -293,8 +294,16 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
                     + stringify(cfg.n_phis) + " precisions");
         const NEWMAT::SymmetricMatrix &cov = dist.GetCovariance();
         const bool prior = string(key) == "noise-initial-prior";
+        for (int i = 1; i <= cfg.n_phis; i++) // WhiteParams::InputFromMVN, noisemodel_white.cc:70-79
+            for (int j = i + 1; j <= cfg.n_phis; j++)
+                if (cov(i, j) != 0)
+                    throw FabberRunDataError("Phis should have zero covariance!");
         for (int i = 0; i < cfg.n_phis; i++)
         {
+            // a Gamma distribution has a positive mean and a positive variance (the reference would carry a
+            // negative scale or a division by zero into its first update)
+            if (!(dist.means(i + 1) > 0) || !(cov(i + 1, i + 1) > 0))
+                throw InvalidOptionValue(key, filename, "Noise precision " + stringify(i + 1) + " needs a positive mean and a positive variance");
             const double b = cov(i + 1, i + 1) / dist.means(i + 1); // GammaDist::SetMeanVariance
             const double c = dist.means(i + 1) / b;
             (prior ? cfg.noise_prior_b : cfg.noise_post_b)[i] = b;
@@ -581,10 +590,33 @@ void Vb::DoCalculations(FabberRunData &rundata)
         // In the voxelwise loop the locked centres only serve the set-up re-centre, which the loop
         // repeats about the posterior means before anything uses it (inference_vb.cc:227-235, :443,
         // :490): no effect on the results. The spatial loop really keeps them (:695).
-        if (spatial)
-            throw InvalidOptionValue("locked-linear-from-mvn", rundata.GetString("locked-linear-from-mvn"),
-                "Fixed linearisation centres are not supported with spatial VB by the MI355X engine");
-        LOG << "Vb::locked-linear-from-mvn has no effect on voxelwise VB (the loop re-centres about the posterior means)" << endl;
+        if (!spatial)
+            LOG << "Vb::locked-linear-from-mvn has no effect on voxelwise VB (the loop re-centres about the posterior means)" << endl;
+    }
+    vector<double> locked_centres; // [P][V]
+    if (m_locked_linear && spatial)
+    {
+        // inference_vb.cc:171-181,225-232: the means of the first P entries of the given MVN image ("does not check
+        // if the correct number of parameters is present"); MVNDist::Load's checks (dist_mvn.cc:324-374)
+        const string file = rundata.GetString("locked-linear-from-mvn");
+        LOG << "Vb::Loading fixed linearization centres from the MVN '" << file << "'" << endl;
+        const Matrix &mvn = rundata.GetVoxelData(file);
+        if (mvn.Ncols() == 0)
+            throw FabberRunDataError("MVNDist::Load - Voxel data is empty");
+        const int n = ((int)sqrt(double(8 * mvn.Nrows() + 1)) - 3) / 2;
+        if (mvn.Nrows() != n * (n + 1) / 2 + n + 1)
+            throw FabberRunDataError("MVNDist::Load  - Incorrect number of rows for an MVN input");
+        if (n < cfg.n_params || mvn.Ncols() != m_nvoxels)
+            throw FabberRunDataError("locked-linear-from-mvn: the MVN does not hold the model's parameters for every voxel");
+        const int nCov = n * (n + 1) / 2;
+        locked_centres.resize((size_t)cfg.n_params * m_nvoxels);
+        for (int v = 0; v < m_nvoxels; v++)
+        {
+            if (mvn.at0(nCov + n, v) != 1)
+                throw FabberRunDataError("MVNDist::Load - Voxel data does not contain a valid MVN - last value != 1");
+            for (int k = 0; k < cfg.n_params; k++)
+                locked_centres[(size_t)k * m_nvoxels + v] = mvn.at0(nCov + k, v);
+        }
     }
     if (spatial)
     {
@@ -608,6 +640,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
             for (int v = 0; v < m_nvoxels; v++)
                 grid[(size_t)d * m_nvoxels + v] = (int32_t)coords.at0(d, v);
         sp.coords = grid.data();
+        sp.locked_centres = locked_centres.empty() ? NULL : locked_centres.data();
         cfg.convergence = FVB_CONV_MAXITS;
         cfg.max_iterations = convertTo<int>(rundata.GetStringDefault("max-iterations", "10"));
         cfg.f_history_rows = 0;
@@ -616,7 +649,14 @@ void Vb::DoCalculations(FabberRunData &rundata)
         LOG << "Vb::Spatial calculations on the MI355X engine, " << m_nvoxels << " voxels x " << cfg.n_times
             << " timepoints, " << cfg.max_iterations << " iterations" << endl;
         s_progress_rundata = &rundata;
-        if (m_store->has_device_model && devices_opt != "")
+        // devices= shards VOXELWISE VB. Spatial VB over several devices (z-slabs, pipelined first sweep) is exact but
+        // slower than one device - the ordered sweep is a latency chain that more devices do not shorten - so it
+        // is an explicit choice (spatial-slabs) for volumes beyond one device's memory.
+        const bool slabs = rundata.GetBool("spatial-slabs");
+        if (devices_opt != "" && !slabs)
+            WARN_ONCE("devices= shards voxelwise VB only: this spatial VB run uses one device (the faster choice; "
+                      "--spatial-slabs cuts the volume into z-slabs over the listed devices for volumes beyond one device's memory)");
+        if (m_store->has_device_model && devices_opt != "" && slabs && !sp.locked_centres)
         {
             // devices=all | devices=0,1,...: z-slabs of the volume on several GPUs, pipelined first sweep
             LOG << "Vb::devices=" << devices_opt << ": the volume is cut into z-slabs" << endl;

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void vb_postproc_kernel(
 namespace fvb
 {
 void api_keep_pool_memory();
+hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream);
 }
 namespace
 {
@@ -261,9 +262,8 @@ struct DevBuf
     }
     hipError_t alloc(size_t bytes, hipStream_t s = nullptr)
     {
-        fvb::api_keep_pool_memory();
         stream = s;
-        return hipMallocAsync(&p, bytes ? bytes : 8, s);
+        return fvb::api_pool_alloc(&p, bytes ? bytes : 8, s);
     }
 };
 
@@ -292,26 +292,76 @@ double api_residual_tol()
 {
     return g_residual_tol;
 }
-// The current device's default memory pool keeps freed memory instead of returning it to the driver at the next
-// synchronisation (hipMallocAsync's default): work buffers of the size of the series are allocated by every run.
-void api_keep_pool_memory()
+// Work buffers of the size of the series are allocated by every run; they come from a stream-ordered memory pool
+// that keeps freed memory instead of returning it to the driver at the next synchronisation. The pool is the
+// LIBRARY'S OWN (one per device, created on first use): the process-wide default pool of an embedding application
+// keeps its settings. fabber_vb_release_cached_memory gives everything back, on every device that was used.
+struct PoolTable
 {
-    static std::mutex lock;
-    static std::vector<int> done;
+    std::mutex lock;
+    std::vector<std::pair<int, hipMemPool_t> > pools; // (device, pool); pool == nullptr: the default pool is used
+};
+static PoolTable &pool_table()
+{
+    static PoolTable t;
+    return t;
+}
+// the current device's pool (nullptr: creation is not supported here - plain hipMallocAsync from the default pool)
+hipMemPool_t api_pool()
+{
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess)
-        return;
-    std::lock_guard<std::mutex> hold(lock);
-    for (int d : done)
-        if (d == dev)
-            return;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+        return nullptr;
+    PoolTable &t = pool_table();
+    std::lock_guard<std::mutex> hold(t.lock);
+    for (auto &e : t.pools)
+        if (e.first == dev)
+            return e.second;
+    hipMemPool_t pool = nullptr;
+    hipMemPoolProps props;
+    memset(&props, 0, sizeof(props));
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess)
     {
         uint64_t never = UINT64_MAX;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
     }
-    done.push_back(dev);
+    else
+    {
+        (void)hipGetLastError();
+        pool = nullptr;
+    }
+    t.pools.push_back(std::make_pair(dev, pool));
+    return pool;
+}
+hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream)
+{
+    hipMemPool_t pool = api_pool();
+    return pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
+}
+void api_keep_pool_memory()
+{
+    (void)api_pool();
+}
+void api_release_pools()
+{
+    PoolTable &t = pool_table();
+    std::lock_guard<std::mutex> hold(t.lock);
+    int before = 0;
+    (void)hipGetDevice(&before);
+    for (auto &e : t.pools)
+    {
+        if (hipSetDevice(e.first) != hipSuccess)
+            continue;
+        (void)hipDeviceSynchronize();
+        hipMemPool_t pool = e.second;
+        if (pool || hipDeviceGetDefaultMemPool(&pool, e.first) == hipSuccess)
+            (void)hipMemPoolTrimTo(pool, 0);
+    }
+    (void)hipSetDevice(before);
 }
 } // namespace fvb
 
@@ -342,13 +392,7 @@ const char *fabber_vb_last_error(void)
 
 void fabber_vb_release_cached_memory(void)
 {
-    int dev = 0;
-    hipMemPool_t pool;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
-    {
-        (void)hipDeviceSynchronize();
-        (void)hipMemPoolTrimTo(pool, 0);
-    }
+    fvb::api_release_pools();
 }
 
 void fabber_vb_set_variant(int32_t variant)
@@ -428,7 +472,7 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
     if (lk.fn || lk.fn_tiles_f32)
     {
         if (needs_save(cfg))
-            FVB_HIP_CHECK(hipMallocAsync((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels, stream));
+            FVB_HIP_CHECK(api_pool_alloc((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels, stream));
         const unsigned grid = (unsigned)((cfg->n_voxels + 63) / 64);
         LaneKernelFn fn = lk.fn;
         void *tiles = nullptr;
@@ -441,13 +485,13 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
             const unsigned rgrid = (unsigned)((V + 255) / 256);
             if (cfg->data_f64)
             {
-                FVB_HIP_CHECK(hipMallocAsync(&tiles, Tile<double>::bytes(V, T), stream));
+                FVB_HIP_CHECK(api_pool_alloc(&tiles, Tile<double>::bytes(V, T), stream));
                 hipLaunchKernelGGL(retile_series<double>, dim3(rgrid), dim3(256), 0, stream, (const double *)data, (double *)tiles, V, T);
                 fn = lk.fn_tiles_f64;
             }
             else
             {
-                FVB_HIP_CHECK(hipMallocAsync(&tiles, Tile<float>::bytes(V, T), stream));
+                FVB_HIP_CHECK(api_pool_alloc(&tiles, Tile<float>::bytes(V, T), stream));
                 hipLaunchKernelGGL(retile_series<float>, dim3(rgrid), dim3(256), 0, stream, (const float *)data, (float *)tiles, V, T);
                 fn = lk.fn_tiles_f32;
             }

@@ -111,10 +111,37 @@ __device__ __forceinline__ void ar_forms(const VoxelState<P> &st, const ArMoment
     lost = (w != 1) && !(kMk > tol * scale) && (scale > 0);
 }
 
+// Where a lane's series comes from: the tiled copy (the voxelwise kernel) or the caller's [t][voxel] image read in
+// place (the spatial kernels, vb_spatial_noise.h). run(body) calls body(t, y_t) for t = 0 .. T-1 in order.
+template <typename RAW>
+struct ArTileFeed
+{
+    const RAW *lane_tile;
+    int T;
+    template <class Body>
+    __device__ __forceinline__ void run(Body body) const
+    {
+        for_each_timepoint_tiled<RAW>(lane_tile, T, body);
+    }
+};
+template <int P>
+struct ArStridedFeed
+{
+    const KernelArgs &ka;
+    int v;
+    template <class Body>
+    __device__ __forceinline__ void run(Body body) const
+    {
+        const int T = ka.cfg.n_times;
+        const size_t V = (size_t)ka.cfg.n_voxels;
+        FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, body)
+    }
+};
+
 // The streaming pass: model + finite-difference Jacobian about `centre`, AR moments
-template <class Model, int P, typename RAW>
-__device__ __forceinline__ int recentre_ar(
-    const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile, const double (&centre)[P], ArMoments<P> &mo, bool precise = false)
+template <class Model, int P, class Feed>
+__device__ __forceinline__ int recentre_ar_feed(
+    const KernelArgs &ka, const ModelArgs &ma, const Feed &feed, const double (&centre)[P], ArMoments<P> &mo, bool precise = false)
 {
     constexpr int PT = P * (P + 1) / 2;
     const int T = ka.cfg.n_times;
@@ -188,17 +215,23 @@ __device__ __forceinline__ int recentre_ar(
             Jp[i] = J[i];
         rp = r;
     };
-    for_each_timepoint_tiled<RAW>(lane_tile, T, step);
+    feed.run(step);
 #pragma unroll
     for (int i = 0; i < P; i++)
         mo.JT[i] = Jp[i];
     mo.rT = rp;
     return bad_offset ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
 }
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ int recentre_ar(
+    const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile, const double (&centre)[P], ArMoments<P> &mo, bool precise = false)
+{
+    return recentre_ar_feed<Model, P>(ka, ma, ArTileFeed<RAW>{ lane_tile, ka.cfg.n_times }, centre, mo, precise);
+}
 
 // Direct k = y - g(ml) + J (ml - m): k'M00k, k'M10k, k'M20k summed as the reference does
-template <class Model, int P, typename RAW>
-__device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile,
+template <class Model, int P, class Feed>
+__device__ __forceinline__ void exact_residual_ar_feed(const KernelArgs &ka, const ModelArgs &ma, const Feed &feed,
     const ArMoments<P> &mo, const double (&m)[P], double &kk00, double &kk10, double &kk20)
 {
     const int T = ka.cfg.n_times;
@@ -240,10 +273,16 @@ __device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const Mo
             k_first = k;
         k_prev = k;
     };
-    for_each_timepoint_tiled<RAW>(lane_tile, T, step);
+    feed.run(step);
     kk00 = sum_all - k_first * k_first;
     kk20 = sum_all - k_prev * k_prev;
     kk10 = -2 * cross;
+}
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ void exact_residual_ar(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile,
+    const ArMoments<P> &mo, const double (&m)[P], double &kk00, double &kk10, double &kk20)
+{
+    exact_residual_ar_feed<Model, P>(ka, ma, ArTileFeed<RAW>{ lane_tile, ka.cfg.n_times }, mo, m, kk00, kk10, kk20);
 }
 
 // All residual-dependent scalars of one iteration
@@ -253,8 +292,8 @@ struct ArForms
     double tr[3]; // tr(Sigma J'M J) for the three M
 };
 
-template <class Model, int P, typename RAW>
-__device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile, const VoxelState<P> &st,
+template <class Model, int P, class Feed>
+__device__ __forceinline__ void ar_residuals_feed(const KernelArgs &ka, const ModelArgs &ma, const Feed &feed, const VoxelState<P> &st,
     const ArMoments<P> &mo, ArForms &f)
 {
     bool lost = false;
@@ -270,7 +309,7 @@ __device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelAr
     if (__any(want))
     {
         double e00, e10, e20;
-        exact_residual_ar<Model, P, RAW>(ka, ma, lane_tile, mo, st.m, e00, e10, e20);
+        exact_residual_ar_feed<Model, P>(ka, ma, feed, mo, st.m, e00, e10, e20);
         if (want)
         {
             f.kk[0] = e00;
@@ -283,6 +322,13 @@ __device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelAr
         f.kk[0] = (f.kk[0] > 0.0) ? f.kk[0] : ((f.kk[0] <= 0.0) ? 0.0 : f.kk[0]);
         f.kk[2] = (f.kk[2] > 0.0) ? f.kk[2] : ((f.kk[2] <= 0.0) ? 0.0 : f.kk[2]);
     }
+}
+
+template <class Model, int P, typename RAW>
+__device__ __forceinline__ void ar_residuals(const KernelArgs &ka, const ModelArgs &ma, const RAW *lane_tile, const VoxelState<P> &st,
+    const ArMoments<P> &mo, ArForms &f)
+{
+    ar_residuals_feed<Model, P>(ka, ma, ArTileFeed<RAW>{ lane_tile, ka.cfg.n_times }, st, mo, f);
 }
 
 // With the linearisation centred on the current mean (d = 0): k = r

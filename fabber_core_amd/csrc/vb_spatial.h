@@ -102,6 +102,10 @@ struct SpatialArgs
     uint32_t *sw_counter;    // (unused by the data-flow sweep; kept for the barrier variant)
     int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the
                              // sweep, a barrier timed out): the run is repeated with the per-level launches
+    // ---- noise models other than white noise with one precision (vb_spatial_noise.h) ----
+    double nz_count[4];      // noise-pattern: timepoints of each class (trace of Q_k, noisemodel_white.cc:207-225)
+    int32_t locked_linear;   // locked-linear-from-mvn: the second sweep does not re-centre (inference_vb.cc:695-696)
+    const double *locked_centres; // [P][V] the fixed centres (set-up re-centre, inference_vb.cc:225-232), or NULL
 };
 
 #if defined(__HIPCC__)
@@ -179,6 +183,34 @@ __device__ __forceinline__ bool is_spatial_type(int t)
 {
     return t >= FVB_PRIOR_SPATIAL_M;
 }
+
+// The noise model seen from the FIRST sweep (inference_vb.cc:643-651). UpdateTheta needs J'XJ and J'X(y - g) only, and
+// whatever the noise model is, those sit in the A / U rows of the state as "effective" moments with the factor
+// E[phi] in rows B x C (vb_spatial_noise.h writes them so for several precisions and for AR(1) noise): priors, eq
+// (19), (20) and the whole split sweep never look at the noise model. What does is the free energy "before" and
+// "theta", whose value nobody reads but whose failure stops the voxel - this policy evaluates it.
+// at_centre: the means are still the linearisation centre (k = y - g); Fprior as Vb::CalculateF adds it.
+template <int P>
+struct SpWhite
+{
+    static constexpr int EXTRA_ROWS = 0;
+    static __device__ __forceinline__ bool sweep_F(const SpatialArgs &sa, int v, VoxelState<P> &st, const Moments<P> &mo,
+        bool at_centre, double Fprior, double &F, bool &finite)
+    {
+        double kk, trSA;
+        if (at_centre)
+        {
+            kk = mo.s;
+            trSA = trace_SA<P>(st, mo);
+        }
+        else
+        {
+            bool lost;
+            residual_terms<P>(st, mo, 0.0, kk, trSA, lost);
+        }
+        return calc_free_energy<P>(sa.ka, st, kk, trSA, Fprior, F, finite);
+    }
+};
 
 // ---- setup: Vb::SetupPerVoxelDists (inference_vb.cc:207-247), one lane per voxel --------------
 template <class Model, int P>
@@ -258,7 +290,11 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
         ma.lin_T = T;
         ma.lin = sa.lin_next + (size_t)v * T * (P + 1);
     }
-    const int status = recentre<Model, P>(ka, ma, v, st.m, mo, true);
+    double centre[P]; // the posterior means, or the locked centres (inference_vb.cc:225-232)
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        centre[i] = sa.locked_centres ? sa.locked_centres[(size_t)i * V + v] : st.m[i];
+    const int status = recentre<Model, P>(ka, ma, v, centre, mo, true);
     sa.status[v] = status ? (status | 0x100) : 0;
     sp_store_theta<P>(sa, v, st);
     sp_store_noise<P>(sa, v, st, mo);
@@ -386,7 +422,7 @@ __global__ void vb_spatial_ak_final_kernel(const SpatialArgs sa)
 // ---- first sweep, one level: priors + UpdateTheta (inference_vb.cc:614-672) -------------------
 // There are hundreds of these launches per iteration, so the (large) argument block stays in
 // device memory and only the level range travels with the launch.
-template <int P, bool NEEDF>
+template <int P, bool NEEDF, class NZ = SpWhite<P> >
 __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs *__restrict__ sap, int level_begin,
     int level_count, int it)
 {
@@ -557,7 +593,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
         double F;
         bool finite = true;
         // the means are still the linearisation centre: k = y - g, k'k = s
-        const bool ok = calc_free_energy<P>(ka, st, mo.s, trace_SA<P>(st, mo), Fprior, F, finite);
+        const bool ok = NZ::sweep_F(sa, v, st, mo, true, Fprior, F, finite);
         if (!ok || !finite)
         {
             sa.status[v] = ok ? FVB_BAD_FREE_ENERGY : FVB_BAD_RESULT;
@@ -569,10 +605,9 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
         status = FVB_BAD_RESULT;
     if (NEEDF && status == FVB_OK)
     {
-        double kk, trSA, F;
-        bool lost, finite = true;
-        residual_terms<P>(st, mo, 0.0, kk, trSA, lost);
-        const bool ok = calc_free_energy<P>(ka, st, kk, trSA, Fprior, F, finite);
+        double F;
+        bool finite = true;
+        const bool ok = NZ::sweep_F(sa, v, st, mo, false, Fprior, F, finite);
         if (!ok || !finite)
             status = ok ? FVB_BAD_FREE_ENERGY : FVB_BAD_RESULT;
     }
@@ -650,7 +685,7 @@ __device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, ui
     }
 }
 
-template <int P, bool NEEDF>
+template <int P, bool NEEDF, class NZ = SpWhite<P> >
 __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *__restrict__ sap, int it, uint32_t serial)
 {
     typedef SpLayout<P> L;
@@ -771,7 +806,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
                 tmp.pm[k] = tmp.m[k];
         double F0;
         bool finite0 = true;
-        if (!calc_free_energy<P>(ka, tmp, mo.s, trace_SA<P>(tmp, mo), Fprior, F0, finite0) || !finite0)
+        if (!NZ::sweep_F(sa, v, tmp, mo, true, Fprior, F0, finite0) || !finite0)
         {
             sa.sw_flags[0] = 1;
             sa.sw_alive[pos] = 0;
@@ -1273,6 +1308,64 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
     }
 }
 
+// The rest of UpdateTheta after the split first sweep: the state holds this iteration's priors, Sigma and
+// log|det Lambda| (prep) and still the OLD means; the sweep left the spatial parameters' new means and prior means at
+// the voxel's level-major position. Returns false for a voxel that failed in prep (the run is being repeated anyway).
+template <int P, bool NEEDF, class NZ>
+__device__ __forceinline__ bool sp_complete_theta(const SpatialArgs &sa, int v, VoxelState<P> &st, const Moments<P> &mo)
+{
+    typedef SpLayout<P> L;
+    const KernelArgs &ka = sa.ka;
+    const size_t V = (size_t)ka.cfg.n_voxels, NP = (size_t)sa.n_pos;
+    const int pos = sa.pos_of[v];
+    if (!sa.sw_alive[pos])
+        return false;
+    const double phibar = st.b * st.c;
+    double m_new[P], rhs[P];
+    int si = 0;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+        if (is_spatial_type(ka.cfg.prior_type[k]))
+        {
+            st.pm[k] = sa.sw_pm[si * NP + pos];
+            m_new[k] = sa.sw_x[si * NP + pos];
+            if (NEEDF) // F "before" (:643) would see this prior mean next to the old posterior mean
+            {
+                const double dm = st.m[k] - st.pm[k];
+                if (!is_finite(dm * st.pprec[k] * dm))
+                    sa.sw_flags[0] = 1;
+            }
+            si++;
+        }
+#pragma unroll
+    for (int k = 0; k < P; k++)
+        rhs[k] = theta_rhs(theta_rhs_base<P>(phibar, mo, k), st.pprec[k], st.pm[k]);
+#pragma unroll
+    for (int k = 0; k < P; k++)
+        if (!is_spatial_type(ka.cfg.prior_type[k]))
+            m_new[k] = theta_mean<P>(st.Sig, rhs, k);
+#pragma unroll
+    for (int k = 0; k < P; k++)
+        st.m[k] = m_new[k];
+    if (NEEDF) // F "theta" (:651): its value is overwritten, its failure would have stopped the voxel
+    {
+        double F0;
+        bool finite0 = true;
+        st.precValid = true; // log|det Lambda| came with Sigma
+        if (!NZ::sweep_F(sa, v, st, mo, false, 0.0, F0, finite0) || !finite0)
+            sa.sw_flags[0] = 1;
+        st.precValid = false;
+    }
+    double *p = sa.state + v;
+#pragma unroll
+    for (int k = 0; k < P; k++)
+    {
+        p[(size_t)(L::M + k) * V] = st.m[k];
+        p[(size_t)(L::PM + k) * V] = st.pm[k];
+    }
+    return true;
+}
+
 // ---- second sweep: UpdateNoise, ReCentre, F (inference_vb.cc:674-722), all voxels -------------
 template <class Model, int P, bool NEEDF, bool FAST = false>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(const SpatialArgs sa)
@@ -1292,58 +1385,8 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
     sp_load<P>(sa, v, st, mo);
     if (FAST)
     {
-        // The rest of UpdateTheta after the split first sweep: the state holds this iteration's priors,
-        // Sigma and log|det Lambda| (prep) and still the OLD means; the sweep left the spatial parameters'
-        // new means and prior means at the voxel's level-major position.
-        typedef SpLayout<P> L;
-        const size_t V = (size_t)ka.cfg.n_voxels, NP = (size_t)sa.n_pos;
-        const int pos = sa.pos_of[v];
-        if (!sa.sw_alive[pos])
-            return; // failed in prep: the run is being repeated anyway
-        const double phibar = st.b * st.c;
-        double m_new[P], rhs[P];
-        int si = 0;
-#pragma unroll
-        for (int k = 0; k < P; k++)
-            if (is_spatial_type(ka.cfg.prior_type[k]))
-            {
-                st.pm[k] = sa.sw_pm[si * NP + pos];
-                m_new[k] = sa.sw_x[si * NP + pos];
-                if (NEEDF) // F "before" (:643) would see this prior mean next to the old posterior mean
-                {
-                    const double dm = st.m[k] - st.pm[k];
-                    if (!is_finite(dm * st.pprec[k] * dm))
-                        sa.sw_flags[0] = 1;
-                }
-                si++;
-            }
-#pragma unroll
-        for (int k = 0; k < P; k++)
-            rhs[k] = theta_rhs(theta_rhs_base<P>(phibar, mo, k), st.pprec[k], st.pm[k]);
-#pragma unroll
-        for (int k = 0; k < P; k++)
-            if (!is_spatial_type(ka.cfg.prior_type[k]))
-                m_new[k] = theta_mean<P>(st.Sig, rhs, k);
-#pragma unroll
-        for (int k = 0; k < P; k++)
-            st.m[k] = m_new[k];
-        if (NEEDF) // F "theta" (:651): its value is overwritten, its failure would have stopped the voxel
-        {
-            double kk0, tr0, F0;
-            bool lost0, finite0 = true;
-            st.precValid = true; // log|det Lambda| came with Sigma
-            residual_terms<P>(st, mo, 0.0, kk0, tr0, lost0);
-            if (!calc_free_energy<P>(ka, st, kk0, tr0, 0.0, F0, finite0) || !finite0)
-                sa.sw_flags[0] = 1;
-            st.precValid = false;
-        }
-        double *p = sa.state + v;
-#pragma unroll
-        for (int k = 0; k < P; k++)
-        {
-            p[(size_t)(L::M + k) * V] = st.m[k];
-            p[(size_t)(L::PM + k) * V] = st.pm[k];
-        }
+        if (!sp_complete_theta<P, NEEDF, SpWhite<P> >(sa, v, st, mo))
+            return;
     }
     double kk, trSA;
     if (Model::host_evaluated) // the residual about the centre the moments belong to ...
@@ -1355,7 +1398,13 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
     update_noise<P>(ka, st, kk, trSA);
     if (Model::host_evaluated) // ... and the re-centre about the means of this iteration's first sweep
         ma.lin = sa.lin_next + (size_t)v * ka.cfg.n_times * (P + 1);
-    int status = recentre<Model, P>(ka, ma, v, st.m, mo);
+    int status = FVB_OK;
+    if (!sa.locked_linear) // inference_vb.cc:695-696
+    {
+        status = recentre<Model, P>(ka, ma, v, st.m, mo);
+        kk = mo.s; // the centre is the mean now: k = y - g
+        trSA = trace_SA<P>(st, mo);
+    }
     if (status == FVB_OK && NEEDF)
     {
         // only the last of the reference's four F evaluations per iteration is observable
@@ -1365,7 +1414,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
         st.precValid = false;
         double F;
         bool finite = true;
-        if (!calc_free_energy<P>(ka, st, mo.s, trace_SA<P>(st, mo), *sa.fprior_last, F, finite))
+        if (!calc_free_energy<P>(ka, st, kk, trSA, *sa.fprior_last, F, finite))
             status = FVB_BAD_RESULT;
         else if (!finite)
             status = FVB_BAD_FREE_ENERGY;
@@ -1431,6 +1480,7 @@ struct SpatialKernels
     SpatialSweepFn sweep[3]; // built for 1, 2 and up to P spatial parameters (what a lane keeps in registers grows with it)
     SpatialKernelFn noise_fast;
     SpatialSweepFn slab_sweep[3]; // the slab form of the sweep, same three builds
+    int lds_classes;              // 1: setup / noise / noise_fast keep cfg.phi_index in LDS (n_times bytes of dynamic LDS)
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);

@@ -3,7 +3,7 @@
  * inference_vb.cc:830-964), level ordering, the iteration loop of Vb::DoCalculationsSpatial
  * (inference_vb.cc:605-725) as a sequence of launches on one stream. See vb_spatial.h.
  */
-#include "vb_spatial.h"
+#include "vb_spatial_noise.h"
 
 #include <hip/hip_runtime.h>
 
@@ -30,6 +30,7 @@ int api_validate(const fvb_config *cfg, bool allow_spatial);
 int api_residual_mode();
 double api_residual_tol();
 void api_keep_pool_memory();
+hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream);
 }
 
 namespace
@@ -185,9 +186,8 @@ struct DevMem
     }
     hipError_t alloc(size_t bytes, hipStream_t s = nullptr)
     {
-        fvb::api_keep_pool_memory();
         stream = s;
-        return hipMallocAsync(&p, bytes ? bytes : 8, s);
+        return fvb::api_pool_alloc(&p, bytes ? bytes : 8, s);
     }
 };
 
@@ -363,6 +363,45 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
 
 } // namespace
 
+// Which statistics a configuration's state image carries (vb_spatial_noise.h), or -1: no spatial kernels for it
+static int spatial_noise_kind(const fvb_config *cfg)
+{
+    if (cfg->noise == FVB_NOISE_WHITE)
+        return cfg->n_phis == 1 ? FVB_SPNZ_WHITE : (cfg->n_phis == 2 ? FVB_SPNZ_PATTERN2 : (cfg->n_phis <= 4 ? FVB_SPNZ_PATTERN4 : -1));
+    if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 1 && cfg->ar_cross_terms == 0)
+        return FVB_SPNZ_AR1;
+    return -1;
+}
+static const char *const spatial_noise_refusal
+    = "spatial VB runs white noise with up to 4 noise precisions and AR(1) noise with one echo; more precisions and two-echo AR(1) "
+      "noise (num-echoes=2) run voxelwise only";
+// the kernel table of a configuration (setup == NULL: none was built for this model / parameter count / noise model)
+static SpatialKernels spatial_kernels_for(const fvb_config *cfg)
+{
+    const int kind = spatial_noise_kind(cfg), P = cfg->n_params;
+    const bool need_f = cfg->need_f != 0;
+    if (kind < 0)
+        return SpatialKernels{};
+    switch (cfg->model)
+    {
+    case FVB_MODEL_POLY:
+        return kind == FVB_SPNZ_WHITE ? get_spatial_kernels_poly(P, need_f) : get_spatial_kernels_nz_poly(P, need_f, kind);
+    case FVB_MODEL_LINEAR:
+        return kind == FVB_SPNZ_WHITE ? get_spatial_kernels_linear(P, need_f) : get_spatial_kernels_nz_linear(P, need_f, kind);
+    case FVB_MODEL_EXP:
+        return kind == FVB_SPNZ_WHITE ? get_spatial_kernels_exp(P, need_f) : get_spatial_kernels_nz_exp(P, need_f, kind);
+    case FVB_MODEL_HOSTJAC:
+        return kind == FVB_SPNZ_WHITE ? get_spatial_kernels_host(P, need_f) : get_spatial_kernels_nz_host(P, need_f, kind);
+    default:
+        return SpatialKernels{};
+    }
+}
+// entries of the noise block of the result MVN (WhiteParams / Ar1cParams::OutputAsMVN)
+static int spatial_noise_outputs(const fvb_config *cfg)
+{
+    return cfg->noise == FVB_NOISE_AR1 ? 2 + cfg->ar_cross_terms + cfg->n_phis : cfg->n_phis;
+}
+
 // One spatial VB run on one device: geometry, work buffers and the per-iteration steps. A single
 // process drives it from run_spatial() below; with several slabs the caller interleaves the steps
 // with its collectives (all-reduce of the a_K sums, halo exchange of the boundary planes).
@@ -375,6 +414,7 @@ struct fvb_spatial_run
     hipStream_t stream = nullptr;
     int V = 0, P = 0, owned_begin = 0, owned_end = 0;
     bool has_spatial = false;
+    size_t noise_lds = 0; // dynamic LDS of the set-up and second-sweep kernels (noise-pattern: the class of every timepoint)
     std::vector<int32_t> level_begin;
     std::vector<long long> level_value; // the level (weighted co-ordinate sum) of each entry of level_begin
     int level_w[3] = { 1, 1, 1 };
@@ -432,26 +472,12 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     if (owned_begin < 0 || owned_end > V)
         return api_fail(-45, "owned voxel range outside the local voxel list");
-    const bool need_f = cfg.need_f != 0;
-    switch (cfg.model)
-    {
-    case FVB_MODEL_POLY:
-        k = get_spatial_kernels_poly(P, need_f);
-        break;
-    case FVB_MODEL_LINEAR:
-        k = get_spatial_kernels_linear(P, need_f);
-        break;
-    case FVB_MODEL_EXP:
-        k = get_spatial_kernels_exp(P, need_f);
-        break;
-    case FVB_MODEL_HOSTJAC:
-        k = get_spatial_kernels_host(P, need_f);
-        break;
-    default:
-        k = SpatialKernels{};
-    }
+    if (spatial_noise_kind(&cfg) < 0)
+        return api_fail(-44, spatial_noise_refusal);
+    k = spatial_kernels_for(&cfg);
     if (!k.setup)
-        return api_fail(-40, "no spatial kernel instantiation for this model / parameter count");
+        return api_fail(-40, "no spatial kernel instantiation for this model / parameter count / noise model");
+    noise_lds = k.lds_classes ? (size_t)cfg.n_times : 0;
 
     // ---- Vb::SetupPerVoxelDists for every local voxel (ghosts included: their initial means are what the
     // neighbouring slab starts from too) needs the series and the options only: it runs on a stream of its own
@@ -459,14 +485,20 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V, stream));
     FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V, stream));
     int n_unmasked = cfg.n_times;
+    double nz_count[4] = { (double)cfg.n_times, 0, 0, 0 }; // timepoints per noise precision (trace of Q_k)
     if (cfg.phi_index) // (a device pointer here: read it back once)
     {
         std::vector<uint8_t> h(cfg.n_times);
         FVB_HIP_CHECK(hipMemcpyAsync(h.data(), cfg.phi_index, h.size(), hipMemcpyDeviceToHost, stream));
         FVB_HIP_CHECK(hipStreamSynchronize(stream));
         n_unmasked = 0;
+        nz_count[0] = 0;
         for (int t = 0; t < cfg.n_times; t++)
+        {
             n_unmasked += (h[t] != 255);
+            if (h[t] < 4)
+                nz_count[h[t]] += 1;
+        }
     }
     {
         SpatialArgs early;
@@ -483,12 +515,16 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         early.status = (int32_t *)d_status.p;
         early.owned_begin = owned_begin;
         early.owned_end = owned_end;
+        for (int i = 0; i < 4; i++)
+            early.nz_count[i] = nz_count[i];
+        early.locked_centres = sp.locked_centres;
+        early.locked_linear = sp.locked_centres != nullptr;
         FVB_HIP_CHECK(hipStreamCreateWithFlags(&setup_stream, hipStreamNonBlocking));
         FVB_HIP_CHECK(hipEventCreateWithFlags(&setup_done, hipEventDisableTiming));
         // (the two buffers were allocated in `stream`'s order; the series is the caller's, complete in `stream`'s order too)
         FVB_HIP_CHECK(hipEventRecord(setup_done, stream));
         FVB_HIP_CHECK(hipStreamWaitEvent(setup_stream, setup_done, 0));
-        hipLaunchKernelGGL(k.setup, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, setup_stream, early);
+        hipLaunchKernelGGL(k.setup, dim3((unsigned)((V + 63) / 64)), dim3(64), noise_lds, setup_stream, early);
         FVB_HIP_CHECK(hipGetLastError());
         FVB_HIP_CHECK(hipEventRecord(setup_done, setup_stream));
     }
@@ -830,6 +866,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     sa.owned_begin = owned_begin;
     sa.owned_end = owned_end;
     sa.n_voxels_global = sp.n_voxels_global > 0 ? sp.n_voxels_global : V;
+    for (int i = 0; i < 4; i++)
+        sa.nz_count[i] = nz_count[i];
+    sa.locked_centres = sp.locked_centres;
+    sa.locked_linear = sp.locked_centres != nullptr;
     if (fast)
     {
         const size_t NP = (size_t)n_pos, ns = (size_t)n_spatial;
@@ -963,7 +1003,7 @@ int fvb_spatial_run::sweep_noise(int it)
     sa.it = it;
     const int n_owned = owned_end - owned_begin;
     if (n_owned > 0)
-        hipLaunchKernelGGL(k.noise, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
+        hipLaunchKernelGGL(k.noise, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -984,7 +1024,7 @@ int fvb_spatial_run::sweep_fast(int it)
         if (lds > 48 * 1024)
             FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k.slab_sweep[which], dim3((unsigned)sa.n_slabs), dim3(1024), lds, stream, sa);
-        hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
+        hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
         FVB_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -992,7 +1032,7 @@ int fvb_spatial_run::sweep_fast(int it)
     const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
     const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane
     hipLaunchKernelGGL(k.sweep[sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2)], dim3(nwg), dim3(256), 2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
-    hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), 0, stream, sa);
+    hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1084,6 +1124,9 @@ struct HostLin
         if (bytes > 48e9)
             return api_fail(-55, "host-evaluated model under spatial VB: two linearisation buffers of " + std::to_string((long long)(bytes / 1e9))
                 + " GB each do not fit the budget (48 GB each)");
+        if (getenv("FVB_SPATIAL_VERBOSE") || bytes > 4e9)
+            fprintf(stderr, "[fvb spatial] host-evaluated model: the linearisations of the whole volume are resident twice on the device "
+                            "and once on the host, %.2f GB each\n", bytes / 1e9);
         for (int i = 0; i < 2; i++)
             FVB_HIP_CHECK(buf[i].alloc(sizeof(double) * V * stride(), stream));
         lin.resize(V * stride());
@@ -1227,8 +1270,8 @@ static int32_t run_spatial_checked(const fvb_config *cfg, const fvb_spatial *sp,
         return api_fail(-42, "spatial description / coordinates missing");
     if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
         return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
-    if (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis != 1)
-        return api_fail(-44, "spatial VB is built for white noise with one noise parameter");
+    if (spatial_noise_kind(cfg) < 0)
+        return api_fail(-44, spatial_noise_refusal);
     if (!out || !out->mvn)
         return api_fail(-20, "outputs.mvn is required");
     if (cfg->n_voxels == 0)
@@ -1251,8 +1294,8 @@ int32_t fabber_vb_spatial_open(const fvb_config *cfg, const fvb_spatial *sp, con
         return api_fail(-42, "spatial description / coordinates missing");
     if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
         return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
-    if (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis != 1)
-        return api_fail(-44, "spatial VB is built for white noise with one noise parameter");
+    if (spatial_noise_kind(cfg) < 0)
+        return api_fail(-44, spatial_noise_refusal);
     if (!out || !out->mvn)
         return api_fail(-20, "outputs.mvn is required");
     if (cfg->n_voxels == 0 || !data)
@@ -1356,9 +1399,11 @@ int32_t fabber_vb_run_spatial_hostmodel_host(const fvb_config *cfg, const fvb_sp
         return api_fail(-50, "linearisation callback is NULL");
     if (!cfg->init_mvn)
         return api_fail(-52, "host-evaluated models need the initial posterior as init_mvn (the model's InitVoxelPosterior runs on the host)");
+    if (sp && sp->locked_centres)
+        return api_fail(-57, "locked linearisation centres are not available for host-evaluated models under spatial VB");
     // the centres of the set-up re-centre: the means of the initial posterior, voxel-major
     const size_t V = (size_t)cfg->n_voxels;
-    const int P = cfg->n_params, n = P + 1, nCov = n * (n + 1) / 2;
+    const int P = cfg->n_params, n = P + spatial_noise_outputs(cfg), nCov = n * (n + 1) / 2;
     std::vector<double> init_means(V * (size_t)P);
     for (size_t v = 0; v < V; v++)
         for (int i = 0; i < P; i++)
@@ -1385,8 +1430,14 @@ static int32_t run_spatial_host_impl(const fvb_config *cfg, const fvb_spatial *s
     const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times;
     if (V == 0)
         return 0;
+    // (before anything is uploaded: a caller that falls back to the host-evaluated route on -40 has not paid for the
+    // series on the device twice)
+    if (spatial_noise_kind(cfg) < 0)
+        return api_fail(-44, spatial_noise_refusal);
+    if (!spatial_kernels_for(cfg).setup)
+        return api_fail(-40, "no spatial kernel instantiation for this model / parameter count / noise model");
     const int P = cfg->n_params;
-    const int n = P + 1, rows = n * (n + 1) / 2 + n + 1;
+    const int n = P + spatial_noise_outputs(cfg), rows = n * (n + 1) / 2 + n + 1;
     const size_t esz = cfg->data_f64 ? 8 : 4;
     fvb_config d = *cfg;
     DevMem b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_status, b_it;
@@ -1437,7 +1488,15 @@ static int32_t run_spatial_host_impl(const fvb_config *cfg, const fvb_spatial *s
         FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * V));
         dout.iterations = (int32_t *)b_it.p;
     }
-    rc = run_spatial_checked(&d, sp, b_data.p, &dout, nullptr, progress_cb, hl);
+    fvb_spatial dsp = *sp;
+    DevMem b_locked;
+    if (sp->locked_centres)
+    {
+        FVB_HIP_CHECK(b_locked.alloc(sizeof(double) * P * V));
+        FVB_HIP_CHECK(hipMemcpy(b_locked.p, sp->locked_centres, sizeof(double) * P * V, hipMemcpyHostToDevice));
+        dsp.locked_centres = (const double *)b_locked.p;
+    }
+    rc = run_spatial_checked(&d, &dsp, b_data.p, &dout, nullptr, progress_cb, hl);
     if (rc)
         return rc;
     FVB_HIP_CHECK(hipDeviceSynchronize());
@@ -1516,8 +1575,8 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         return api_fail(-42, "spatial description / coordinates missing");
     if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
         return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
-    if (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis != 1)
-        return api_fail(-44, "spatial VB is built for white noise with one noise parameter");
+    if (spatial_noise_kind(cfg) < 0)
+        return api_fail(-44, spatial_noise_refusal);
     if (cfg->model == FVB_MODEL_HOSTJAC)
         return api_fail(-56, "a model evaluated on the host runs spatial VB on one device (fabber_vb_run_spatial_hostmodel_host)");
     if (!out || !out->mvn)
@@ -1545,6 +1604,8 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         return 0;
     if (!data)
         return api_fail(-21, "data is NULL");
+    if (sp->locked_centres) // (rare, and nothing a second device would speed up: the one-device run)
+        return fabber_vb_run_spatial_host(cfg, sp, data, out, devs[0], progress_cb);
     const int32_t *X = sp->coords, *Y = sp->coords + V, *Z = sp->coords + 2 * (size_t)V;
     bool second = false, has_spatial = false;
     for (int k = 0; k < P; k++)
@@ -1562,41 +1623,54 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         if (v == 0 || Z[v] != Z[v - 1])
             plane_start.push_back(v);
     }
+    // Every slab keeps at least `halo` planes (its neighbours' ghosts must not reach past it) and leaves as many for
+    // each slab after it; within that the cut falls on the plane boundary nearest to an equal share of the voxels.
+    // A decomposition that does not work out (a very unbalanced mask, planes missing from the z range) is tried
+    // again with one slab fewer, down to the one-device run - never refused.
+    const int n_planes = (int)plane_start.size();
     int world = (int)std::min<size_t>(devs.size(), std::max<size_t>(1, plane_start.size() / (size_t)(2 * halo)));
+    std::vector<std::unique_ptr<SlabRun> > slabs;
+    for (; world > 1; world--)
+    {
+        std::vector<int> cut(1, 0); // plane index at which slab r starts
+        for (int r = 1; r < world; r++)
+        {
+            const int lo = cut.back() + halo, hi = n_planes - (world - r) * halo;
+            const double want = (double)V * r / world;
+            int best = lo;
+            for (int p = lo; p <= hi; p++)
+                if (std::fabs(plane_start[p] - want) < std::fabs(plane_start[best] - want))
+                    best = p;
+            cut.push_back(best);
+        }
+        std::vector<int> bounds;
+        for (int c : cut)
+            bounds.push_back(plane_start[c]);
+        bounds.push_back(V);
+        slabs.clear();
+        bool fits = true;
+        for (int r = 0; r < world && fits; r++)
+        {
+            std::unique_ptr<SlabRun> sl(new SlabRun);
+            sl->dev = devs[r];
+            sl->b = bounds[r];
+            sl->e = bounds[r + 1];
+            sl->g0 = sl->b;
+            sl->g1 = sl->e;
+            if (r > 0)
+                sl->g0 = (int)(std::lower_bound(Z, Z + V, Z[sl->b] - halo) - Z);
+            if (r < world - 1)
+                sl->g1 = (int)(std::upper_bound(Z, Z + V, Z[sl->e - 1] + halo) - Z);
+            fits = !((r > 0 && sl->g0 < bounds[r - 1]) || (r < world - 1 && sl->g1 > bounds[r + 2]));
+            slabs.push_back(std::move(sl));
+        }
+        if (fits)
+            break;
+    }
     if (world <= 1)
         return fabber_vb_run_spatial_host(cfg, sp, data, out, devs[0], progress_cb);
-    std::vector<int> bounds(1, 0);
-    for (int r = 1; r < world; r++)
-    {
-        const double want = (double)V * r / world;
-        int best = plane_start[1];
-        for (int s0 : plane_start)
-            if (s0 > bounds.back() && std::fabs(s0 - want) < std::fabs(best - want))
-                best = s0;
-        if (best <= bounds.back())
-            best = *std::upper_bound(plane_start.begin(), plane_start.end(), bounds.back());
-        bounds.push_back(best);
-    }
-    bounds.push_back(V);
-    std::vector<std::unique_ptr<SlabRun> > slabs;
-    for (int r = 0; r < world; r++)
-    {
-        std::unique_ptr<SlabRun> sl(new SlabRun);
-        sl->dev = devs[r];
-        sl->b = bounds[r];
-        sl->e = bounds[r + 1];
-        sl->g0 = sl->b;
-        sl->g1 = sl->e;
-        if (r > 0)
-            sl->g0 = (int)(std::lower_bound(Z, Z + V, Z[sl->b] - halo) - Z);
-        if (r < world - 1)
-            sl->g1 = (int)(std::upper_bound(Z, Z + V, Z[sl->e - 1] + halo) - Z);
-        if ((r > 0 && sl->g0 < bounds[r - 1]) || (r < world - 1 && sl->g1 > bounds[r + 2]))
-            return api_fail(-48, "a slab is thinner than the halo of its neighbour: use fewer devices for this volume");
-        slabs.push_back(std::move(sl));
-    }
     // ---- per slab: its part of the problem on its device, a run handle ----
-    const int n = P + 1, rows = n * (n + 1) / 2 + n + 1;
+    const int n = P + spatial_noise_outputs(cfg), rows = n * (n + 1) / 2 + n + 1;
     const size_t esz = cfg->data_f64 ? 8 : 4;
     int max_halo = 1;
     for (int r = 0; r < world; r++)

@@ -1,0 +1,16 @@
+// Spatial-VB kernel instantiations for several noise precisions and AR(1) noise (vb_spatial_noise.h), exp model
+#include "vb_spatial_noise.h"
+
+namespace fvb
+{
+SpatialKernels get_spatial_kernels_nz_exp(int P, bool need_f, int kind)
+{
+    switch (P)
+    {
+        FVB_SPATIAL_NZ_CASE(ExpModel, "exp", 2)
+        FVB_SPATIAL_NZ_CASE(ExpModel, "exp", 4)
+    default:
+        return SpatialKernels{};
+    }
+}
+} // namespace fvb

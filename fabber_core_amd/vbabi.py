@@ -14,7 +14,7 @@ import numpy as np
 
 FVB_MAX_PARAMS = 16
 FVB_MAX_PHIS = 8
-FVB_ABI_VERSION = 5
+FVB_ABI_VERSION = 6
 
 MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
 TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)
@@ -317,6 +317,7 @@ class FvbSpatial(C.Structure):
         ("owned_begin", C.c_int32),
         ("owned_end", C.c_int32),
         ("n_voxels_global", C.c_int32),
+        ("locked_centres", C.c_void_p),
     ]
 
 
@@ -331,7 +332,7 @@ def grid_coords(shape, mask=None):
 
 class SpatialHolder:
     def __init__(self, coords, spatial_dims=3, spatial_speed=-1.0, q1=10.0, q2=1.0, update_first_iter=False,
-                 owned=None, n_voxels_global=0):
+                 owned=None, n_voxels_global=0, locked_centres=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.int32)
         assert self.coords.ndim == 2 and self.coords.shape[0] == 3
         self.sp = FvbSpatial()
@@ -343,3 +344,6 @@ class SpatialHolder:
         self.sp.q2 = q2
         self.sp.owned_begin, self.sp.owned_end = owned if owned is not None else (0, 0)
         self.sp.n_voxels_global = n_voxels_global
+        # [P][V] fixed linearisation centres (locked-linear-from-mvn), kept alive with the holder
+        self.locked_centres = None if locked_centres is None else np.ascontiguousarray(locked_centres, dtype=np.float64)
+        self.sp.locked_centres = None if self.locked_centres is None else self.locked_centres.ctypes.data

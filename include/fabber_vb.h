@@ -44,7 +44,7 @@ extern "C" {
 
 #define FVB_MAX_PARAMS 16
 #define FVB_MAX_PHIS 8
-#define FVB_ABI_VERSION 5
+#define FVB_ABI_VERSION 6
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
@@ -267,6 +267,10 @@ typedef struct fvb_spatial
      * boundary planes. owned_end <= owned_begin (e.g. both 0) = every voxel is owned. */
     int32_t owned_begin, owned_end;
     int32_t n_voxels_global; /* voxel count of the whole volume (0 = n_voxels): the V of h_K, priors.cc:321 */
+    const double *locked_centres; /* [n_params][n_voxels] fixed linearisation centres (option locked-linear-from-mvn,
+                                inference_vb.cc:171-181): the set-up re-centre uses them (:225-232) and the spatial
+                                loop never re-centres (:695-696). NULL = re-centre on the posterior means. Same
+                                memory space as data. */
 } fvb_spatial;
 
 /* Same conventions as fabber_vb_run_device / fabber_vb_run_host. The iteration count is

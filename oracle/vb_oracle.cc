@@ -1576,11 +1576,22 @@ int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double
 static std::string g_oracle_error;
 int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out)
 {
-    if (cfg->abi_version != FVB_ABI_VERSION || cfg->noise != FVB_NOISE_WHITE)
+    if (cfg->abi_version != FVB_ABI_VERSION)
         return -1;
     try
     {
-        return run_spatial(cfg, sp, data, out);
+        if (cfg->noise == FVB_NOISE_WHITE)
+            return run_spatial<SpatialWhite>(cfg, sp, data, out);
+        if (cfg->noise != FVB_NOISE_AR1)
+            return -1;
+        if (cfg->phi_index)
+            for (int t = 0; t < cfg->n_times; t++)
+                if (cfg->phi_index[t] == 255)
+                    return -3; // masked timepoints are rejected for AR noise (noisemodel_ar.cc:351-355)
+        if (cfg->n_phis < 1 || cfg->n_phis > 2 || cfg->ar_cross_terms < 0 || cfg->ar_cross_terms > 2
+            || (cfg->n_phis == 1 && cfg->ar_cross_terms != 0) || cfg->n_times % cfg->n_phis != 0)
+            return -4;
+        return run_spatial<SpatialAr>(cfg, sp, data, out);
     }
     catch (std::exception &e)
     {

@@ -29,6 +29,7 @@ TOL_MEAN = 1e-6   # |d mean| <= TOL_MEAN * max(|mean|, posterior sd)
 TOL_COV = 2e-4    # |d cov_ij| <= TOL_COV * sd_i sd_j   (finite-difference noise, see above)
 TOL_F = 1e-6      # |dF| <= TOL_F * max(1, |F|)
 NORTH_STAR = 1e-4  # BASELINE.json: posterior means within 1e-4 relative
+FLOOR_FACTOR = 3   # a comparison that opted in may use this many times the OBSERVED CPU-vs-CPU difference (round 2: 10)
 
 
 def voxel_errors(holder, a, b, mask=None):
@@ -69,7 +70,7 @@ def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=No
     cpu2 (optional) = result of the second CPU build (oracle.run_fma). If two CPU builds of the
     same source already differ by more than the base tolerance on this problem (the
     finite-difference Jacobian amplifies rounding, see module docstring), the tolerance MAY be
-    raised to 10x that measured floor - never beyond the north-star bound of 1e-4 on the means
+    raised to 3x that measured floor - never beyond the north-star bound of 1e-4 on the means
     (1e-2 sd_i sd_j on covariances) - but only for a caller that opted in with allow_floor=True:
     a test that needs the raised bound without having asked for it fails, and every call that ran
     at a raised bound is recorded in RAISED (tests/conftest.py prints them at the end of the run;
@@ -81,11 +82,11 @@ def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=No
         okf = (a["status"] == 0) & (cpu2["status"] == 0) & (a["iterations"] == cpu2["iterations"])
         if okf.any():
             f_mean, f_cov, _ = voxel_errors(holder, a, cpu2, okf)
-            floor["tol_mean"] = min(10 * float(f_mean.max()), NORTH_STAR)
-            floor["tol_cov"] = min(10 * float(f_cov.max()), 1e-2)
+            floor["tol_mean"] = min(FLOOR_FACTOR * float(f_mean.max()), NORTH_STAR)
+            floor["tol_cov"] = min(FLOOR_FACTOR * float(f_cov.max()), 1e-2)
             if cfg.need_f:
                 Fa, Fc = a["free_energy"][okf], cpu2["free_energy"][okf]
-                floor["tol_f"] = min(10 * float(np.max(np.abs(Fa - Fc) / np.maximum(1.0, np.abs(Fa)))), 1e-3)
+                floor["tol_f"] = min(FLOOR_FACTOR * float(np.max(np.abs(Fa - Fc) / np.maximum(1.0, np.abs(Fa)))), 1e-3)
     assert np.array_equal(a["status"], b["status"]), (what, "status", np.flatnonzero(a["status"] != b["status"])[:8])
     n_it = int(np.count_nonzero(a["iterations"] != b["iterations"]))
     assert n_it <= allow_iter_mismatch, (what, "iterations differ on %d voxels" % n_it)
@@ -106,9 +107,9 @@ def strict(holder, a, b, what="", tol_mean=TOL_MEAN, tol_cov=TOL_COV, check_f=No
         if err <= base[k]:
             continue
         # beyond the base tolerance: only acceptable below the measured CPU-vs-CPU floor, and only on request
-        assert err <= floor[k], (what, label[k], err, "base tolerance %g, 10 x CPU-vs-CPU floor %g" % (base[k], floor[k]))
+        assert err <= floor[k], (what, label[k], err, "base tolerance %g, 3 x CPU-vs-CPU floor %g" % (base[k], floor[k]))
         assert allow_floor or os.environ.get("PARITY_RECORD_ONLY"), (
-            what, label[k], err, "within 10 x the CPU-vs-CPU floor (%g) but beyond the base tolerance %g, and the "
+            what, label[k], err, "within 3 x the CPU-vs-CPU floor (%g) but beyond the base tolerance %g, and the "
             "test did not opt in with allow_floor=True" % (floor[k], base[k]))
         out[k] = floor[k]
         out["raised"] = True

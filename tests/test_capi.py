@@ -402,3 +402,15 @@ def test_noise_distributions_from_matrix_files(tmp_path):
     assert np.abs(only_prior["finalMVN"] - by_file["finalMVN"]).max() > 0
     with pytest.raises(fabber.FabberError):
         fabber.run(data, dict(opts, noise="ar", **{"noise-initial-prior": str(f)}))
+    # what WhiteParams::InputFromMVN rejects (noisemodel_white.cc:70-79): precisions with a covariance between them;
+    # and what no Gamma distribution has: a non-positive mean or variance
+    two = tmp_path / "two.mat"
+    two.write_text("32 1 4\n1 32 4\n4 4 1\n")
+    with pytest.raises(fabber.FabberError, match="zero covariance"):
+        fabber.run(data, dict(opts, **{"noise-pattern": "12", "noise-initial-prior": str(two)}))
+    two.write_text("32 0 4\n0 32 4\n4 4 1\n")
+    assert np.isfinite(fabber.run(data, dict(opts, **{"noise-pattern": "12", "noise-initial-prior": str(two)}))["mean_c0"]).all()
+    for text in ("32 -4\n-4 1\n", "0 4\n4 1\n"):
+        f.write_text(text)
+        with pytest.raises(fabber.FabberError, match="positive mean and a positive variance"):
+            fabber.run(data, dict(opts, **{"noise-initial-prior": str(f)}))

@@ -317,10 +317,51 @@ def test_devices_option_with_spatialvb():
     opts = {"model": "poly", "degree": 1, "noise": "white", "method": "spatialvb", "max-iterations": 5, "param-spatial-priors": "MN",
             "save-mean": True, "save-mvn": True}
     one = fabber.run(data, opts)
-    two = fabber.run(data, dict(opts, devices="0,0"))
-    assert "z-slabs" in two["log"]
+    two = fabber.run(data, dict(opts, devices="0,0", **{"spatial-slabs": True}))
+    assert "cut into z-slabs" in two["log"]
     for k in ("finalMVN", "mean_c0", "mean_c1"):
         assert np.array_equal(one[k], two[k]), k
+    # devices= alone shards voxelwise VB: a spatial run stays on one device (the faster choice) and says so
+    plain = fabber.run(data, dict(opts, devices="0,0"))
+    assert "cut into z-slabs" not in plain["log"] and "uses one device" in plain["log"]
+    assert np.array_equal(one["finalMVN"], plain["finalMVN"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", ["M", "P"])
+def test_engine_slabs_on_a_very_unbalanced_mask(typ):
+    """Plane voxel counts 1, 1, 1, 1, 1, 1, 60, 60 (round 2: the voxel-balanced cut ran off the end of the plane list
+    or left a slab thinner than the halo of second-neighbour priors and the run was refused): every slab keeps its
+    halo, and what cannot be cut runs on fewer slabs - the single-device result either way"""
+    pts = [(0, 0, z) for z in range(6)] + [(x, y, z) for z in (6, 7) for y in range(6) for x in range(10)]
+    coords = np.array(pts, dtype=np.int32).T.copy()
+    V, T = coords.shape[1], 20
+    rng = np.random.default_rng(31)
+    t = np.arange(1, T + 1.0)
+    y = 2.0 + 0.1 * coords[0][None, :] + 0.3 * t[:, None] + rng.normal(0, 0.2, (T, V))
+    h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=5, param_overrides={"c0": dict(type=typ)})
+    sp = vbabi.SpatialHolder(coords)
+    ref = hiplib.run_spatial_host(h, sp, y)
+    for slabs in (2, 3, 4):
+        got = hiplib.run_spatial_host(h, sp, y, devices=[0] * slabs)
+        assert np.array_equal(got["mvn"], ref["mvn"]) and np.array_equal(got["status"], ref["status"]), (typ, slabs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise_kw", [dict(noise=vbabi.NOISE_AR1), dict(noise_pattern="12")])
+def test_engine_slabs_under_other_noise_models(noise_kw):
+    """the slab driver runs the same kernels: AR(1) noise and two noise precisions, bit for bit the one-device run"""
+    coords = masked_coords((8, 7, 10), seed=41, keep=0.9)
+    V, T = coords.shape[1], 30
+    rng = np.random.default_rng(42)
+    t = np.arange(1, T + 1.0)
+    y = 2.0 + np.sin(coords[0] / 2.0)[None, :] + 0.3 * t[:, None] + rng.normal(0, 0.3, (T, V))
+    h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=5, need_f=True, param_overrides={"c0": dict(type="M")}, **noise_kw)
+    sp = vbabi.SpatialHolder(coords)
+    ref = hiplib.run_spatial_host(h, sp, y)
+    got = hiplib.run_spatial_host(h, sp, y, devices=[0, 0, 0])
+    for k in ("mvn", "status", "free_energy"):
+        assert np.array_equal(got[k], ref[k]), k
 
 
 @pytest.mark.gpu
