@@ -187,6 +187,83 @@ def bench_spatial(args, world, rank, device):
     return result
 
 
+def bench_boundary(w, V, holder, y, need_f, steps=3):
+    """The drop-in boundary itself, PCIe and host work included (never the headline `value`):
+    (1) fabber_vb_run_host - host pointers in and out of the engine's own entry point (pageable buffers the caller
+        allocated beforehand): pipelined over voxel blocks, and as one block (round 2's path) beside it;
+    (2) the reference's C ABI on the same problem - fabber_new, fabber_set_extent, fabber_set_opt, fabber_set_data
+        (float32 [t][z][y][x] -> NEWMAT-style double matrix), fabber_dorun (Vb::DoCalculations through
+        fabber_vb_run_host with the series as float64, then SaveResults), fabber_get_data of finalMVN and the means
+        (fabber_capi.cc:96-233, rundata_array.cc:68-133), timed stage by stage."""
+    import ctypes as C
+    from fabber_core_amd import fabber, hiplib
+    out = {}
+    res = hiplib.run_host(holder, y)
+
+    def timed(fn, n=steps):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.min(ts)), float(np.mean(ts))
+    prev = os.environ.get("FVB_HOST_BLOCK_VOXELS")
+    try:
+        os.environ.pop("FVB_HOST_BLOCK_VOXELS", None)
+        best, mean = timed(lambda: hiplib.run_host(holder, y, into=res))
+        out["fabber_vb_run_host_ms"] = {"min": best, "mean": mean, "voxels_per_s": V / (mean * 1e-3),
+                                        "how": "blocks of 262144 voxels: upload / fit / download overlap on three streams"}
+        os.environ["FVB_HOST_BLOCK_VOXELS"] = "0"
+        best, mean = timed(lambda: hiplib.run_host(holder, y, into=res))
+        out["fabber_vb_run_host_one_block_ms"] = {"min": best, "mean": mean}
+    finally:
+        if prev is None:
+            os.environ.pop("FVB_HOST_BLOCK_VOXELS", None)
+        else:
+            os.environ["FVB_HOST_BLOCK_VOXELS"] = prev
+    if w.get("kind", "exp") != "exp":
+        return out
+    # (2) the reference's C ABI; the volume is V x 1 x 1 (x fastest = the voxel order of the series as it is)
+    L = fabber.load_library()
+    err = C.create_string_buffer(255)
+    mask = np.ones(V, dtype=np.int32)
+    opts = {"model": "exp", "num-exps": w["num_exps"], "dt": w["dt"], "max-iterations": w["its"], "noise": "white", "method": "vb",
+            "save-mean": "", "save-mvn": "", "allow-bad-voxels": ""}
+    if need_f:
+        opts["save-free-energy"] = ""
+    rows = holder.n_mvn_rows
+    mvn = np.empty((rows, V), dtype=np.float32)
+    mean = np.empty(V, dtype=np.float32)
+    stages = {k: [] for k in ("new+extent+options", "set_data", "dorun", "get_data", "destroy", "total")}
+    log = C.create_string_buffer(1 << 16)
+    for _ in range(steps):
+        t = [time.perf_counter()]
+        fab = L.fabber_new(err)
+        assert L.fabber_set_extent(fab, V, 1, 1, mask.ctypes.data, err) == 0, err.value
+        for k, v in opts.items():
+            assert L.fabber_set_opt(fab, k.encode(), str(v).encode(), err) == 0, err.value
+        t.append(time.perf_counter())
+        assert L.fabber_set_data(fab, b"data", w["T"], y.ctypes.data, err) == 0, err.value
+        t.append(time.perf_counter())
+        assert L.fabber_dorun(fab, len(log), log, err, None) == 0, err.value
+        t.append(time.perf_counter())
+        assert L.fabber_get_data_size(fab, b"finalMVN", err) == rows, err.value
+        assert L.fabber_get_data(fab, b"finalMVN", mvn.ctypes.data, err) == 0, err.value
+        for name in ("mean_amp1", "mean_r1"):
+            assert L.fabber_get_data(fab, name.encode(), mean.ctypes.data, err) == 0, err.value
+        t.append(time.perf_counter())
+        L.fabber_destroy(fab)
+        t.append(time.perf_counter())
+        for k, a, b in zip(list(stages)[:5], t[:-1], t[1:]):
+            stages[k].append((b - a) * 1e3)
+        stages["total"].append((t[-1] - t[0]) * 1e3)
+    out["fabber_capi_ms"] = {k: float(np.mean(v)) for k, v in stages.items()}
+    out["fabber_capi_ms"]["voxels_per_s"] = V / (out["fabber_capi_ms"]["total"] * 1e-3)
+    out["fabber_capi_ms"]["how"] = ("fabber_new .. fabber_destroy per run, %d runs; the C ABI takes float32 volumes, keeps them as double "
+                                    "matrices (the reference's NEWMAT::Matrix) and returns float32 volumes" % steps)
+    return out
+
+
 def bench_single_process(args):
     """--single-process: N devices driven by ONE process through the C ABI's own sharding
     (fabber_vb_run_host_multi: contiguous voxel blocks, one host thread + stream per device, nothing
@@ -262,6 +339,7 @@ def main():
     ap.add_argument("--residual", default="auto", choices=["auto", "exact", "moments"],
                     help="how k'Qk is obtained (fabber_vb_set_residual_mode); default adaptive")
     ap.add_argument("--residual-tol", type=float, default=None)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the timing of the host-pointer entry point and of the C ABI (the `e2e` object)")
     ap.add_argument("--single-process", action="store_true",
                     help="with --gpus N: one process, the C++ engine's own sharding (fabber_vb_run_host_multi, host buffers: "
                          "the rate includes the PCIe transfers and is reported as such)")
@@ -445,6 +523,9 @@ def main():
                        **({"rehearsal": "ranks share one GPU over gloo: not a measurement"} if rehearsal else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if world == 1 and not args.no_e2e:
+            # outside the timed region: the boundary's own rate (host pointers / the reference's C ABI)
+            result["e2e"] = bench_boundary(w, V, holder, y, bool(args.need_f))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

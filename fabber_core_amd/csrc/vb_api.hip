@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -532,101 +534,242 @@ namespace
 // Voxels [v0, v1) of a host-resident problem on one device: the block's columns of every [row][voxel]
 // image go up and down as 2-D copies (row pitch = the caller's n_voxels), the kernels see a problem of
 // v1 - v0 voxels. Runs on `stream`; returns after the block's results are in the caller's arrays.
+// The three stages of a block: in (allocate, upload), fit (the kernels), out (download). They may run on three
+// different streams - the pipelined host entry point below uploads block b + 1 and downloads block b - 1 while block
+// b is being fitted - ordered by the events up_done and fit_done.
+struct HostBlock
+{
+    const fvb_config *cfg = nullptr;
+    const void *data = nullptr;
+    const fvb_outputs *out = nullptr;
+    int v0 = 0, v1 = 0, kernel_voxels = 0, rows = 0;
+    fvb_config d;
+    fvb_outputs dout;
+    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
+    hipEvent_t up_done = nullptr, fit_done = nullptr;
+    ~HostBlock()
+    {
+        if (up_done)
+            (void)hipEventDestroy(up_done);
+        if (fit_done)
+            (void)hipEventDestroy(fit_done);
+    }
+    int stage_in(hipStream_t stream)
+    {
+        const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times, Vb = (size_t)(v1 - v0);
+        const int P = cfg->n_params;
+        rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
+        const size_t esz = cfg->data_f64 ? 8 : 4;
+        auto upload = [&](void *dst, const void *src, size_t elem, size_t nrows) {
+            return hipMemcpy2DAsync(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows,
+                hipMemcpyHostToDevice, stream);
+        };
+        d = *cfg;
+        d.n_voxels = (int32_t)Vb;
+        FVB_HIP_CHECK(b_data.alloc(T * Vb * esz, stream));
+        FVB_HIP_CHECK(upload(b_data.p, data, esz, T));
+        if (cfg->design)
+        {
+            FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P, stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice, stream));
+            d.design = (const double *)b_design.p;
+        }
+        if (cfg->phi_index)
+        {
+            FVB_HIP_CHECK(b_phi.alloc(T, stream));
+            FVB_HIP_CHECK(hipMemcpyAsync(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice, stream));
+            d.phi_index = (const uint8_t *)b_phi.p;
+        }
+        if (cfg->init_mvn)
+        {
+            FVB_HIP_CHECK(b_init.alloc(sizeof(double) * rows * Vb, stream));
+            FVB_HIP_CHECK(upload(b_init.p, cfg->init_mvn, sizeof(double), rows));
+            d.init_mvn = (const double *)b_init.p;
+        }
+        for (int k = 0; k < P; k++)
+            if (cfg->image_prior[k])
+            {
+                FVB_HIP_CHECK(b_img[k].alloc(sizeof(double) * Vb, stream));
+                FVB_HIP_CHECK(upload(b_img[k].p, cfg->image_prior[k], sizeof(double), 1));
+                d.image_prior[k] = (const double *)b_img[k].p;
+            }
+        memset(&dout, 0, sizeof(dout));
+        FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * Vb, stream));
+        dout.mvn = (double *)b_mvn.p;
+        if (out->free_energy)
+        {
+            FVB_HIP_CHECK(b_f.alloc(sizeof(double) * Vb, stream));
+            dout.free_energy = (double *)b_f.p;
+        }
+        if (out->f_history && cfg->f_history_rows > 0)
+        {
+            FVB_HIP_CHECK(b_hist.alloc(sizeof(double) * cfg->f_history_rows * Vb, stream));
+            FVB_HIP_CHECK(hipMemsetAsync(b_hist.p, 0xff, sizeof(double) * cfg->f_history_rows * Vb, stream)); // NaN fill
+            dout.f_history = (double *)b_hist.p;
+        }
+        if (out->f_history_len)
+        {
+            FVB_HIP_CHECK(b_hlen.alloc(sizeof(int32_t) * Vb, stream));
+            dout.f_history_len = (int32_t *)b_hlen.p;
+        }
+        if (out->status)
+        {
+            FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * Vb, stream));
+            dout.status = (int32_t *)b_status.p;
+        }
+        if (out->iterations)
+        {
+            FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * Vb, stream));
+            dout.iterations = (int32_t *)b_it.p;
+        }
+        FVB_HIP_CHECK(hipEventCreateWithFlags(&up_done, hipEventDisableTiming));
+        FVB_HIP_CHECK(hipEventRecord(up_done, stream));
+        return 0;
+    }
+    int fit(hipStream_t stream, int n_unmasked)
+    {
+        FVB_HIP_CHECK(hipStreamWaitEvent(stream, up_done, 0));
+        int rc = run_device_as(&d, b_data.p, &dout, stream, n_unmasked, kernel_voxels);
+        if (rc)
+            return rc;
+        FVB_HIP_CHECK(hipEventCreateWithFlags(&fit_done, hipEventDisableTiming));
+        FVB_HIP_CHECK(hipEventRecord(fit_done, stream));
+        return 0;
+    }
+    // returns after the block's results are in the caller's arrays
+    int stage_out(hipStream_t stream)
+    {
+        const size_t V = (size_t)cfg->n_voxels, Vb = (size_t)(v1 - v0);
+        auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
+            return hipMemcpy2DAsync((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows,
+                hipMemcpyDeviceToHost, stream);
+        };
+        FVB_HIP_CHECK(hipStreamWaitEvent(stream, fit_done, 0));
+        FVB_HIP_CHECK(download(out->mvn, dout.mvn, sizeof(double), rows));
+        if (dout.free_energy)
+            FVB_HIP_CHECK(download(out->free_energy, dout.free_energy, sizeof(double), 1));
+        if (dout.f_history)
+            FVB_HIP_CHECK(download(out->f_history, dout.f_history, sizeof(double), cfg->f_history_rows));
+        if (dout.f_history_len)
+            FVB_HIP_CHECK(download(out->f_history_len, dout.f_history_len, sizeof(int32_t), 1));
+        if (dout.status)
+            FVB_HIP_CHECK(download(out->status, dout.status, sizeof(int32_t), 1));
+        if (dout.iterations)
+            FVB_HIP_CHECK(download(out->iterations, dout.iterations, sizeof(int32_t), 1));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
+    }
+};
+
 int run_host_block(const fvb_config *cfg, const void *data, const fvb_outputs *out, int device, int v0, int v1,
     hipStream_t stream, int kernel_voxels)
 {
     FVB_HIP_CHECK(hipSetDevice(device));
-    const size_t V = (size_t)cfg->n_voxels, T = (size_t)cfg->n_times, Vb = (size_t)(v1 - v0);
-    if (Vb == 0)
+    if (v1 <= v0)
         return 0;
-    const int P = cfg->n_params;
-    const int rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
-    const size_t esz = cfg->data_f64 ? 8 : 4;
-    auto upload = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-        return hipMemcpy2DAsync(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows,
-            hipMemcpyHostToDevice, stream);
-    };
-    auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-        return hipMemcpy2DAsync((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows,
-            hipMemcpyDeviceToHost, stream);
-    };
-    fvb_config d = *cfg;
-    d.n_voxels = (int32_t)Vb;
-    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS];
-    FVB_HIP_CHECK(b_data.alloc(T * Vb * esz, stream));
-    FVB_HIP_CHECK(upload(b_data.p, data, esz, T));
-    if (cfg->design)
-    {
-        FVB_HIP_CHECK(b_design.alloc(sizeof(double) * T * P, stream));
-        FVB_HIP_CHECK(hipMemcpyAsync(b_design.p, cfg->design, sizeof(double) * T * P, hipMemcpyHostToDevice, stream));
-        d.design = (const double *)b_design.p;
-    }
-    if (cfg->phi_index)
-    {
-        FVB_HIP_CHECK(b_phi.alloc(T, stream));
-        FVB_HIP_CHECK(hipMemcpyAsync(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice, stream));
-        d.phi_index = (const uint8_t *)b_phi.p;
-    }
-    if (cfg->init_mvn)
-    {
-        FVB_HIP_CHECK(b_init.alloc(sizeof(double) * rows * Vb, stream));
-        FVB_HIP_CHECK(upload(b_init.p, cfg->init_mvn, sizeof(double), rows));
-        d.init_mvn = (const double *)b_init.p;
-    }
-    for (int k = 0; k < P; k++)
-        if (cfg->image_prior[k])
+    HostBlock b;
+    b.cfg = cfg;
+    b.data = data;
+    b.out = out;
+    b.v0 = v0;
+    b.v1 = v1;
+    b.kernel_voxels = kernel_voxels;
+    int rc = b.stage_in(stream);
+    if (rc == 0)
+        rc = b.fit(stream, count_unmasked(cfg, cfg->phi_index));
+    if (rc == 0)
+        rc = b.stage_out(stream);
+    if (rc)
+        (void)hipStreamSynchronize(stream); // (before the block's buffers go back to the pool)
+    return rc;
+}
+
+// The whole problem through host pointers on one device, as a PIPELINE over blocks of voxels: while block b is being
+// fitted, block b + 1 goes up and block b - 1 comes down (three streams; the caller's buffers are pageable, so a copy
+// holds the host thread that issued it: this thread uploads and launches, a second one downloads). What a voxel gets
+// depends on nothing but that voxel, and every block runs the kernel the whole problem would, so the result is the
+// one-block run's bit for bit (tests/test_multi_device.py). C3 (1e6 voxels, 400 MB up, 176 MB down): the sum of its
+// parts was 7.5 + 15.2 + 3.3 ms; piped, the copies hide behind the 15 ms of arithmetic.
+int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_outputs *out, int device, int block_voxels)
+{
+    FVB_HIP_CHECK(hipSetDevice(device));
+    const int V = cfg->n_voxels;
+    const int n_blocks = (V + block_voxels - 1) / block_voxels;
+    const int n_unmasked = count_unmasked(cfg, cfg->phi_index);
+    hipStream_t s_up = nullptr, s_fit = nullptr, s_down = nullptr;
+    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit, hipStreamNonBlocking));
+    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    std::vector<std::unique_ptr<HostBlock> > blocks((size_t)n_blocks);
+    std::mutex lock;
+    std::condition_variable cv;
+    int launched = 0;       // blocks whose fit has been enqueued
+    bool abandoned = false; // the uploading side failed: no more blocks will come
+    int rc_down = 0;
+    std::string err_down;
+    std::thread downloader([&] {
+        if (hipSetDevice(device) != hipSuccess)
         {
-            FVB_HIP_CHECK(b_img[k].alloc(sizeof(double) * Vb, stream));
-            FVB_HIP_CHECK(upload(b_img[k].p, cfg->image_prior[k], sizeof(double), 1));
-            d.image_prior[k] = (const double *)b_img[k].p;
+            rc_down = -32;
+            err_down = "cannot select the device in the download thread";
+            return;
         }
-    fvb_outputs dout;
-    memset(&dout, 0, sizeof(dout));
-    DevBuf b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
-    FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * Vb, stream));
-    dout.mvn = (double *)b_mvn.p;
-    if (out->free_energy)
+        for (int b = 0; b < n_blocks; b++)
+        {
+            {
+                std::unique_lock<std::mutex> hold(lock);
+                cv.wait(hold, [&] { return launched > b || abandoned; });
+                if (launched <= b)
+                    return;
+            }
+            const int rc = blocks[(size_t)b]->stage_out(s_down);
+            if (rc && rc_down == 0)
+            {
+                rc_down = rc;
+                err_down = g_last_error; // thread-local: carry it to the caller's thread
+            }
+            std::unique_lock<std::mutex> hold(lock);
+            blocks[(size_t)b].reset(); // (its buffers go back to the pool: at most three blocks are resident)
+        }
+    });
+    int rc = 0;
+    for (int b = 0; b < n_blocks && rc == 0; b++)
     {
-        FVB_HIP_CHECK(b_f.alloc(sizeof(double) * Vb, stream));
-        dout.free_energy = (double *)b_f.p;
+        std::unique_ptr<HostBlock> blk(new HostBlock);
+        blk->cfg = cfg;
+        blk->data = data;
+        blk->out = out;
+        blk->v0 = b * block_voxels;
+        blk->v1 = std::min(V, (b + 1) * block_voxels);
+        blk->kernel_voxels = V;
+        rc = blk->stage_in(s_up);
+        if (rc == 0)
+            rc = blk->fit(s_fit, n_unmasked);
+        std::unique_lock<std::mutex> hold(lock);
+        if (rc == 0)
+        {
+            blocks[(size_t)b] = std::move(blk);
+            launched = b + 1;
+        }
+        else
+        {
+            (void)hipDeviceSynchronize(); // (before the failed block's buffers go back to the pool)
+            abandoned = true;
+        }
+        cv.notify_all();
     }
-    if (out->f_history && cfg->f_history_rows > 0)
-    {
-        FVB_HIP_CHECK(b_hist.alloc(sizeof(double) * cfg->f_history_rows * Vb, stream));
-        FVB_HIP_CHECK(hipMemsetAsync(b_hist.p, 0xff, sizeof(double) * cfg->f_history_rows * Vb, stream)); // NaN fill
-        dout.f_history = (double *)b_hist.p;
-    }
-    if (out->f_history_len)
-    {
-        FVB_HIP_CHECK(b_hlen.alloc(sizeof(int32_t) * Vb, stream));
-        dout.f_history_len = (int32_t *)b_hlen.p;
-    }
-    if (out->status)
-    {
-        FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * Vb, stream));
-        dout.status = (int32_t *)b_status.p;
-    }
-    if (out->iterations)
-    {
-        FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * Vb, stream));
-        dout.iterations = (int32_t *)b_it.p;
-    }
-    // (the uploads above read pageable host memory: the copies have completed on return)
-    int rc = run_device_as(&d, b_data.p, &dout, stream, count_unmasked(cfg, cfg->phi_index), kernel_voxels);
+    downloader.join();
+    (void)hipStreamSynchronize(s_up);
+    (void)hipStreamSynchronize(s_fit);
+    (void)hipStreamSynchronize(s_down);
+    blocks.clear();
+    (void)hipStreamDestroy(s_up);
+    (void)hipStreamDestroy(s_fit);
+    (void)hipStreamDestroy(s_down);
     if (rc)
         return rc;
-    FVB_HIP_CHECK(download(out->mvn, dout.mvn, sizeof(double), rows));
-    if (dout.free_energy)
-        FVB_HIP_CHECK(download(out->free_energy, dout.free_energy, sizeof(double), 1));
-    if (dout.f_history)
-        FVB_HIP_CHECK(download(out->f_history, dout.f_history, sizeof(double), cfg->f_history_rows));
-    if (dout.f_history_len)
-        FVB_HIP_CHECK(download(out->f_history_len, dout.f_history_len, sizeof(int32_t), 1));
-    if (dout.status)
-        FVB_HIP_CHECK(download(out->status, dout.status, sizeof(int32_t), 1));
-    if (dout.iterations)
-        FVB_HIP_CHECK(download(out->iterations, dout.iterations, sizeof(int32_t), 1));
-    FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    if (rc_down)
+        return fail(rc_down, err_down);
     return 0;
 }
 } // namespace
@@ -640,6 +783,15 @@ int32_t fabber_vb_run_host(const fvb_config *cfg, const void *data, const fvb_ou
         return fail(-20, "outputs.mvn is required");
     if (fabber_vb_device_count() <= 0)
         return fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
+    // large problems on a throughput (lane) kernel: upload, fit and download overlap block by block. A block holds
+    // as many voxels as fill the chip twice (256 CUs x 4 SIMDs x 2 waves x 64 lanes = 131072): smaller ones leave
+    // SIMDs idle in every block's tail, larger ones lengthen the pipeline's fill and drain.
+    int block = 262144;
+    if (const char *e = getenv("FVB_HOST_BLOCK_VOXELS")) // (0 = one block, the round-2 behaviour)
+        block = atoi(e) / 64 * 64;
+    fvb_config choice = *cfg;
+    if (block > 0 && cfg->n_voxels >= 2 * block && (select_lane(&choice).fn || select_lane(&choice).fn_tiles_f32))
+        return run_host_pipelined(cfg, data, out, device, block);
     return run_host_block(cfg, data, out, device, 0, cfg->n_voxels, nullptr, cfg->n_voxels);
 }
 

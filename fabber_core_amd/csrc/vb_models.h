@@ -23,7 +23,13 @@
 // when a parameter is small). To keep J as close as possible to what the reference's CPU code
 // computes, model bodies and the differencing are compiled WITHOUT fused multiply-add
 // contraction, i.e. with the same operation sequence as the reference's C++.
+// (FVB_CONTRACT_MODELS: experiment switch - contraction left to the compiler everywhere; measured against the binary128
+// ground truth by tools/measure/c3_truth.py, profiles/r3_c3_truth_contract.json)
+#ifdef FVB_CONTRACT_MODELS
+#define FVB_NO_CONTRACT _Pragma("clang fp contract(fast)")
+#else
 #define FVB_NO_CONTRACT _Pragma("clang fp contract(off)")
+#endif
 
 namespace fvb
 {

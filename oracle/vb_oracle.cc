@@ -1295,10 +1295,12 @@ static inline real load_data(const fvb_config *cfg, const void *data, size_t idx
     return cfg->data_f64 ? ((const double *)data)[idx] : (real)((const float *)data)[idx];
 }
 
-#ifndef ORACLE_QUAD // the binary128 build restates the white-noise voxelwise loop only
+#ifndef ORACLE_QUAD // the binary128 build restates the white-noise loops only (voxelwise and spatial)
 #include "vb_oracle_ar.inc"
 #include "vb_oracle_arn.inc"
+#endif
 #include "vb_oracle_spatial.inc"
+#ifndef ORACLE_QUAD
 #include "vb_oracle_nlls.inc"
 #endif
 
@@ -1511,6 +1513,42 @@ void oracle_set_inverse(int32_t mode)
     g_inverse_mode = mode;
 }
 
+// Vb::DoCalculationsSpatial. Returns 0, or < 0 with the exception text in oracle_last_error().
+static std::string g_oracle_error;
+int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out)
+{
+    if (cfg->abi_version != FVB_ABI_VERSION)
+        return -1;
+    try
+    {
+        if (cfg->noise == FVB_NOISE_WHITE)
+            return run_spatial<SpatialWhite>(cfg, sp, data, out);
+#ifdef ORACLE_QUAD
+        return -2;
+#else
+        if (cfg->noise != FVB_NOISE_AR1)
+            return -1;
+        if (cfg->phi_index)
+            for (int t = 0; t < cfg->n_times; t++)
+                if (cfg->phi_index[t] == 255)
+                    return -3; // masked timepoints are rejected for AR noise (noisemodel_ar.cc:351-355)
+        if (cfg->n_phis < 1 || cfg->n_phis > 2 || cfg->ar_cross_terms < 0 || cfg->ar_cross_terms > 2
+            || (cfg->n_phis == 1 && cfg->ar_cross_terms != 0) || cfg->n_times % cfg->n_phis != 0)
+            return -4;
+        return run_spatial<SpatialAr>(cfg, sp, data, out);
+#endif
+    }
+    catch (std::exception &e)
+    {
+        g_oracle_error = e.what();
+        return -10;
+    }
+}
+const char *oracle_last_error(void)
+{
+    return g_oracle_error.c_str();
+}
+
 #ifndef ORACLE_QUAD
 // InferenceTechnique::SaveResults (inference.cc:112-281), Vb::SaveResults (inference_vb.cc:966-995)
 int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double *mvn, const fvb_postproc *pp)
@@ -1572,33 +1610,6 @@ int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double
     return 0;
 }
 
-// Vb::DoCalculationsSpatial. Returns 0, or < 0 with the exception text in oracle_last_error().
-static std::string g_oracle_error;
-int32_t oracle_vb_run_spatial(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out)
-{
-    if (cfg->abi_version != FVB_ABI_VERSION)
-        return -1;
-    try
-    {
-        if (cfg->noise == FVB_NOISE_WHITE)
-            return run_spatial<SpatialWhite>(cfg, sp, data, out);
-        if (cfg->noise != FVB_NOISE_AR1)
-            return -1;
-        if (cfg->phi_index)
-            for (int t = 0; t < cfg->n_times; t++)
-                if (cfg->phi_index[t] == 255)
-                    return -3; // masked timepoints are rejected for AR noise (noisemodel_ar.cc:351-355)
-        if (cfg->n_phis < 1 || cfg->n_phis > 2 || cfg->ar_cross_terms < 0 || cfg->ar_cross_terms > 2
-            || (cfg->n_phis == 1 && cfg->ar_cross_terms != 0) || cfg->n_times % cfg->n_phis != 0)
-            return -4;
-        return run_spatial<SpatialAr>(cfg, sp, data, out);
-    }
-    catch (std::exception &e)
-    {
-        g_oracle_error = e.what();
-        return -10;
-    }
-}
 int32_t oracle_nlls_run(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
     int32_t v_begin, int32_t v_end, int32_t halt_bad_voxel)
 {
@@ -1607,10 +1618,6 @@ int32_t oracle_nlls_run(const fvb_config *cfg, const fvb_nlls *nl, const void *d
     return run_nlls(cfg, nl, data, out, v_begin, v_end, halt_bad_voxel);
 }
 
-const char *oracle_last_error(void)
-{
-    return g_oracle_error.c_str();
-}
 
 // Neighbour lists as Vb::CalcNeighbours builds them: for voxel v (0-based) up to 6 first
 // neighbours into nn[v*6..] (1-based ids, 0 = none) and the number of second neighbours (with

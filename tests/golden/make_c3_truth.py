@@ -12,6 +12,7 @@ iterations, so the result is exact at fp64 resolution.
 binary128 runs at ~8 voxels/s per core, so the result is committed as a fixture:
     tests/golden/c3_truth_binary128.npz
       mvn [21][V], status [V], iterations [V]   final posterior of the 50-iteration run
+      free_energy [V]                           F of that posterior (noisemodel_white.cc:365-454 + the priors' term)
       its [K], trace_means [K][4][V]            posterior means after its[k] iterations
       data_sha256                               of the float32 series cases.exp_problem generates
 
@@ -41,9 +42,10 @@ def problem(n_voxels, **kw):
 def _block(args):
     n_voxels, v0, v1 = args
     import oracle
-    h, y = problem(n_voxels)
+    # (with the counting detector F does not steer the loop: the posterior is the same with and without it)
+    h, y = problem(n_voxels, need_f=True)
     r = oracle.run_quad(h, y, v_begin=v0, v_end=v1, trace_rows=MAX_ITS)
-    return v0, v1, {k: (r[k][..., v0:v1]) for k in ("mvn", "status", "iterations", "trace_means")}
+    return v0, v1, {k: (r[k][..., v0:v1]) for k in ("mvn", "status", "iterations", "trace_means", "free_energy")}
 
 
 def main():
@@ -59,19 +61,21 @@ def main():
     status = np.full(V, -1, dtype=np.int32)
     iters = np.full(V, -1, dtype=np.int32)
     trace = np.full((len(ITS), 4, V), np.nan)
+    free_energy = np.full(V, np.nan)
     done = 0
     with concurrent.futures.ProcessPoolExecutor(max_workers=a.jobs) as ex:
         for v0, v1, r in ex.map(_block, work):
             mvn[:, v0:v1] = r["mvn"]
             status[v0:v1] = r["status"]
             iters[v0:v1] = r["iterations"]
+            free_energy[v0:v1] = r["free_energy"]
             for k, it in enumerate(ITS):
                 trace[k, :, v0:v1] = r["trace_means"][it - 1]
             done += v1 - v0
             print("\r%d / %d voxels" % (done, V), end="", file=sys.stderr, flush=True)
     print(file=sys.stderr)
     out = os.path.join(HERE, "c3_truth_binary128.npz")
-    np.savez_compressed(out, mvn=mvn, status=status, iterations=iters, its=np.array(ITS), trace_means=trace,
+    np.savez_compressed(out, mvn=mvn, status=status, iterations=iters, its=np.array(ITS), trace_means=trace, free_energy=free_energy,
                         data_sha256=np.array(hashlib.sha256(y.tobytes()).hexdigest()), n_voxels=np.array(V))
     print("wrote", out, os.path.getsize(out), "bytes; failed voxels:", int(np.count_nonzero(status)))
 

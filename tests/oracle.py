@@ -244,6 +244,11 @@ def run_spatial_fma(holder, spatial, data):
     return run_spatial(holder, spatial, data, _lib=lib_fma())
 
 
+def run_spatial_quad(holder, spatial, data):
+    """The spatial loop (white noise) with every internal variable in IEEE binary128"""
+    return run_spatial(holder, spatial, data, _lib=lib_quad())
+
+
 def calc_neighbours(coords, spatial_dims=3):
     """Reference neighbour lists: (nn [V][6], nn2 [V][30], n2count [V]) with 1-based ids."""
     coords = np.ascontiguousarray(coords, dtype=np.int32)

@@ -139,12 +139,19 @@ def population_stats(holder, a, b):
     )
 
 
-def population(holder, cpu, gpu, floor, what="", slack=0.05):
+def population(holder, cpu, gpu, floor, what="", slack=None):
     """gpu-vs-cpu agreement must be as good as cpu-vs-cpu' agreement (floor = population_stats
-    of the two CPU builds), within `slack` (absolute, on shares) / 3 % (on quantiles)."""
+    of the two CPU builds). Both are shares of a finite sample of voxels of a chaotic fit - which voxel lands on
+    which fixed point is a coin that every build tosses anew - so the comparison allows the sampling noise of such
+    a share and nothing else: 3 sigma of a binomial share p over n voxels (round 2: a flat 5 points). Where a
+    binary128 ground truth exists the bar is no_worse_than_the_cpu_builds instead, without any allowance."""
     s = population_stats(holder, cpu, gpu)
-    assert s["frac_within_1e4"] >= floor["frac_within_1e4"] - slack, (what, s, floor)
-    assert s["frac_within_1e6"] >= floor["frac_within_1e6"] - slack, (what, s, floor)
+    n = max(1, int(np.count_nonzero((cpu["status"] == 0) & (gpu["status"] == 0))))
+
+    def allowance(p):
+        return slack if slack is not None else 3.0 * float(np.sqrt(max(p * (1 - p), 1.0 / n) / n))
+    assert s["frac_within_1e4"] >= floor["frac_within_1e4"] - allowance(floor["frac_within_1e4"]), (what, s, floor)
+    assert s["frac_within_1e6"] >= floor["frac_within_1e6"] - allowance(floor["frac_within_1e6"]), (what, s, floor)
     assert s["median_err"] <= max(10 * floor["median_err"], 1e-7), (what, s, floor)
     assert s["bad_b"] <= max(2 * max(floor["bad_a"], floor["bad_b"]), 0.005), (what, s, floor)
     assert np.allclose(s["phi_quantiles_b"], s["phi_quantiles_a"], rtol=0.03), (what, s)
@@ -166,19 +173,64 @@ def load_c3_truth():
     _, y = mt.problem(V)
     assert hashlib.sha256(y.tobytes()).hexdigest() == str(f["data_sha256"]), "the seeded series changed"
     return dict(mvn=f["mvn"], status=f["status"], iterations=f["iterations"], its=[int(i) for i in f["its"]],
-                trace_means=f["trace_means"], n_voxels=V)
+                trace_means=f["trace_means"], n_voxels=V, free_energy=f["free_energy"])
 
 
-def truth_stats(holder, truth, r):
+def truth_stats(holder, truth, r, with_f=False):
     """Distribution of the per-voxel error of result r against the ground truth: the scaled metric of
-    voxel_errors and SURVEY 8d's pure relative one, over the voxels r finished."""
+    voxel_errors and SURVEY 8d's pure relative one, over the voxels r finished. with_f: also the free
+    energy's error |F - F_truth| / max(1, |F_truth|); truth["iterations"] present and r run with an F-driven
+    detector: also the share of voxels that stopped after the truth's number of iterations."""
     ok = (r["status"] == 0) & (truth["status"] == 0)
     e, e_cov, rel = voxel_errors(holder, truth, r, ok)
     q = lambda x, p: float(np.quantile(x, p))
-    return dict(failed=float(np.mean(r["status"] != 0)), within_1e4=float(np.mean(e <= NORTH_STAR)),
-                within_1e6=float(np.mean(e <= 1e-6)), within_1e4_rel=float(np.mean(rel <= NORTH_STAR)),
-                median=q(e, 0.5), p75=q(e, 0.75), p90=q(e, 0.9), p99=q(e, 0.99),
-                median_rel=q(rel, 0.5), p90_rel=q(rel, 0.9), median_cov=q(e_cov, 0.5))
+    out = dict(failed=float(np.mean(r["status"] != 0)), within_1e4=float(np.mean(e <= NORTH_STAR)),
+               within_1e6=float(np.mean(e <= 1e-6)), within_1e4_rel=float(np.mean(rel <= NORTH_STAR)),
+               median=q(e, 0.5), p75=q(e, 0.75), p90=q(e, 0.9), p99=q(e, 0.99),
+               median_rel=q(rel, 0.5), p90_rel=q(rel, 0.9), median_cov=q(e_cov, 0.5))
+    if with_f:
+        Ft, Fr = truth["free_energy"][ok], r["free_energy"][ok]
+        with np.errstate(invalid="ignore"):
+            ef = np.abs(Fr - Ft) / np.maximum(1.0, np.abs(Ft))
+        ef = np.where(np.isnan(ef), np.inf, ef)
+        out.update(f_within_1e6=float(np.mean(ef <= 1e-6)), f_within_1e4=float(np.mean(ef <= 1e-4)), f_median=q(ef, 0.5),
+                   f_p75=q(ef, 0.75), f_p90=q(ef, 0.9))
+        if "iterations" in truth:
+            out["same_iterations"] = float(np.mean(r["iterations"][ok] == truth["iterations"][ok]))
+    return out
+
+
+def no_worse_than_the_cpu_builds(gpu, cpu1, cpu2, what="", with_f=False, median_factor=1.5):
+    """The bar where a binary128 ground truth exists (tests/golden/make_c*_truth.py): the kernels' error against what
+    the ALGORITHM computes must be no worse than that of the worse of two fp64 CPU builds of the oracle - NO slack -
+    in the shares of voxels within 1e-4 / 1e-6 of the truth, in the 75th / 90th / 99th percentile of the error and in
+    the share of failed voxels (and the same for F). One stated exception: the MEDIAN of the final error, ~5e-10 on a
+    converged voxel, may be median_factor x the CPU's (the lane kernels' exponentials carry up to 7 extra roundings
+    between two exact evaluations, vb_models.h: 6e-10 against 5e-10, five orders below the north star)."""
+    shares = ["within_1e4", "within_1e6", "within_1e4_rel"] + (["f_within_1e6", "f_within_1e4"] if with_f else [])
+    tails = ["p75", "p90", "p99", "failed"] + (["f_p75", "f_p90"] if with_f else [])
+    if with_f and "same_iterations" in gpu:
+        shares.append("same_iterations")
+    for k in shares:
+        assert gpu[k] >= min(cpu1[k], cpu2[k]), (what, k, gpu[k], cpu1[k], cpu2[k])
+    for k in tails:
+        assert gpu[k] <= max(cpu1[k], cpu2[k]), (what, k, gpu[k], cpu1[k], cpu2[k])
+    assert gpu["median"] <= median_factor * max(cpu1["median"], cpu2["median"]), (what, gpu["median"], cpu1["median"], cpu2["median"])
+    if with_f:
+        assert gpu["f_median"] <= median_factor * max(cpu1["f_median"], cpu2["f_median"], 1e-12), (what, gpu["f_median"], cpu1["f_median"], cpu2["f_median"])
+
+
+def load_c5_truth():
+    """tests/golden/c5_truth_binary128.npz (make_c5_truth.py): the spatial bi-exponential fit on a 16 x 16 x 12 block"""
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if gdir not in sys.path:
+        sys.path.insert(0, gdir)
+    import make_c5_truth as mt
+    f = np.load(os.path.join(gdir, "c5_truth_binary128.npz"))
+    h, sp, y = mt.problem(need_f=True)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == str(f["data_sha256"]), "the seeded series changed"
+    return dict(mvn=f["mvn"], status=f["status"], free_energy=f["free_energy"]), (h, sp, y)
 
 
 def truth_trace_stats(holder, truth_means, r):

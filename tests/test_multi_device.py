@@ -108,3 +108,35 @@ def test_cached_device_memory_can_be_given_back():
     lib.fabber_vb_release_cached_memory.restype = None
     lib.fabber_vb_release_cached_memory()
     same(first, hiplib.run_host(h, y))
+
+
+@pytest.mark.parametrize("case", ["plain", "detector + image prior + continue"])
+def test_the_host_entry_point_pipelines_over_blocks(case, monkeypatch):
+    """fabber_vb_run_host on a large problem: blocks of voxels go up, are fitted and come down on three streams, the
+    uploads and downloads of neighbouring blocks hidden behind the arithmetic (vb_api.hip, run_host_pipelined). The
+    result is the one-block run's bit for bit - here with small blocks (many of them, a ragged last one) and at the
+    default block size."""
+    V = 50000 + 21
+    if case == "plain":
+        h, y = cases.exp_problem(V, 50, 1, 0.04, seed=3, max_iterations=6)
+    else:
+        rng = np.random.default_rng(6)
+        img = rng.normal(0.5, 0.1, V)
+        h0, y = cases.poly_problem(V, 16, 2, seed=4, max_iterations=3)
+        first = hiplib.run_host(h0, y)
+        h, y = cases.poly_problem(V, 16, 2, seed=4, max_iterations=8, need_f=True, convergence="trialmode", f_history_rows=10,
+                                  param_overrides={"c1": dict(type="I", prec=4.0)}, image_priors={"c1": img}, init_mvn=first["mvn"])
+    monkeypatch.setenv("FVB_HOST_BLOCK_VOXELS", "0")
+    one = hiplib.run_host(h, y)
+    monkeypatch.setenv("FVB_HOST_BLOCK_VOXELS", "4096")
+    piped = hiplib.run_host(h, y)
+    same(one, piped)
+    if "f_history" in one:
+        assert np.array_equal(one["f_history"], piped["f_history"], equal_nan=True)
+    monkeypatch.delenv("FVB_HOST_BLOCK_VOXELS")
+    if case == "plain":
+        hb, yb = cases.exp_problem(2 * 262144 + 4097, 20, 1, 0.1, seed=5, max_iterations=3)
+        monkeypatch.setenv("FVB_HOST_BLOCK_VOXELS", "0")
+        one = hiplib.run_host(hb, yb)
+        monkeypatch.delenv("FVB_HOST_BLOCK_VOXELS")
+        same(one, hiplib.run_host(hb, yb))
