@@ -134,9 +134,12 @@ void fabber_destroy(void *fab)
         FabberSetup::Destroy();
         delete ctx(fab);
         // the engine keeps its device work buffers between runs (a private memory pool per device); when the last
-        // handle of the process goes, so do they
+        // handle of the process goes, all but 4 GiB per device go back to the driver (FVB_POOL_KEEP_BYTES)
         if (--g_live_handles == 0)
-            fabber_vb_release_cached_memory();
+        {
+            const char *keep = getenv("FVB_POOL_KEEP_BYTES");
+            fabber_vb_trim_cached_memory(keep ? strtoull(keep, NULL, 10) : (4ull << 30));
+        }
     }
 }
 

@@ -153,6 +153,15 @@ public:
     virtual void ClearVoxelData(std::string key = "");
     virtual void SetVoxelData(std::string key, const NEWMAT::Matrix &data);
     void SetVoxelCoords(const NEWMAT::Matrix &coords);
+    /**
+     * Voxel data as the C ABI hands it over: float32, [rows][voxels]. It is kept as it is - the engine reads float32
+     * series directly - and becomes a (double) Matrix only if somebody asks for one through GetVoxelData /
+     * LoadVoxelData. (The reference converts every volume to a NEWMAT matrix on arrival, rundata_array.cc:100-133:
+     * for a million voxels x 100 timepoints that is 800 MB of freshly faulted memory before anything is computed.)
+     */
+    void SetVoxelDataF32(std::string key, int rows, std::vector<float> &&values);
+    /** The main series (key "data") as float32 [rows][cols] if that is how it is held, else NULL */
+    const float *GetMainVoxelDataF32(int &rows, int &cols);
 
     void Progress(int voxel, int nVoxels)
     {
@@ -178,6 +187,12 @@ protected:
     void CheckSize(std::string key, const NEWMAT::Matrix &mat);
 
     std::map<std::string, NEWMAT::Matrix> m_voxel_data;
+    struct F32Image
+    {
+        int rows;
+        std::vector<float> values; // [rows][voxels]
+    };
+    std::map<std::string, F32Image> m_voxel_data_f32; // what has not been asked for as a Matrix (yet)
     std::vector<int> m_extent;
     std::vector<float> m_dims;
     ProgressCheck *m_progress;

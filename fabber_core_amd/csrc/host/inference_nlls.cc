@@ -12,6 +12,8 @@
 #include <cstring>
 
 using namespace std;
+
+const void *engine_series(FabberRunData &rundata, bool as_matrix, int32_t &data_f64, int &rows, int &cols); // inference_vb.cc
 using NEWMAT::Matrix;
 
 struct NLLSInferenceTechnique::EngineStorage
@@ -96,11 +98,11 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
     fvb_config &cfg = st.cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.abi_version = FVB_ABI_VERSION;
-    const Matrix &data = rundata.GetMainVoxelData();
     const Matrix &coords = rundata.GetVoxelCoords();
-    cfg.n_voxels = data.Ncols();
-    cfg.n_times = data.Nrows();
-    cfg.data_f64 = 1;
+    int series_rows = 0, series_cols = 0;
+    const void *series = engine_series(rundata, false, cfg.data_f64, series_rows, series_cols);
+    cfg.n_voxels = series_cols;
+    cfg.n_times = series_rows;
     // the post-processing kernel reads these as for a VB result without noise entries
     cfg.noise = FVB_NOISE_WHITE;
     cfg.n_phis = 0;
@@ -167,7 +169,7 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
     out.iterations = iterations.data();
     LOG << "NLLSInferenceTechnique::Calculations on the MI355X engine, " << V << " voxels x " << cfg.n_times << " timepoints, "
         << (m_lm ? "Levenberg-Marquardt" : "Levenberg") << " damping" << endl;
-    const int rc = fabber_nlls_run_host(&cfg, &nl, data.Store(), &out, rundata.GetIntDefault("device", 0, 0));
+    const int rc = fabber_nlls_run_host(&cfg, &nl, series, &out, rundata.GetIntDefault("device", 0, 0));
     if (rc != 0)
         throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
     rundata.Progress(V, V);

@@ -208,15 +208,35 @@ bool Vb::IsSpatial(FabberRunData &rundata) const
     return false;
 }
 
+// The main series as the engine reads it: float32 where the run data holds it so (every volume set through the C
+// ABI, FabberRunData::SetVoxelDataF32), else the double matrix. as_matrix: the caller needs the matrix anyway (a
+// model evaluated on the host is handed NEWMAT columns).
+const void *engine_series(FabberRunData &rundata, bool as_matrix, int32_t &data_f64, int &rows, int &cols)
+{
+    const float *f32 = as_matrix ? NULL : rundata.GetMainVoxelDataF32(rows, cols);
+    if (f32)
+    {
+        data_f64 = 0;
+        return f32;
+    }
+    const Matrix &data = rundata.GetMainVoxelData();
+    rows = data.Nrows();
+    cols = data.Ncols();
+    data_f64 = 1; // (rows = timepoints, columns = voxels)
+    return data.Store();
+}
+
 void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
 {
     EngineStorage &st = *m_store;
     memset(&cfg, 0, sizeof(cfg));
     cfg.abi_version = FVB_ABI_VERSION;
-    const Matrix &data = rundata.GetMainVoxelData();
-    cfg.n_voxels = data.Ncols();
-    cfg.n_times = data.Nrows();
-    cfg.data_f64 = 1; // the run data holds doubles (rows = timepoints, columns = voxels)
+    {
+        int rows = 0, cols = 0;
+        (void)engine_series(rundata, false, cfg.data_f64, rows, cols);
+        cfg.n_voxels = cols;
+        cfg.n_times = rows;
+    }
 
     // ---- model ----
     st.params.clear();
@@ -526,7 +546,9 @@ void Vb::DoCalculations(FabberRunData &rundata)
         return;
     }
 
-    const Matrix &data = rundata.GetMainVoxelData();
+    // (a model evaluated on the host takes its data as NEWMAT columns: the matrix then, for the engine too)
+    int series_rows = 0, series_cols = 0;
+    const void *series = engine_series(rundata, !m_store->has_device_model, cfg.data_f64, series_rows, series_cols);
     vector<int> iterations(m_nvoxels, 0), hist_len(m_nvoxels, 0);
     m_free_energy.assign(m_nvoxels, 9999);
     if (cfg.f_history_rows > 0)
@@ -567,7 +589,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
     int rc;
     // a model evaluated on the host: one model instance per host thread (host-model-threads, default: the
     // hardware's, at most 16)
-    HostModelContext ctx = { this, m_model, &rundata, &data, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
+    HostModelContext ctx = { this, m_model, &rundata, NULL, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
     std::vector<std::unique_ptr<FwdModel> > copies;
     auto prepare_host_model = [&]() {
         int nthreads = rundata.GetIntDefault("host-model-threads", 0, 0, 256);
@@ -584,6 +606,8 @@ void Vb::DoCalculations(FabberRunData &rundata)
             ctx.models.push_back(copies.back().get());
         }
         LOG << "Vb::Model evaluations on " << nthreads << " host thread(s)" << endl;
+        ctx.data = &rundata.GetMainVoxelData();
+        series = engine_series(rundata, true, cfg.data_f64, series_rows, series_cols);
     };
     if (m_locked_linear)
     {
@@ -660,11 +684,11 @@ void Vb::DoCalculations(FabberRunData &rundata)
         {
             // devices=all | devices=0,1,...: z-slabs of the volume on several GPUs, pipelined first sweep
             LOG << "Vb::devices=" << devices_opt << ": the volume is cut into z-slabs" << endl;
-            rc = fabber_vb_run_spatial_host_multi(&cfg, &sp, data.Store(), &out, device_list.empty() ? NULL : device_list.data(),
+            rc = fabber_vb_run_spatial_host_multi(&cfg, &sp, series, &out, device_list.empty() ? NULL : device_list.data(),
                 (int32_t)device_list.size(), spatial_progress);
         }
         else if (m_store->has_device_model)
-            rc = fabber_vb_run_spatial_host(&cfg, &sp, data.Store(), &out, device, spatial_progress);
+            rc = fabber_vb_run_spatial_host(&cfg, &sp, series, &out, device, spatial_progress);
         if (m_store->has_device_model && rc == -40)
         {
             // no spatial kernels were built for this model with this many parameters: the model's own host code
@@ -681,7 +705,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
             LOG << "Vb::the model is evaluated on the host" << endl;
             BuildInitialMvn(rundata, cfg);
             prepare_host_model();
-            rc = fabber_vb_run_spatial_hostmodel_host(&cfg, &sp, data.Store(), &out, device, &Vb::LineariseCallback, &ctx, spatial_progress);
+            rc = fabber_vb_run_spatial_hostmodel_host(&cfg, &sp, series, &out, device, &Vb::LineariseCallback, &ctx, spatial_progress);
             if (rc == -54 && ctx.error != "")
             {
                 s_progress_rundata = NULL;
@@ -696,7 +720,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
             << " voxels x " << cfg.n_times << " timepoints" << endl;
         BuildInitialMvn(rundata, cfg);
         prepare_host_model();
-        rc = fabber_vb_run_hostmodel_host(&cfg, data.Store(), &out, device, &Vb::LineariseCallback, &ctx);
+        rc = fabber_vb_run_hostmodel_host(&cfg, series, &out, device, &Vb::LineariseCallback, &ctx);
         if (rc == -54 && ctx.error != "")
             throw FabberInternalError(ctx.error);
     }
@@ -707,7 +731,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
         if (devices_opt != "")
         {
             fvb_summary total;
-            rc = fabber_vb_run_host_multi(&cfg, data.Store(), &out, device_list.empty() ? NULL : device_list.data(),
+            rc = fabber_vb_run_host_multi(&cfg, series, &out, device_list.empty() ? NULL : device_list.data(),
                 (int32_t)device_list.size(), &total);
             if (rc == 0)
                 LOG << "Vb::devices=" << devices_opt << ": " << total.sum_iterations << " voxel-iterations, " << total.bad_voxels
@@ -715,7 +739,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
                     << (m_needF ? stringify(total.sum_free_energy) : string("")) << endl;
         }
         else
-            rc = fabber_vb_run_host(&cfg, data.Store(), &out, device);
+            rc = fabber_vb_run_host(&cfg, series, &out, device);
     }
     if (rc != 0)
         throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
@@ -808,14 +832,17 @@ void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_con
 
     if (V > 0)
     {
-        const Matrix &data = rundata.GetMainVoxelData();
         if (host_model) // the model prediction can only come from the model's own host code
             pp.modelfit = pp.residuals = NULL;
-        int rc = fabber_vb_postproc_host(&cfg, data.Store(), m_result_image.Store(), &pp, rundata.GetIntDefault("device", 0, 0));
+        fvb_config pcfg = cfg;
+        int series_rows = 0, series_cols = 0;
+        const void *series = engine_series(rundata, host_model, pcfg.data_f64, series_rows, series_cols);
+        int rc = fabber_vb_postproc_host(&pcfg, series, m_result_image.Store(), &pp, rundata.GetIntDefault("device", 0, 0));
         if (rc != 0)
             throw FabberInternalError(string("MI355X engine failed in post-processing: ") + fabber_vb_last_error());
         if (host_model && (want_fit || want_resid)) // inference.cc:181-243
         {
+            const Matrix &data = rundata.GetMainVoxelData();
             const Matrix &coords = rundata.GetVoxelCoords();
             const Matrix &supp = rundata.GetVoxelSuppData();
             const int nCov = (P + N) * (P + N + 1) / 2;

@@ -10,6 +10,7 @@
 #include "fwdmodel.h"
 #include "inference.h"
 #include "setup.h"
+#include "tools.h"
 #include "version.h"
 
 #include <errno.h>
@@ -555,8 +556,53 @@ const Matrix &FabberRunData::LoadVoxelData(const std::string &key)
 {
     map<string, Matrix>::iterator it = m_voxel_data.find(key);
     if (it == m_voxel_data.end())
-        throw DataNotFound(key);
+    {
+        // held as float32 (SetVoxelDataF32): somebody wants the matrix now
+        map<string, F32Image>::iterator f = m_voxel_data_f32.find(key);
+        if (f == m_voxel_data_f32.end())
+            throw DataNotFound(key);
+        const int rows = f->second.rows;
+        const size_t cols = rows > 0 ? f->second.values.size() / (size_t)rows : 0;
+        Matrix &m = m_voxel_data[key];
+        m.ReSize(rows, (int)cols);
+        const float *src = f->second.values.data();
+        double *dst = m.Store();
+        fabber_parallel_for(rows, [&](int r) {
+            const float *s = src + (size_t)r * cols;
+            double *d = dst + (size_t)r * cols;
+            for (size_t i = 0; i < cols; i++)
+                d[i] = s[i];
+        });
+        return m;
+    }
     return it->second;
+}
+
+void FabberRunData::SetVoxelDataF32(string key, int rows, std::vector<float> &&values)
+{
+    const size_t cols = rows > 0 ? values.size() / (size_t)rows : 0;
+    map<string, Matrix>::iterator coords = m_voxel_data.find("coords");
+    if (coords != m_voxel_data.end() && key != "coords" && (int)cols != coords->second.Ncols())
+        throw InvalidOptionValue(key, stringify(cols) + " voxels",
+            "Number of voxels does not match the co-ordinates (" + stringify(coords->second.Ncols()) + ")");
+    m_voxel_data.erase(key);
+    F32Image &img = m_voxel_data_f32[key];
+    img.rows = rows;
+    img.values = std::move(values);
+}
+
+const float *FabberRunData::GetMainVoxelDataF32(int &rows, int &cols)
+{
+    // (the key "data" itself, not a reference to another key, and no matrix of that name: GetMainVoxelData would
+    // find the same series)
+    if (GetStringDefault("data", "") != "" || m_voxel_data.find("data") != m_voxel_data.end())
+        return NULL;
+    map<string, F32Image>::iterator f = m_voxel_data_f32.find("data");
+    if (f == m_voxel_data_f32.end() || f->second.rows <= 0)
+        return NULL;
+    rows = f->second.rows;
+    cols = (int)(f->second.values.size() / (size_t)rows);
+    return f->second.values.data();
 }
 
 const Matrix &FabberRunData::GetMainVoxelDataMultiple()
@@ -615,9 +661,15 @@ const Matrix &FabberRunData::GetMainVoxelDataMultiple()
 void FabberRunData::ClearVoxelData(string key)
 {
     if (key != "")
+    {
         m_voxel_data.erase(key);
+        m_voxel_data_f32.erase(key);
+    }
     else
+    {
         m_voxel_data.clear();
+        m_voxel_data_f32.clear();
+    }
 }
 
 void FabberRunData::CheckSize(std::string key, const Matrix &mat)
@@ -632,6 +684,7 @@ void FabberRunData::CheckSize(std::string key, const Matrix &mat)
 void FabberRunData::SetVoxelData(string key, const Matrix &data)
 {
     CheckSize(key, data);
+    m_voxel_data_f32.erase(key);
     m_voxel_data[key] = data;
 }
 

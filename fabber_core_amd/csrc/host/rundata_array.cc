@@ -4,6 +4,10 @@
 // that scan (reference: rundata_array.cc:23-133).
 #include "rundata_array.h"
 
+#include "tools.h"
+
+#include <string.h>
+
 using NEWMAT::Matrix;
 
 void FabberRunDataArray::SetExtent(int nx, int ny, int nz, const int *mask)
@@ -31,18 +35,37 @@ void FabberRunDataArray::SetExtent(int nx, int ny, int nz, const int *mask)
     SetVoxelCoords(coords);
 }
 
+// Both directions are passes over whole volumes (rows x nx ny nz elements): rows are independent, so they are
+// shared out over host threads, and a mask that keeps every voxel - the usual case when the caller has masked
+// already - is a plain conversion loop without the gather / scatter.
 void FabberRunDataArray::GetVoxelDataArray(std::string key, float *out)
 {
     const Matrix &m = FabberRunData::GetVoxelData(key);
     const size_t nv = m_mask.size();
     const int rows = m.Nrows();
-    for (int r = 0; r < rows; r++)
-    {
+    const size_t cols = (size_t)m.Ncols();
+    const bool dense = cols == nv;
+    const double *src = m.Store();
+    const int *mask = m_mask.data();
+    // (large rows are cut into pieces too: one-row images - every mean_ / std_ image - would be one thread's otherwise)
+    const int pieces = (nv >= (1u << 18)) ? 8 : 1;
+    fabber_parallel_for(rows * pieces, [=](int job) {
+        const int r = job / pieces, piece = job % pieces;
+        const size_t i0 = nv * piece / pieces, i1 = nv * (piece + 1) / pieces;
         float *dst = out + (size_t)r * nv;
-        int v = 0;
-        for (size_t i = 0; i < nv; i++)
-            dst[i] = (m_mask[i] != 0) ? (float)m.at0(r, v++) : 0.0f;
-    }
+        const double *row = src + (size_t)r * cols;
+        if (dense)
+        {
+            for (size_t i = i0; i < i1; i++)
+                dst[i] = (float)row[i];
+            return;
+        }
+        size_t v = 0;
+        for (size_t i = 0; i < i0; i++)
+            v += (mask[i] != 0);
+        for (size_t i = i0; i < i1; i++)
+            dst[i] = (mask[i] != 0) ? (float)row[v++] : 0.0f;
+    });
 }
 
 void FabberRunDataArray::SetVoxelDataArray(std::string key, int data_size, const float *in)
@@ -51,14 +74,24 @@ void FabberRunDataArray::SetVoxelDataArray(std::string key, int data_size, const
     size_t n_in = 0;
     for (size_t i = 0; i < nv; i++)
         n_in += (m_mask[i] != 0);
-    Matrix m(data_size, (int)n_in);
-    for (int r = 0; r < data_size; r++)
-    {
+    // kept as float32 [rows][masked voxels] (FabberRunData::SetVoxelDataF32): what the engine reads, and a Matrix
+    // only when something asks for one
+    std::vector<float> values((size_t)std::max(data_size, 0) * n_in);
+    float *dst0 = values.data();
+    const int *mask = m_mask.data();
+    const bool dense = n_in == nv;
+    fabber_parallel_for(data_size, [=](int r) {
         const float *src = in + (size_t)r * nv;
-        int v = 0;
+        float *dst = dst0 + (size_t)r * n_in;
+        if (dense)
+        {
+            memcpy(dst, src, sizeof(float) * nv);
+            return;
+        }
+        size_t v = 0;
         for (size_t i = 0; i < nv; i++)
-            if (m_mask[i] != 0)
-                m.at0(r, v++) = src[i];
-    }
-    FabberRunData::SetVoxelData(key, m);
+            if (mask[i] != 0)
+                dst[v++] = src[i];
+    });
+    FabberRunData::SetVoxelDataF32(key, data_size, std::move(values));
 }

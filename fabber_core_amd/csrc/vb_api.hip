@@ -290,6 +290,10 @@ int api_residual_mode()
 {
     return g_residual_mode;
 }
+int api_precise_passes()
+{
+    return g_precise_passes >= 0 ? g_precise_passes : 2; // (see run_device_as)
+}
 double api_residual_tol()
 {
     return g_residual_tol;
@@ -348,7 +352,8 @@ void api_keep_pool_memory()
 {
     (void)api_pool();
 }
-void api_release_pools()
+// keep_bytes: what every pool may keep for the next run (0 = give everything back)
+void api_release_pools(uint64_t keep_bytes)
 {
     PoolTable &t = pool_table();
     std::lock_guard<std::mutex> hold(t.lock);
@@ -361,7 +366,7 @@ void api_release_pools()
         (void)hipDeviceSynchronize();
         hipMemPool_t pool = e.second;
         if (pool || hipDeviceGetDefaultMemPool(&pool, e.first) == hipSuccess)
-            (void)hipMemPoolTrimTo(pool, 0);
+            (void)hipMemPoolTrimTo(pool, (size_t)keep_bytes);
     }
     (void)hipSetDevice(before);
 }
@@ -394,7 +399,12 @@ const char *fabber_vb_last_error(void)
 
 void fabber_vb_release_cached_memory(void)
 {
-    fvb::api_release_pools();
+    fvb::api_release_pools(0);
+}
+
+void fabber_vb_trim_cached_memory(uint64_t keep_bytes)
+{
+    fvb::api_release_pools(keep_bytes);
 }
 
 void fabber_vb_set_variant(int32_t variant)
@@ -696,9 +706,12 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     const int V = cfg->n_voxels;
     const int n_blocks = (V + block_voxels - 1) / block_voxels;
     const int n_unmasked = count_unmasked(cfg, cfg->phi_index);
-    hipStream_t s_up = nullptr, s_fit = nullptr, s_down = nullptr;
+    // (two streams take the blocks' kernels in turn: the first wavefronts of block b + 1 move into the SIMDs the last
+    // stragglers of block b have left, instead of every block paying for its own tail)
+    hipStream_t s_up = nullptr, s_fit[2] = { nullptr, nullptr }, s_down = nullptr;
     FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit, hipStreamNonBlocking));
+    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit[0], hipStreamNonBlocking));
+    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit[1], hipStreamNonBlocking));
     FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
     std::vector<std::unique_ptr<HostBlock> > blocks((size_t)n_blocks);
     std::mutex lock;
@@ -744,7 +757,7 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
         blk->kernel_voxels = V;
         rc = blk->stage_in(s_up);
         if (rc == 0)
-            rc = blk->fit(s_fit, n_unmasked);
+            rc = blk->fit(s_fit[b & 1], n_unmasked);
         std::unique_lock<std::mutex> hold(lock);
         if (rc == 0)
         {
@@ -760,11 +773,13 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     }
     downloader.join();
     (void)hipStreamSynchronize(s_up);
-    (void)hipStreamSynchronize(s_fit);
+    (void)hipStreamSynchronize(s_fit[0]);
+    (void)hipStreamSynchronize(s_fit[1]);
     (void)hipStreamSynchronize(s_down);
     blocks.clear();
     (void)hipStreamDestroy(s_up);
-    (void)hipStreamDestroy(s_fit);
+    (void)hipStreamDestroy(s_fit[0]);
+    (void)hipStreamDestroy(s_fit[1]);
     (void)hipStreamDestroy(s_down);
     if (rc)
         return rc;

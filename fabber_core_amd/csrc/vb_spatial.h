@@ -135,7 +135,10 @@ __device__ __forceinline__ void sp_load(const SpatialArgs &sa, int v, VoxelState
     st.b = p[(size_t)L::B * V];
     st.c = p[(size_t)L::C * V];
     mo.s = p[(size_t)L::S * V];
-    mo.precise = false;
+    // how the linearisation these moments belong to evaluated the model: the set-up re-centre is linearisation 0, the
+    // one that ends iteration it - 1 is linearisation it; the first ka.precise_passes of a run are pointwise (see
+    // sp_precise below)
+    mo.precise = sa.it < sa.ka.precise_passes;
     st.covValid = true;
     st.precValid = false;
 }
@@ -182,6 +185,15 @@ __device__ __forceinline__ void sp_store_noise(const SpatialArgs &sa, int v, con
 __device__ __forceinline__ bool is_spatial_type(int t)
 {
     return t >= FVB_PRIOR_SPATIAL_M;
+}
+
+// The re-centre that ends iteration sa.it is the run's linearisation number sa.it + 1 (the set-up's is number 0). Like
+// the voxelwise kernels, the first ka.precise_passes = 2 linearisations of a run evaluate the model pointwise
+// (vb_lane_kernel.h, recentre): round 2 did so for the set-up only, and against the binary128 ground truth of a
+// spatial block (tests/golden/c5_truth_binary128.npz) the error after 10 iterations was twice a CPU build's.
+__device__ __forceinline__ bool sp_precise(const SpatialArgs &sa)
+{
+    return sa.it + 1 < sa.ka.precise_passes;
 }
 
 // The noise model seen from the FIRST sweep (inference_vb.cc:643-651). UpdateTheta needs J'XJ and J'X(y - g) only, and
@@ -1401,7 +1413,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
     int status = FVB_OK;
     if (!sa.locked_linear) // inference_vb.cc:695-696
     {
-        status = recentre<Model, P>(ka, ma, v, st.m, mo);
+        status = recentre<Model, P>(ka, ma, v, st.m, mo, sp_precise(sa));
         kk = mo.s; // the centre is the mean now: k = y - g
         trSA = trace_SA<P>(st, mo);
     }

@@ -28,6 +28,7 @@ namespace fvb
 int api_fail(int code, const std::string &msg); // vb_api.hip
 int api_validate(const fvb_config *cfg, bool allow_spatial);
 int api_residual_mode();
+int api_precise_passes();
 double api_residual_tol();
 void api_keep_pool_memory();
 hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream);
@@ -511,6 +512,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         early.ka.n_unmasked = n_unmasked;
         early.ka.residual_mode = api_residual_mode();
         early.ka.residual_tol = api_residual_tol();
+        early.ka.precise_passes = api_precise_passes();
         early.state = (double *)d_state.p;
         early.status = (int32_t *)d_status.p;
         early.owned_begin = owned_begin;
@@ -848,6 +850,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     sa.ka.save = nullptr;
     sa.ka.residual_mode = api_residual_mode();
     sa.ka.residual_tol = api_residual_tol();
+    sa.ka.precise_passes = api_precise_passes();
     sa.state = (double *)d_state.p;
     sa.nn = (const int32_t *)d_nn.p;
     sa.order = (const int32_t *)d_order.p;

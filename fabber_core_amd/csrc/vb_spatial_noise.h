@@ -73,7 +73,7 @@ struct SpPattern
 #pragma unroll
         for (int i = 0; i < P; i++)
             f.mo.ml[i] = p[(size_t)(L::ML + i) * V];
-        f.mo.precise = false;
+        f.mo.precise = sa.it < sa.ka.precise_passes; // (as sp_load)
     }
     static __device__ __forceinline__ void store_full(const SpatialArgs &sa, int v, const Full &f)
     {
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64, NZ::WAVES) void vb_spatial_noise_nz_kernel(cons
     if (Model::host_evaluated) // ... and the re-centre about the means of this iteration's first sweep
         ma.lin = sa.lin_next + (size_t)v * ka.cfg.n_times * (P + 1);
     if (status == FVB_OK && !sa.locked_linear) // inference_vb.cc:695-696
-        status = NZ::template recentre<Model>(sa, ma, v, st.m, full, false, classes);
+        status = NZ::template recentre<Model>(sa, ma, v, st.m, full, sp_precise(sa), classes);
     if (status == FVB_OK && NEEDF)
     {
         // only the last of the reference's four F evaluations per iteration is observable; it uses the prior

@@ -412,6 +412,10 @@ int32_t fabber_nlls_run_host(const fvb_config *cfg, const fvb_nlls *nl, const vo
  * once). This returns what the pool holds to the driver; the reference has no counterpart (host memory, freed by
  * the run). */
 void fabber_vb_release_cached_memory(void);
+/* The same, keeping up to keep_bytes per device for the next run (the C ABI's fabber_destroy does so with 4 GiB when
+ * the last handle of the process goes: a client that runs volume after volume pays for its allocations once, and one
+ * that is finished holds a bounded amount). */
+void fabber_vb_trim_cached_memory(uint64_t keep_bytes);
 
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);

@@ -189,12 +189,21 @@ def truth_stats(holder, truth, r, with_f=False):
                median=q(e, 0.5), p75=q(e, 0.75), p90=q(e, 0.9), p99=q(e, 0.99),
                median_rel=q(rel, 0.5), p90_rel=q(rel, 0.9), median_cov=q(e_cov, 0.5))
     if with_f:
+        # The free energy of a voxel that ended on another fixed point than the truth's is another number altogether, and
+        # which voxels do is the coin every build tosses anew (the shares above). What an implementation OWES is F where
+        # its posterior is the truth's: the error of F over the voxels whose posterior is within 1e-4 of the truth.
         Ft, Fr = truth["free_energy"][ok], r["free_energy"][ok]
         with np.errstate(invalid="ignore"):
             ef = np.abs(Fr - Ft) / np.maximum(1.0, np.abs(Ft))
         ef = np.where(np.isnan(ef), np.inf, ef)
-        out.update(f_within_1e6=float(np.mean(ef <= 1e-6)), f_within_1e4=float(np.mean(ef <= 1e-4)), f_median=q(ef, 0.5),
-                   f_p75=q(ef, 0.75), f_p90=q(ef, 0.9))
+        there = e <= NORTH_STAR
+        out["f_all_within_1e4"] = float(np.mean(ef <= 1e-4))  # (reported, not compared: it follows the coin)
+        if there.any():
+            efc = ef[there]
+            out.update(f_within_1e6=float(np.mean(efc <= 1e-6)), f_within_1e8=float(np.mean(efc <= 1e-8)), f_median=q(efc, 0.5),
+                       f_p75=q(efc, 0.75), f_p90=q(efc, 0.9), f_p99=q(efc, 0.99))
+        else:
+            out.update(f_within_1e6=1.0, f_within_1e8=1.0, f_median=0.0, f_p75=0.0, f_p90=0.0, f_p99=0.0)
         if "iterations" in truth:
             out["same_iterations"] = float(np.mean(r["iterations"][ok] == truth["iterations"][ok]))
     return out
@@ -207,8 +216,8 @@ def no_worse_than_the_cpu_builds(gpu, cpu1, cpu2, what="", with_f=False, median_
     the share of failed voxels (and the same for F). One stated exception: the MEDIAN of the final error, ~5e-10 on a
     converged voxel, may be median_factor x the CPU's (the lane kernels' exponentials carry up to 7 extra roundings
     between two exact evaluations, vb_models.h: 6e-10 against 5e-10, five orders below the north star)."""
-    shares = ["within_1e4", "within_1e6", "within_1e4_rel"] + (["f_within_1e6", "f_within_1e4"] if with_f else [])
-    tails = ["p75", "p90", "p99", "failed"] + (["f_p75", "f_p90"] if with_f else [])
+    shares = ["within_1e4", "within_1e6", "within_1e4_rel"] + (["f_within_1e6", "f_within_1e8"] if with_f else [])
+    tails = ["p75", "p90", "p99", "failed"]
     if with_f and "same_iterations" in gpu:
         shares.append("same_iterations")
     for k in shares:
@@ -217,7 +226,14 @@ def no_worse_than_the_cpu_builds(gpu, cpu1, cpu2, what="", with_f=False, median_
         assert gpu[k] <= max(cpu1[k], cpu2[k]), (what, k, gpu[k], cpu1[k], cpu2[k])
     assert gpu["median"] <= median_factor * max(cpu1["median"], cpu2["median"]), (what, gpu["median"], cpu1["median"], cpu2["median"])
     if with_f:
-        assert gpu["f_median"] <= median_factor * max(cpu1["f_median"], cpu2["f_median"], 1e-12), (what, gpu["f_median"], cpu1["f_median"], cpu2["f_median"])
+        # F where the posterior is the truth's (truth_stats). Its percentiles sit at the rounding level of a sum of
+        # ~20 terms of size 1e2 (1e-12 relative: the kernels add the terms in another order and keep some of them
+        # between evaluations): the same factor as the median above while the CPU's value is below 1e-9,
+        # none above it.
+        for k in ("f_median", "f_p75", "f_p90", "f_p99"):
+            worst = max(cpu1[k], cpu2[k])
+            allowed = max(median_factor * worst, 2e-12) if worst < 1e-9 else worst
+            assert gpu[k] <= allowed, (what, k, gpu[k], cpu1[k], cpu2[k])
 
 
 def load_c5_truth():
