@@ -69,26 +69,36 @@ def _compile_one(args):
     return obj, True, p.stderr
 
 
-def build_hip(force=False, jobs=None, verbose=True, extra_flags=(), variant=None):
+def build_hip(force=False, jobs=None, verbose=True, extra_flags=(), variant=None, only=None):
     """variant: build an experiment copy of the engine - objects under build/obj_<variant>, library
-    lib/libfabber_vb_hip_<variant>.so (load it with FVB_LIB_PATH=...) - next to the product library."""
+    lib/libfabber_vb_hip_<variant>.so (load it with FVB_LIB_PATH=...) - next to the product library.
+    only: with a variant, the sources the extra flags apply to; the other objects are the product's."""
     global OBJDIR
     objdir_product = OBJDIR
     if variant:
         OBJDIR = os.path.join(HERE, "build", "obj_" + variant)
     try:
-        return _build_hip(force, jobs, verbose, extra_flags, variant)
+        return _build_hip(force, jobs, verbose, extra_flags, variant, only, objdir_product)
     finally:
         OBJDIR = objdir_product
 
 
-def _build_hip(force, jobs, verbose, extra_flags, variant):
+def _build_hip(force, jobs, verbose, extra_flags, variant, only=None, objdir_product=None):
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     flags = HIP_FLAGS + list(extra_flags) + os.environ.get("FVB_EXTRA_HIPCC_FLAGS", "").split()
-    work = [(os.path.join(CSRC, s), flags, force) for s in HIP_SOURCES]
+    sources = [s for s in HIP_SOURCES if not (variant and only) or s in only]
+    work = [(os.path.join(CSRC, s), flags, force) for s in sources]
     jobs = jobs or min(len(work), os.cpu_count() or 4)
     objs, rebuilt = [], False
+    if variant and only:
+        for s in HIP_SOURCES:
+            if s not in only:
+                obj = os.path.join(objdir_product, s + ".o")
+                if not os.path.exists(obj):
+                    raise RuntimeError("build the product library first: %s is missing" % obj)
+                objs.append(obj)
+        rebuilt = True
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
         for obj, did, warn in ex.map(_compile_one, work):
             objs.append(obj)
@@ -195,10 +205,12 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--variant", default=None, help="experiment copy of the HIP engine only (with --flags)")
-    ap.add_argument("--flags", default="", help="extra hipcc flags for --variant, e.g. '-DFVB_NO_RESCUE'")
+    ap.add_argument("--flags", default="", help="extra hipcc flags for --variant, e.g. --flags=-DFVB_NO_RESCUE")
+    ap.add_argument("--only", default="", help="with --variant: comma-separated sources the flags apply to (the rest: the product's objects)")
     a = ap.parse_args()
     if a.variant:
-        print(build_hip(force=a.force, jobs=a.jobs, extra_flags=a.flags.split(), variant=a.variant))
+        print(build_hip(force=a.force, jobs=a.jobs, extra_flags=a.flags.split(), variant=a.variant,
+                        only=[x for x in a.only.split(",") if x] or None))
         sys.exit(0)
     for l in build_all(force=a.force, jobs=a.jobs):
         print(l)

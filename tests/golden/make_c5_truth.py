@@ -12,6 +12,7 @@ iteration).
 
     tests/golden/c5_truth_binary128.npz
       mvn [21][V], status [V], free_energy [V], data_sha256 (of the float32 series), shape
+      its [K], trace_means [K][4][V]   posterior means after its[k] = 1, 2, 3, 5 iterations (runs of their own)
 
     python tests/golden/make_c5_truth.py
 """
@@ -26,6 +27,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 SHAPE = (16, 16, 12)
+ITS = [1, 2, 3, 5]
 
 
 def problem(**kw):
@@ -39,8 +41,16 @@ def main():
     import oracle
     h, sp, y = problem(need_f=True)
     r = oracle.run_spatial_quad(h, sp, y)
+    n = h.cfg.n_params + 1
+    off = n * (n + 1) // 2
+    trace = []
+    for it in ITS:
+        hk, _, _ = problem(max_iterations=it)
+        trace.append(oracle.run_spatial_quad(hk, sp, y)["mvn"][off:off + h.cfg.n_params])
+        print("after", it, "iterations", file=sys.stderr)
     out = os.path.join(HERE, "c5_truth_binary128.npz")
     np.savez_compressed(out, mvn=r["mvn"], status=r["status"], free_energy=r["free_energy"], shape=np.array(SHAPE),
+                        its=np.array(ITS), trace_means=np.array(trace),
                         data_sha256=np.array(hashlib.sha256(y.tobytes()).hexdigest()))
     print("wrote", out, os.path.getsize(out), "bytes; failed voxels:", int(np.count_nonzero(r["status"])))
 

@@ -102,7 +102,7 @@ def logfile(cwd, name="out.tmp"):
 def test_cl_poly_model_without_a_mask_and_output_properties(tmp_path):
     """PolyModelNoMask (:250-262) and OutputCopiesPropsNoMask (:236-247): the output images carry the input's voxel
     sizes; the fit equals the same volume through the C API"""
-    r = run_cli(*BASE, "--degree=2", "--save-mean", cwd=tmp_path)
+    r = run_cli(*BASE, "--degree=2", cwd=tmp_path)  # (the tool saves the means by default, rundata.cc:221-231)
     assert r.returncode == 0, r.stderr
     log = logfile(tmp_path)
     for s in ("model=poly", "method=vb", "noise=white", "test_data_small.nii.gz"):
@@ -143,7 +143,7 @@ def test_cl_mask_from_the_reference_file(tmp_path):
     mask = np.zeros((3, 3, 2), dtype=np.int16)
     mask[1:, :2, :] = 1
     nu.write(str(tmp_path / "m.nii.gz"), mask)
-    r = run_cli(*BASE, "--degree=2", "--save-mean", "--overwrite", "--mask=" + str(tmp_path / "m.nii.gz"), cwd=tmp_path)
+    r = run_cli(*BASE, "--degree=2", "--overwrite", "--mask=" + str(tmp_path / "m.nii.gz"), cwd=tmp_path)
     assert r.returncode == 0, r.stderr
     mean, _ = nu.read(str(tmp_path / "out.tmp" / "mean_c0.nii.gz"))
     assert np.all(mean[..., 0][mask == 0] == 0) and np.all(mean[..., 0][mask != 0] != 0)

@@ -186,7 +186,9 @@ def test_failing_voxels_under_other_noise_models(typ, noise):
     for need_f in (True, False):
         h = vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=6, need_f=need_f,
                                param_overrides={"amp1": dict(type=typ)}, **NOISES[noise])
-        _, got = spatial_check(h, vbabi.SpatialHolder(coords), y, "IgnoreVoxel %s %s F=%d" % (typ, noise, need_f), check_f=need_f)
+        # (two CPU builds are up to 6e-7 apart here: the bound follows 3 x that floor)
+        _, got = spatial_check(h, vbabi.SpatialHolder(coords), y, "IgnoreVoxel %s %s F=%d" % (typ, noise, need_f), check_f=need_f,
+                               allow_floor=True)
         if need_f:
             assert sorted(np.flatnonzero(got["status"]).tolist()) == sorted(bad)
 
