@@ -108,6 +108,9 @@ private:
     void (*m_cb)(int, int);
 };
 
+/** float32 voxel data as the C ABI hands it over, sized without being written (see NEWMAT::DefaultInitAllocator) */
+typedef std::vector<float, NEWMAT::DefaultInitAllocator<float> > FabberF32Values;
+
 class FabberRunData : public Loggable
 {
 public:
@@ -142,6 +145,12 @@ public:
 
     // ---- voxel data ----
     virtual void SaveVoxelData(const std::string &filename, NEWMAT::Matrix &data, VoxelDataType data_type = VDT_SCALAR);
+    /** SaveVoxelData for a matrix the caller is done with: run data that keeps its results in memory may take the
+     * storage instead of copying it (`data` is left in an unspecified state). Default: SaveVoxelData. */
+    virtual void SaveVoxelDataMove(const std::string &filename, NEWMAT::Matrix &data, VoxelDataType data_type = VDT_SCALAR)
+    {
+        SaveVoxelData(filename, data, data_type);
+    }
     const NEWMAT::Matrix &GetVoxelCoords();
     const NEWMAT::Matrix &GetVoxelData(const std::string &key);
     virtual const NEWMAT::Matrix &LoadVoxelData(const std::string &key);
@@ -159,7 +168,7 @@ public:
      * LoadVoxelData. (The reference converts every volume to a NEWMAT matrix on arrival, rundata_array.cc:100-133:
      * for a million voxels x 100 timepoints that is 800 MB of freshly faulted memory before anything is computed.)
      */
-    void SetVoxelDataF32(std::string key, int rows, std::vector<float> &&values);
+    void SetVoxelDataF32(std::string key, int rows, FabberF32Values &&values);
     /** The main series (key "data") as float32 [rows][cols] if that is how it is held, else NULL */
     const float *GetMainVoxelDataF32(int &rows, int &cols);
 
@@ -190,7 +199,7 @@ protected:
     struct F32Image
     {
         int rows;
-        std::vector<float> values; // [rows][voxels]
+        FabberF32Values values; // [rows][voxels]
     };
     std::map<std::string, F32Image> m_voxel_data_f32; // what has not been asked for as a Matrix (yet)
     std::vector<int> m_extent;

@@ -20,6 +20,8 @@ public:
     void GetVoxelDataArray(std::string key, float *data);
     /** gather a nx*ny*nz*data_size float volume through the mask */
     void SetVoxelDataArray(std::string key, int data_size, const float *data);
+    /** results stay in memory here: the matrix is taken over, not copied */
+    void SaveVoxelDataMove(const std::string &filename, NEWMAT::Matrix &data, VoxelDataType data_type = VDT_SCALAR);
 
 private:
     std::vector<int> m_mask;

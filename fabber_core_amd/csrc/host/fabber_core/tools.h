@@ -4,6 +4,9 @@
 #include "armawrap/newmat.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,3 +43,25 @@ void fabber_parallel_for(int n, Body body, int max_threads = 16)
     for (auto &th : pool)
         th.join();
 }
+
+/** FVB_HOST_TIMING=1: stage times of the host side of a run on stderr */
+struct FabberStageTimer
+{
+    bool on;
+    const char *who;
+    std::chrono::steady_clock::time_point last;
+    explicit FabberStageTimer(const char *who_)
+        : on(getenv("FVB_HOST_TIMING") != NULL)
+        , who(who_)
+        , last(std::chrono::steady_clock::now())
+    {
+    }
+    void lap(const char *what)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fabber host] %s: %s %.1f ms\n", who, what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};

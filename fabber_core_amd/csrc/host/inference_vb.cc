@@ -8,6 +8,7 @@
 // stores the result images in the run data. There is no CPU path: without a GPU the engine
 // call fails and the failure is reported as a FabberInternalError.
 #include "inference_vb.h"
+#include "tools.h"
 
 #include "convergence.h"
 #include "priors.h"
@@ -84,8 +85,13 @@ void InferenceTechnique::SaveResults(FabberRunData &rundata) const
 {
     if (rundata.GetBool("save-mvn"))
     {
-        Matrix image = m_result_image;
-        rundata.SaveVoxelData("finalMVN", image, VDT_MVN);
+        Matrix image;
+        image.ReSizeNoInit(m_result_image.Nrows(), m_result_image.Ncols());
+        const size_t cols = (size_t)m_result_image.Ncols();
+        const double *src = m_result_image.Store();
+        double *dst = image.Store();
+        fabber_parallel_for(m_result_image.Nrows(), [=](int r) { memcpy(dst + (size_t)r * cols, src + (size_t)r * cols, sizeof(double) * cols); });
+        rundata.SaveVoxelDataMove("finalMVN", image, VDT_MVN);
     }
 }
 
@@ -523,13 +529,16 @@ static void spatial_progress(int it, int maxits)
 
 void Vb::DoCalculations(FabberRunData &rundata)
 {
+    FabberStageTimer timer("Vb::DoCalculations");
     fvb_config &cfg = m_store->cfg;
     BuildEngineConfig(rundata, cfg);
+    timer.lap("engine configuration");
     m_nvoxels = cfg.n_voxels;
     const int rows = fabber_vb_mvn_rows(cfg.n_params + m_noise_params);
-    m_result_image.ReSize(rows, m_nvoxels);
+    m_result_image.ReSizeNoInit(rows, m_nvoxels); // (the engine writes every voxel's column)
     m_free_energy.clear();
     m_status.assign(m_nvoxels, 0);
+    timer.lap("result image");
 
     const bool output_only = rundata.GetBool("output-only");
     const bool spatial = IsSpatial(rundata);
@@ -743,6 +752,7 @@ void Vb::DoCalculations(FabberRunData &rundata)
     }
     if (rc != 0)
         throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
+    timer.lap("engine");
 
     // ---- per-voxel failures: what the reference's catch blocks do (inference_vb.cc:529-544) ----
     static const char *reasons[] = { "", "LinearizedFwdModel::ReCentre: Non-finite values found in offset",
@@ -782,16 +792,18 @@ void Vb::DoCalculations(FabberRunData &rundata)
         }
         m_f_history = hist;
     }
+    timer.lap("status pass");
 }
 
-static void save_rows(FabberRunData &rundata, const string &name, const vector<double> &buf, int rows, int row0, int n_rows, int V)
+static void save_rows(FabberRunData &rundata, const string &name, const std::vector<double, NEWMAT::DefaultInitAllocator<double> > &buf,
+    int rows, int row0, int n_rows, int V)
 {
-    Matrix m(n_rows, V);
+    Matrix m;
+    m.ReSizeNoInit(n_rows, V);
     (void)rows;
-    for (int r = 0; r < n_rows; r++)
-        for (int v = 0; v < V; v++)
-            m.at0(r, v) = buf[(size_t)(row0 + r) * V + v];
-    rundata.SaveVoxelData(name, m);
+    if (n_rows > 0 && V > 0)
+        memcpy(m.Store(), buf.data() + (size_t)row0 * V, sizeof(double) * (size_t)n_rows * V);
+    rundata.SaveVoxelDataMove(name, m);
 }
 
 // InferenceTechnique::SaveResults of the reference (inference.cc:112-281) plus the noise images
@@ -801,7 +813,9 @@ static void save_rows(FabberRunData &rundata, const string &name, const vector<d
 void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_config &cfg, const vector<Parameter> &params,
     int N, int n_noise_saved, bool host_model) const
 {
+    FabberStageTimer timer("SaveEngineResults");
     InferenceTechnique::SaveResults(rundata); // finalMVN
+    timer.lap("finalMVN");
 
     const int V = cfg.n_voxels, P = cfg.n_params, T = cfg.n_times;
     const bool want_mean = rundata.GetBool("save-mean"), want_std = rundata.GetBool("save-std");
@@ -809,7 +823,9 @@ void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_con
     const bool want_nmean = rundata.GetBool("save-noise-mean"), want_nstd = rundata.GetBool("save-noise-std");
     const bool want_fit = rundata.GetBool("save-model-fit"), want_resid = rundata.GetBool("save-residuals");
 
-    vector<double> mean, var, sd, zstat, fit, resid, nmean, nstd;
+    // (sized without being written: the post-processing fills them)
+    typedef std::vector<double, NEWMAT::DefaultInitAllocator<double> > Image;
+    Image mean, var, sd, zstat, fit, resid, nmean, nstd;
     fvb_postproc pp;
     memset(&pp, 0, sizeof(pp));
     const size_t PV = (size_t)P * V, TV = (size_t)T * V, NV = (size_t)N * V;
@@ -836,10 +852,12 @@ void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_con
             pp.modelfit = pp.residuals = NULL;
         fvb_config pcfg = cfg;
         int series_rows = 0, series_cols = 0;
-        const void *series = engine_series(rundata, host_model, pcfg.data_f64, series_rows, series_cols);
+        // (only the residuals need the series on the device: not uploaded otherwise)
+        const void *series = (pp.residuals != NULL) ? engine_series(rundata, host_model, pcfg.data_f64, series_rows, series_cols) : NULL;
         int rc = fabber_vb_postproc_host(&pcfg, series, m_result_image.Store(), &pp, rundata.GetIntDefault("device", 0, 0));
         if (rc != 0)
             throw FabberInternalError(string("MI355X engine failed in post-processing: ") + fabber_vb_last_error());
+        timer.lap("post-processing kernel (host pointers)");
         if (host_model && (want_fit || want_resid)) // inference.cc:181-243
         {
             const Matrix &data = rundata.GetMainVoxelData();
@@ -888,6 +906,7 @@ void InferenceTechnique::SaveEngineResults(FabberRunData &rundata, const fvb_con
         save_rows(rundata, "noise_means", nmean, N, 0, n_noise_saved, V); // first NumParams() noise entries (inference_vb.cc:981-989)
     if (want_nstd && N > 0)
         save_rows(rundata, "noise_stdevs", nstd, N, 0, n_noise_saved, V);
+    timer.lap("images into the run data");
 
     // model-specific extra outputs are defined by host code only (FwdModel::EvaluateModel with
     // a key): evaluate them on the host, like inference.cc:181-252

@@ -13,6 +13,7 @@
 #include "tools.h"
 #include "version.h"
 
+#include <chrono>
 #include <errno.h>
 #include <fstream>
 #include <iostream>
@@ -167,17 +168,29 @@ void FabberRunData::Run(ProgressCheck *progress)
             names << params[i].name << endl;
     }
 
+    // FVB_HOST_TIMING: where the host side of a run spends its time (stderr)
+    const bool timing = getenv("FVB_HOST_TIMING") != NULL;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     std::unique_ptr<InferenceTechnique> infer(InferenceTechnique::NewFromName(GetString("method")));
     infer->Initialize(fwd_model.get(), *this);
+    const auto t1 = now();
 
     int nvoxels = GetVoxelCoords().Ncols();
     LOG << "FabberRunData::Num voxels " << nvoxels << endl;
     Progress(0, nvoxels);
     infer->DoCalculations(*this);
+    const auto t2 = now();
     Progress(nvoxels, nvoxels);
     LOG << "FabberRunData::Saving results " << endl;
     infer->SaveResults(*this);
+    const auto t3 = now();
     LOG << "FabberRunData::All done." << endl;
+    if (timing)
+        fprintf(stderr, "[fabber host] Initialize %.1f ms, DoCalculations %.1f ms, SaveResults %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
 
     CheckAllOptionsUsed();
     time_t end;
@@ -564,7 +577,7 @@ const Matrix &FabberRunData::LoadVoxelData(const std::string &key)
         const int rows = f->second.rows;
         const size_t cols = rows > 0 ? f->second.values.size() / (size_t)rows : 0;
         Matrix &m = m_voxel_data[key];
-        m.ReSize(rows, (int)cols);
+        m.ReSizeNoInit(rows, (int)cols);
         const float *src = f->second.values.data();
         double *dst = m.Store();
         fabber_parallel_for(rows, [&](int r) {
@@ -578,7 +591,7 @@ const Matrix &FabberRunData::LoadVoxelData(const std::string &key)
     return it->second;
 }
 
-void FabberRunData::SetVoxelDataF32(string key, int rows, std::vector<float> &&values)
+void FabberRunData::SetVoxelDataF32(string key, int rows, FabberF32Values &&values)
 {
     const size_t cols = rows > 0 ? values.size() / (size_t)rows : 0;
     map<string, Matrix>::iterator coords = m_voxel_data.find("coords");

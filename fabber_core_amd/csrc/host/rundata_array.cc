@@ -9,6 +9,7 @@
 #include <string.h>
 
 using NEWMAT::Matrix;
+using std::endl;
 
 void FabberRunDataArray::SetExtent(int nx, int ny, int nz, const int *mask)
 {
@@ -76,7 +77,8 @@ void FabberRunDataArray::SetVoxelDataArray(std::string key, int data_size, const
         n_in += (m_mask[i] != 0);
     // kept as float32 [rows][masked voxels] (FabberRunData::SetVoxelDataF32): what the engine reads, and a Matrix
     // only when something asks for one
-    std::vector<float> values((size_t)std::max(data_size, 0) * n_in);
+    FabberF32Values values;
+    values.resize((size_t)std::max(data_size, 0) * n_in); // (not written here: the threads below touch their own rows first)
     float *dst0 = values.data();
     const int *mask = m_mask.data();
     const bool dense = n_in == nv;
@@ -94,4 +96,12 @@ void FabberRunDataArray::SetVoxelDataArray(std::string key, int data_size, const
                 dst[v++] = src[i];
     });
     FabberRunData::SetVoxelDataF32(key, data_size, std::move(values));
+}
+
+void FabberRunDataArray::SaveVoxelDataMove(const std::string &filename, Matrix &data, VoxelDataType)
+{
+    LOG << "FabberRunData::Saving to memory: " << filename << endl;
+    CheckSize(filename, data);
+    m_voxel_data_f32.erase(filename);
+    m_voxel_data[filename].SwapContents(data);
 }

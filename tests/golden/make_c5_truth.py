@@ -12,7 +12,7 @@ iteration).
 
     tests/golden/c5_truth_binary128.npz
       mvn [21][V], status [V], free_energy [V], data_sha256 (of the float32 series), shape
-      its [K], trace_means [K][4][V]   posterior means after its[k] = 1, 2, 3, 5 iterations (runs of their own)
+      its [K], trace_means [K][4][V]   posterior means after its[k] = 1, 2, 3, 5, 7, 8, 9 iterations (runs of their own)
 
     python tests/golden/make_c5_truth.py
 """
@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 SHAPE = (16, 16, 12)
-ITS = [1, 2, 3, 5]
+ITS = [1, 2, 3, 5, 7, 8, 9]
 
 
 def problem(**kw):
