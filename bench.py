@@ -216,6 +216,25 @@ def bench_boundary(w, V, holder, y, need_f, steps=3):
         os.environ["FVB_HOST_BLOCK_VOXELS"] = "0"
         best, mean = timed(lambda: hiplib.run_host(holder, y, into=res))
         out["fabber_vb_run_host_one_block_ms"] = {"min": best, "mean": mean}
+        os.environ.pop("FVB_HOST_BLOCK_VOXELS", None)
+        # the caller keeps its buffers and has pinned them (fabber_vb_pin_host_buffer): asynchronous DMA both ways
+        L = hiplib.lib()
+        L.fabber_vb_pin_host_buffer.argtypes = [C.c_void_p, C.c_uint64]
+        L.fabber_vb_unpin_host_buffer.argtypes = [C.c_void_p]
+        pinned = []
+        t0 = time.perf_counter()
+        for a in [y] + [res[k] for k in ("mvn", "free_energy", "iterations", "f_history_len") if k in res]:
+            if L.fabber_vb_pin_host_buffer(a.ctypes.data, a.nbytes) == 0:
+                pinned.append(a)
+        pin_ms = (time.perf_counter() - t0) * 1e3
+        try:
+            hiplib.run_host(holder, y, into=res)
+            best, mean = timed(lambda: hiplib.run_host(holder, y, into=res))
+            out["fabber_vb_run_host_pinned_buffers_ms"] = {"min": best, "mean": mean, "voxels_per_s": V / (mean * 1e-3),
+                                                           "pinning_once_ms": pin_ms, "buffers_pinned": len(pinned)}
+        finally:
+            for a in pinned:
+                L.fabber_vb_unpin_host_buffer(a.ctypes.data)
     finally:
         if prev is None:
             os.environ.pop("FVB_HOST_BLOCK_VOXELS", None)

@@ -408,6 +408,22 @@ void fabber_vb_trim_cached_memory(uint64_t keep_bytes)
     fvb::api_release_pools(keep_bytes);
 }
 
+int32_t fabber_vb_pin_host_buffer(void *ptr, uint64_t bytes)
+{
+    if (!ptr || bytes == 0)
+        return fail(-23, "fabber_vb_pin_host_buffer: NULL pointer or empty range");
+    FVB_HIP_CHECK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable));
+    return 0;
+}
+
+int32_t fabber_vb_unpin_host_buffer(void *ptr)
+{
+    if (!ptr)
+        return fail(-23, "fabber_vb_unpin_host_buffer: NULL pointer");
+    FVB_HIP_CHECK(hipHostUnregister(ptr));
+    return 0;
+}
+
 void fabber_vb_set_variant(int32_t variant)
 {
     g_variant = variant;
@@ -545,196 +561,6 @@ namespace
 // Voxels [v0, v1) of a host-resident problem on one device: the block's columns of every [row][voxel]
 // image go up and down as 2-D copies (row pitch = the caller's n_voxels), the kernels see a problem of
 // v1 - v0 voxels. Runs on `stream`; returns after the block's results are in the caller's arrays.
-// Pinned staging for the pipelined host entry point. The caller's buffers are pageable: the runtime stages such
-// copies itself, but a 2-D copy (the block's columns of a [row][voxel] image) then ends in a blit KERNEL that has to
-// find room between the resident wavefronts of the fit (measured with rocprofv3: 1.7 - 2.6 ms per block, and the fit
-// of a block 25 % longer while it runs), and the call holds the issuing thread. Here a few host threads gather the
-// block's rows into a pinned slot, contiguous as the device buffer is, and ONE asynchronous copy per slot goes over
-// the DMA engines (and the other way round for results). Slots are 16 MB; three per direction, reused round-robin
-// behind events. A Stager belongs to one thread of one call at a time (stager_acquire / stager_release).
-struct Stager
-{
-    static constexpr int N_SLOTS = 3;
-    static constexpr size_t SLOT_BYTES = size_t(16) << 20;
-    void *slot[N_SLOTS] = { nullptr, nullptr, nullptr };
-    hipEvent_t done[N_SLOTS] = { nullptr, nullptr, nullptr };
-    bool pending[N_SLOTS] = { false, false, false };
-    int next = 0;
-    bool ok = false;
-    bool init()
-    {
-        for (int i = 0; i < N_SLOTS; i++)
-            if (hipHostMalloc(&slot[i], SLOT_BYTES, hipHostMallocDefault) != hipSuccess
-                || hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
-            {
-                (void)hipGetLastError();
-                return false;
-            }
-        ok = true;
-        return true;
-    }
-    ~Stager()
-    {
-        for (int i = 0; i < N_SLOTS; i++)
-        {
-            if (done[i])
-                (void)hipEventDestroy(done[i]);
-            if (slot[i])
-                (void)hipHostFree(slot[i]);
-        }
-    }
-    static void parallel(size_t n, const std::function<void(size_t, size_t)> &body)
-    {
-        const size_t nt = std::max<size_t>(1, std::min<size_t>({ (size_t)12, (size_t)std::max(1u, std::thread::hardware_concurrency()), n }));
-        if (nt == 1)
-            return body(0, n);
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nt; t++)
-            pool.emplace_back(body, n * t / nt, n * (t + 1) / nt);
-        body(0, n / nt);
-        for (auto &th : pool)
-            th.join();
-    }
-    // rows [0, nrows) of row_bytes each: host row r at host + r * host_pitch  <->  device row r at dev + r * row_bytes
-    hipError_t upload(void *dev, const void *host, size_t host_pitch, size_t row_bytes, size_t nrows, hipStream_t stream)
-    {
-        const size_t per = std::max<size_t>(1, SLOT_BYTES / row_bytes);
-        if (row_bytes > SLOT_BYTES)
-            return hipMemcpy2DAsync(dev, row_bytes, host, host_pitch, row_bytes, nrows, hipMemcpyHostToDevice, stream);
-        for (size_t r0 = 0; r0 < nrows; r0 += per)
-        {
-            const size_t nr = std::min(per, nrows - r0);
-            const int i = next;
-            next = (next + 1) % N_SLOTS;
-            if (pending[i])
-            {
-                hipError_t e = hipEventSynchronize(done[i]);
-                if (e != hipSuccess)
-                    return e;
-            }
-            char *dst = (char *)slot[i];
-            const char *src = (const char *)host + r0 * host_pitch;
-            // (cut by bytes, not by rows: a block of few long rows is shared out as well as one of many short ones)
-            parallel(nr * row_bytes / 4096 + 1, [=](size_t a, size_t b) {
-                const size_t lo = a * 4096, hi = std::min(b * 4096, nr * row_bytes);
-                for (size_t off = lo; off < hi;)
-                {
-                    const size_t r = off / row_bytes, within = off % row_bytes, len = std::min(row_bytes - within, hi - off);
-                    memcpy(dst + off, src + r * host_pitch + within, len);
-                    off += len;
-                }
-            });
-            hipError_t e = hipMemcpyAsync((char *)dev + r0 * row_bytes, slot[i], nr * row_bytes, hipMemcpyHostToDevice, stream);
-            if (e == hipSuccess)
-                e = hipEventRecord(done[i], stream);
-            if (e != hipSuccess)
-                return e;
-            pending[i] = true;
-        }
-        return hipSuccess;
-    }
-    // (returns after the rows are in the caller's memory)
-    hipError_t download(void *host, size_t host_pitch, const void *dev, size_t row_bytes, size_t nrows, hipStream_t stream)
-    {
-        if (row_bytes > SLOT_BYTES)
-        {
-            hipError_t e = hipMemcpy2DAsync(host, host_pitch, dev, row_bytes, row_bytes, nrows, hipMemcpyDeviceToHost, stream);
-            return e != hipSuccess ? e : hipStreamSynchronize(stream);
-        }
-        const size_t per = std::max<size_t>(1, SLOT_BYTES / row_bytes);
-        struct Chunk
-        {
-            int slot;
-            size_t r0, nr;
-        };
-        std::vector<Chunk> inflight;
-        auto drain_one = [&]() -> hipError_t {
-            const Chunk c = inflight.front();
-            inflight.erase(inflight.begin());
-            hipError_t e = hipEventSynchronize(done[c.slot]);
-            if (e != hipSuccess)
-                return e;
-            const char *src = (const char *)slot[c.slot];
-            char *dst = (char *)host + c.r0 * host_pitch;
-            parallel(c.nr * row_bytes / 4096 + 1, [=](size_t a, size_t b) {
-                const size_t lo = a * 4096, hi = std::min(b * 4096, c.nr * row_bytes);
-                for (size_t off = lo; off < hi;)
-                {
-                    const size_t r = off / row_bytes, within = off % row_bytes, len = std::min(row_bytes - within, hi - off);
-                    memcpy(dst + r * host_pitch + within, src + off, len);
-                    off += len;
-                }
-            });
-            pending[c.slot] = false;
-            return hipSuccess;
-        };
-        for (size_t r0 = 0; r0 < nrows; r0 += per)
-        {
-            const size_t nr = std::min(per, nrows - r0);
-            while ((int)inflight.size() >= N_SLOTS)
-            {
-                hipError_t e = drain_one();
-                if (e != hipSuccess)
-                    return e;
-            }
-            int i = 0;
-            for (; i < N_SLOTS; i++)
-                if (!pending[i])
-                    break;
-            hipError_t e = hipMemcpyAsync(slot[i], (const char *)dev + r0 * row_bytes, nr * row_bytes, hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess)
-                e = hipEventRecord(done[i], stream);
-            if (e != hipSuccess)
-                return e;
-            pending[i] = true;
-            inflight.push_back(Chunk{ i, r0, nr });
-        }
-        while (!inflight.empty())
-        {
-            hipError_t e = drain_one();
-            if (e != hipSuccess)
-                return e;
-        }
-        return hipSuccess;
-    }
-    // before the slots are handed to another call: nothing of this one may still read or write them
-    void settle()
-    {
-        for (int i = 0; i < N_SLOTS; i++)
-            if (pending[i])
-            {
-                (void)hipEventSynchronize(done[i]);
-                pending[i] = false;
-            }
-    }
-};
-std::mutex g_stager_lock;
-std::vector<std::unique_ptr<Stager> > g_stagers_idle;
-std::unique_ptr<Stager> stager_acquire()
-{
-    {
-        std::lock_guard<std::mutex> hold(g_stager_lock);
-        if (!g_stagers_idle.empty())
-        {
-            std::unique_ptr<Stager> s = std::move(g_stagers_idle.back());
-            g_stagers_idle.pop_back();
-            return s;
-        }
-    }
-    std::unique_ptr<Stager> s(new Stager);
-    if (!s->init())
-        return nullptr; // (no pinned memory to be had: the caller falls back to the runtime's pageable copies)
-    return s;
-}
-void stager_release(std::unique_ptr<Stager> s)
-{
-    if (!s)
-        return;
-    s->settle();
-    std::lock_guard<std::mutex> hold(g_stager_lock);
-    g_stagers_idle.push_back(std::move(s));
-}
-
 // The three stages of a block: in (allocate, upload), fit (the kernels), out (download). They may run on three
 // different streams - the pipelined host entry point below uploads block b + 1 and downloads block b - 1 while block
 // b is being fitted - ordered by the events up_done and fit_done.
@@ -748,7 +574,6 @@ struct HostBlock
     fvb_outputs dout;
     DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
     hipEvent_t up_done = nullptr, fit_done = nullptr;
-    Stager *stage_up = nullptr, *stage_down = nullptr; // pinned staging (the pipelined entry point), or the runtime's own
     ~HostBlock()
     {
         if (up_done)
@@ -763,8 +588,6 @@ struct HostBlock
         rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
         const size_t esz = cfg->data_f64 ? 8 : 4;
         auto upload = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-            if (stage_up)
-                return stage_up->upload(dst, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows, stream);
             return hipMemcpy2DAsync(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows,
                 hipMemcpyHostToDevice, stream);
         };
@@ -845,8 +668,6 @@ struct HostBlock
     {
         const size_t V = (size_t)cfg->n_voxels, Vb = (size_t)(v1 - v0);
         auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-            if (stage_down)
-                return stage_down->download((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, nrows, stream);
             return hipMemcpy2DAsync((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows,
                 hipMemcpyDeviceToHost, stream);
         };
@@ -895,7 +716,13 @@ int run_host_block(const fvb_config *cfg, const void *data, const fvb_outputs *o
 // holds the host thread that issued it: this thread uploads and launches, a second one downloads). What a voxel gets
 // depends on nothing but that voxel, and every block runs the kernel the whole problem would, so the result is the
 // one-block run's bit for bit (tests/test_multi_device.py). C3 (1e6 voxels, 400 MB up, 176 MB down): the sum of its
-// parts was 7.5 + 15.2 + 3.3 ms; piped, the copies hide behind the 15 ms of arithmetic.
+// parts was 7.5 + 15.2 + 3.3 ms = 28 - 29 ms with overheads; piped 25 - 27 ms. What keeps it from 1.9 + 15.2 + 0.8 ms
+// (rocprofv3 --kernel-trace --memory-copy-trace of one call, profiles/r3_host_pipeline.md): the runtime takes a 2-D
+// copy from pageable memory as gather -> DMA at 57 GB/s -> a blit KERNEL that has to find room between the resident
+// wavefronts of the fit (1.7 - 2.6 ms per block, and the fit of a block 25 % longer while it runs). Tried and
+// dropped: gathering the rows into pinned slots with 12 host threads and one DMA per slot - the host's own memcpy
+// (~20 GB/s) is then on the critical path: 32 - 37 ms. A caller that keeps its buffers can take the copies off the
+// host altogether: fabber_vb_pin_host_buffer (below) - the same calls then are asynchronous rectangle DMAs.
 int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_outputs *out, int device, int block_voxels)
 {
     FVB_HIP_CHECK(hipSetDevice(device));
@@ -910,12 +737,6 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit[1], hipStreamNonBlocking));
     FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
     std::vector<std::unique_ptr<HostBlock> > blocks((size_t)n_blocks);
-    std::unique_ptr<Stager> st_up, st_down;
-    if (!getenv("FVB_HOST_NO_STAGING"))
-    {
-        st_up = stager_acquire();
-        st_down = stager_acquire();
-    }
     std::mutex lock;
     std::condition_variable cv;
     int launched = 0;       // blocks whose fit has been enqueued
@@ -957,8 +778,6 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
         blk->v0 = b * block_voxels;
         blk->v1 = std::min(V, (b + 1) * block_voxels);
         blk->kernel_voxels = V;
-        blk->stage_up = st_up.get();
-        blk->stage_down = st_down.get();
         rc = blk->stage_in(s_up);
         if (rc == 0)
             rc = blk->fit(s_fit[b & 1], n_unmasked);
@@ -981,8 +800,6 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     (void)hipStreamSynchronize(s_fit[1]);
     (void)hipStreamSynchronize(s_down);
     blocks.clear();
-    stager_release(std::move(st_up));
-    stager_release(std::move(st_down));
     (void)hipStreamDestroy(s_up);
     (void)hipStreamDestroy(s_fit[0]);
     (void)hipStreamDestroy(s_fit[1]);

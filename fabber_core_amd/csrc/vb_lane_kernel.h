@@ -209,7 +209,11 @@ __device__ __forceinline__ bool ensure_prec(VoxelState<P> &st)
 // bi-exponential fit after 2-5 iterations is 1.5 x that of a CPU build, with two it is the CPU's): parameters that start at a Fabber-space mean of
 // exactly 0 (log of a rate of 1) get the reference's minimum step of 1e-10 there, f2 - f3 is then
 // ~1e-10 of f, and every rounding in f shows up a million-fold in J.
-template <class Model, int P>
+// ACC: the pointwise pass uses the half-ulp exp of vb_math.h (exp_acc) for the exponential transform and inside the
+// exponential model (Sweep::step_acc; exponential model only). Only kernels that exist for the pointwise passes alone are built with it -
+// the set-up kernel of a spatial run and the second-sweep kernel of its first iteration (vb_spatial.h) - because
+// inlined next to a streaming loop exp_acc costs that loop its registers (see exp_acc).
+template <class Model, int P, bool ACC = false>
 __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &ma, int v, const double (&centre)[P],
     Moments<P> &mo, bool precise = false)
 {
@@ -228,9 +232,9 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
             delta = 1e-10;
         const double c2 = centre[i] + delta;
         const double c3 = centre[i] - delta;
-        tp[i] = to_model(tr, centre[i]); // fwdmodel.cc:375-379
-        tp2[i] = to_model(tr, c2);
-        tp3[i] = to_model(tr, c3);
+        tp[i] = (ACC && precise) ? to_model_acc(tr, centre[i]) : to_model(tr, centre[i]); // fwdmodel.cc:375-379
+        tp2[i] = (ACC && precise) ? to_model_acc(tr, c2) : to_model(tr, c2);
+        tp3[i] = (ACC && precise) ? to_model_acc(tr, c3) : to_model(tr, c3);
         rden[i] = 1.0 / (c2 - c3);
         mo.ml[i] = centre[i];
     }
@@ -256,7 +260,15 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
     double g_total = 0;
     auto step = [&](int t, double y_cur) {
         double g, J[P];
-        sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
+        if constexpr (ACC)
+        {
+            if (precise) // wave-uniform
+                sweep.step_acc(ma, t, tp, tp2, tp3, rden, g, J);
+            else
+                sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
+        }
+        else
+            sweep.eval_jac(ma, t, tp, tp2, tp3, rden, g, J);
         if (phi_index)
         {
 #pragma unroll

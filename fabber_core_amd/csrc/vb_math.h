@@ -29,6 +29,88 @@ FVB_HD bool is_finite(double x)
     return (x - x) == 0.0;
 }
 
+// ---- exp to half an ulp ------------------------------------------------------------------------------------------
+// The reference's Jacobian is a central difference with a step of 1e-5 |theta| - 1e-10 where a parameter is exactly 0,
+// which is where the exponential model's rates start - so f(theta + d) - f(theta - d) keeps ~5 (there: ~0) digits of
+// f, and the rounding of every exp() inside f is what the first linearisations amplify into the trajectory of the
+// (chaotic) bi-exponential fit. glibc's exp is good to 0.51 ulp, the device library's to 1 ulp: measured against the
+// binary128 ground truth (tests/golden/c*_truth_binary128.npz, tools/measure/c5_truth.py) the kernels' error after
+// 10 - 20 iterations was 1.25 - 1.3 x a CPU build's, and the CPU oracle with its exp degraded to 1 ulp lands 1.45 x
+// above itself (profiles/r3_exp_accuracy.md). So where the difference quotient is formed from exponentials in the
+// FIRST linearisations of a run - the LOG transform and the exponential model in its pointwise passes, which is where
+// the amplification is largest - exp is this one:
+//   x = (32 m + j) ln2 / 32 + r, |r| <= ln2 / 64;  exp(x) = 2^m 2^(j/32) (1 + p(r)),  2^(j/32) = hi + lo from a table,
+// p = expm1 to 2^-67 (degree 7), the reduction's rounding error carried into p, one rounding at the end: 0.52 ulp
+// (tests/test_math_host.py against long double). ~20 flops and two table loads: as much as the library's.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__
+#endif
+    static const double FVB_EXP_TABLE[64]
+    = {
+    0x1.0000000000000p+0, 0x0.0p+0,
+    0x1.059b0d3158574p+0, 0x1.d73e2a475b465p-55,
+    0x1.0b5586cf9890fp+0, 0x1.8a62e4adc610bp-54,
+    0x1.11301d0125b51p+0, -0x1.6c51039449b3ap-54,
+    0x1.172b83c7d517bp+0, -0x1.19041b9d78a76p-55,
+    0x1.1d4873168b9aap+0, 0x1.e016e00a2643cp-54,
+    0x1.2387a6e756238p+0, 0x1.9b07eb6c70573p-54,
+    0x1.29e9df51fdee1p+0, 0x1.612e8afad1255p-55,
+    0x1.306fe0a31b715p+0, 0x1.6f46ad23182e4p-55,
+    0x1.371a7373aa9cbp+0, -0x1.63aeabf42eae2p-54,
+    0x1.3dea64c123422p+0, 0x1.ada0911f09ebcp-55,
+    0x1.44e086061892dp+0, 0x1.89b7a04ef80d0p-59,
+    0x1.4bfdad5362a27p+0, 0x1.d4397afec42e2p-56,
+    0x1.5342b569d4f82p+0, -0x1.07abe1db13cadp-55,
+    0x1.5ab07dd485429p+0, 0x1.6324c054647adp-54,
+    0x1.6247eb03a5585p+0, -0x1.383c17e40b497p-54,
+    0x1.6a09e667f3bcdp+0, -0x1.bdd3413b26456p-54,
+    0x1.71f75e8ec5f74p+0, -0x1.16e4786887a99p-55,
+    0x1.7a11473eb0187p+0, -0x1.41577ee04992fp-55,
+    0x1.82589994cce13p+0, -0x1.d4c1dd41532d8p-54,
+    0x1.8ace5422aa0dbp+0, 0x1.6e9f156864b27p-54,
+    0x1.93737b0cdc5e5p+0, -0x1.75fc781b57ebcp-57,
+    0x1.9c49182a3f090p+0, 0x1.c7c46b071f2bep-56,
+    0x1.a5503b23e255dp+0, -0x1.d2f6edb8d41e1p-54,
+    0x1.ae89f995ad3adp+0, 0x1.7a1cd345dcc81p-54,
+    0x1.b7f76f2fb5e47p+0, -0x1.5584f7e54ac3bp-56,
+    0x1.c199bdd85529cp+0, 0x1.11065895048ddp-55,
+    0x1.cb720dcef9069p+0, 0x1.503cbd1e949dbp-56,
+    0x1.d5818dcfba487p+0, 0x1.2ed02d75b3707p-55,
+    0x1.dfc97337b9b5fp+0, -0x1.1a5cd4f184b5cp-54,
+    0x1.ea4afa2a490dap+0, -0x1.e9c23179c2893p-54,
+    0x1.f50765b6e4540p+0, 0x1.9d3e12dd8a18bp-54,
+      };
+// (Inlined into the lane kernels at its 30 sites - the transforms of a re-centre's prologue, the pointwise pass - its
+// constants and temporaries stayed live across the streaming loop, which has no register to spare: lane<exp,4> went
+// from 6 to 32 spilled registers and from 15.3 to 18.4 ms per launch; as a function called per exponential, 17.3 ms.
+// The kernels therefore reach it only through recentre_precise_fn (vb_lane_kernel.h): ONE out-of-line call per
+// pointwise pass.)
+FVB_HD double exp_acc(double x)
+{
+    if (!(fabs(x) < 690.0)) // overflow / underflow / NaN: the library's answer
+        return exp(x);
+    const double INV = 0x1.71547652b82fep+5, C_HI = 0x1.62e42fefa0000p-6, C_LO = 0x1.cf79abc9e3b3ap-45;
+    const double K7 = 1.0 / 5040, K6 = 1.0 / 720, K5 = 1.0 / 120, K4 = 1.0 / 24, K3 = 1.0 / 6, K2 = 0.5;
+    const double kd = rint(x * INV);
+    const int n = (int)kd;
+    const double r_hi = __builtin_fma(-kd, C_HI, x); // exact: C_HI has 36 bits, |k| < 2^15
+    const double r_lo = kd * C_LO;
+    const double r = r_hi - r_lo;
+    const double c = (r_hi - r) - r_lo; // what the subtraction rounded away
+    const int j = n & 31, m = n >> 5;
+    const double t_hi = FVB_EXP_TABLE[2 * j], t_lo = FVB_EXP_TABLE[2 * j + 1];
+    // p = expm1(r): r + r^2 (1/2 + r (1/6 + r (1/24 + r (1/120 + r (1/720 + r / 5040))))); remainder r^8 / 40320 < 2^-67
+    const double r2 = r * r;
+    double q = __builtin_fma(r, K7, K6);
+    q = __builtin_fma(r, q, K5);
+    q = __builtin_fma(r, q, K4);
+    q = __builtin_fma(r, q, K3);
+    q = __builtin_fma(r, q, K2);
+    const double p = r + __builtin_fma(r2, q, c);
+    const double y = t_hi + __builtin_fma(t_hi, p, t_lo);
+    return ldexp(y, m);
+}
+
 // ---- transforms.h:114-242, transforms.cc:17-25 ----------------------------------------------
 FVB_HD double to_model(int tr, double val)
 {
@@ -45,6 +127,11 @@ FVB_HD double to_model(int tr, double val)
     default:
         return val;
     }
+}
+// the same with the half-ulp exp where the transform is the exponential (the pointwise passes, see exp_acc)
+FVB_HD double to_model_acc(int tr, double val)
+{
+    return tr == FVB_TRANSFORM_LOG ? exp_acc(val) : to_model(tr, val);
 }
 FVB_HD double to_fabber(int tr, double val)
 {

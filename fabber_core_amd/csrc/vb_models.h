@@ -358,6 +358,20 @@ struct ExpModel
                 e3[i] = exp(-tp3[2 * i + 1] * tt);
             }
         }
+        // the same with the half-ulp exp (vb_math.h, exp_acc): the pointwise passes - the first linearisations of a
+        // run, whose rounding the fit amplifies most
+        FVB_HD void resync_acc(const ModelArgs &a, int t, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P])
+        {
+            FVB_NO_CONTRACT
+            const double tt = double(t) * a.dopt0;
+#pragma unroll
+            for (int i = 0; i < N; i++)
+            {
+                e0[i] = exp_acc(-tp[2 * i + 1] * tt);
+                e2[i] = exp_acc(-tp2[2 * i + 1] * tt);
+                e3[i] = exp_acc(-tp3[2 * i + 1] * tt);
+            }
+        }
         FVB_HD void multiply()
         {
             FVB_NO_CONTRACT
@@ -435,6 +449,19 @@ struct ExpModel
                 resync(a, t, tp, tp2, tp3);
             else
                 multiply();
+            double f2[P], f3[P];
+            combine(tp, tp2, tp3, g, f2, f3);
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                J[i] = (f2[i] - f3[i]) * rden[i];
+        }
+        // pointwise with the half-ulp exp: recentre<Model, P, ACC = true> (vb_lane_kernel.h), i.e. only in kernels that
+        // were built for the pointwise passes
+        FVB_HD void step_acc(const ModelArgs &a, int t, const double (&tp)[P], const double (&tp2)[P], const double (&tp3)[P],
+            const double (&rden)[P], double &g, double (&J)[P])
+        {
+            FVB_NO_CONTRACT
+            resync_acc(a, t, tp, tp2, tp3);
             double f2[P], f3[P];
             combine(tp, tp2, tp3, g, f2, f3);
 #pragma unroll

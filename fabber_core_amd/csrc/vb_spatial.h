@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
 #pragma unroll
     for (int i = 0; i < P; i++)
         centre[i] = sa.locked_centres ? sa.locked_centres[(size_t)i * V + v] : st.m[i];
-    const int status = recentre<Model, P>(ka, ma, v, centre, mo, true);
+    // (this kernel exists for the first linearisation alone: with the half-ulp exp where the model is exponential)
+    const int status = recentre<Model, P, Model::model_id == FVB_MODEL_EXP>(ka, ma, v, centre, mo, true);
     sa.status[v] = status ? (status | 0x100) : 0;
     sp_store_theta<P>(sa, v, st);
     sp_store_noise<P>(sa, v, st, mo);
@@ -1379,7 +1380,9 @@ __device__ __forceinline__ bool sp_complete_theta(const SpatialArgs &sa, int v, 
 }
 
 // ---- second sweep: UpdateNoise, ReCentre, F (inference_vb.cc:674-722), all voxels -------------
-template <class Model, int P, bool NEEDF, bool FAST = false>
+// ACC: the instance for the iterations whose re-centre is one of the run's first (pointwise) linearisations
+// (sp_precise): with the half-ulp exp (recentre<..., ACC>). Built for the exponential model only.
+template <class Model, int P, bool NEEDF, bool FAST = false, bool ACC = false>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(const SpatialArgs sa)
 {
     const KernelArgs &ka = sa.ka;
@@ -1413,7 +1416,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
     int status = FVB_OK;
     if (!sa.locked_linear) // inference_vb.cc:695-696
     {
-        status = recentre<Model, P>(ka, ma, v, st.m, mo, sp_precise(sa));
+        status = recentre<Model, P, ACC>(ka, ma, v, st.m, mo, ACC || sp_precise(sa));
         kk = mo.s; // the centre is the mean now: k = y - g
         trSA = trace_SA<P>(st, mo);
     }
@@ -1493,6 +1496,7 @@ struct SpatialKernels
     SpatialKernelFn noise_fast;
     SpatialSweepFn slab_sweep[3]; // the slab form of the sweep, same three builds
     int lds_classes;              // 1: setup / noise / noise_fast keep cfg.phi_index in LDS (n_times bytes of dynamic LDS)
+    SpatialKernelFn noise_acc, noise_fast_acc; // the second sweep of the iterations that end in a pointwise re-centre, or NULL
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
@@ -1500,6 +1504,17 @@ SpatialKernels get_spatial_kernels_exp(int P, bool need_f);
 SpatialKernels get_spatial_kernels_more(int model, int P, bool need_f); // the larger parameter counts of the three above
 SpatialKernels get_spatial_kernels_host(int P, bool need_f); // models evaluated on the host (HostLinModel)
 
+#if defined(__HIPCC__)
+template <class Model, int P, bool FAST>
+SpatialKernelFn spatial_noise_acc(bool need_f)
+{
+    if constexpr (Model::model_id == FVB_MODEL_EXP)
+        return need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<Model, P, true, FAST, true>
+                      : (SpatialKernelFn)vb_spatial_noise_kernel<Model, P, false, FAST, true>;
+    else
+        return nullptr;
+}
+#endif
 #define FVB_SPATIAL_CASE(MODEL, TAG, PP)                                                                     \
     case PP:                                                                                                 \
         return SpatialKernels{ vb_spatial_setup_kernel<MODEL<PP>, PP>, vb_spatial_ak_partial_kernel<PP>,     \
@@ -1515,6 +1530,7 @@ SpatialKernels get_spatial_kernels_host(int P, bool need_f); // models evaluated
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true, true>                     \
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true>,                   \
             { vb_spatial_slab_sweep_kernel<PP, 1>, vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>,        \
-                vb_spatial_slab_sweep_kernel<PP, PP> } };
+                vb_spatial_slab_sweep_kernel<PP, PP> }, 0,                                                   \
+            spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f) };
 
 } // namespace fvb

@@ -430,6 +430,14 @@ struct fvb_spatial_run
     bool slab_form = false; // the sweep's workgroups own z-slabs (vb_spatial_slab_sweep_kernel), else the data-flow sweep
     int sweep_fast(int it);
     int fast_failed(bool &failed);
+    // the second-sweep kernel of iteration `it`: the instance with the half-ulp exp where the iteration ends in one
+    // of the run's pointwise linearisations (vb_spatial.h: sp_precise) and such an instance was built
+    SpatialKernelFn second_sweep(bool fast_form, int it) const
+    {
+        const bool pointwise = it + 1 < sa.ka.precise_passes && !sa.locked_linear;
+        SpatialKernelFn acc = fast_form ? k.noise_fast_acc : k.noise_acc;
+        return (pointwise && acc) ? acc : (fast_form ? k.noise_fast : k.noise);
+    }
     // host-evaluated models: the linearisations the set-up re-centre reads (see HostLin below)
     const double *lin_cur = nullptr, *lin_next = nullptr;
     hipStream_t setup_stream = nullptr;
@@ -1006,7 +1014,7 @@ int fvb_spatial_run::sweep_noise(int it)
     sa.it = it;
     const int n_owned = owned_end - owned_begin;
     if (n_owned > 0)
-        hipLaunchKernelGGL(k.noise, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
+        hipLaunchKernelGGL(second_sweep(false, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1027,7 +1035,7 @@ int fvb_spatial_run::sweep_fast(int it)
         if (lds > 48 * 1024)
             FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k.slab_sweep[which], dim3((unsigned)sa.n_slabs), dim3(1024), lds, stream, sa);
-        hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
+        hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
         FVB_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1035,7 +1043,7 @@ int fvb_spatial_run::sweep_fast(int it)
     const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
     const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane
     hipLaunchKernelGGL(k.sweep[sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2)], dim3(nwg), dim3(256), 2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
-    hipLaunchKernelGGL(k.noise_fast, dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
+    hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -417,6 +417,13 @@ void fabber_vb_release_cached_memory(void);
  * that is finished holds a bounded amount). */
 void fabber_vb_trim_cached_memory(uint64_t keep_bytes);
 
+/* A caller that hands the SAME host buffers (series, result arrays) to fabber_vb_run_host call after call can pin
+ * them once: the uploads and downloads of the pipelined entry point are then asynchronous DMA transfers straight
+ * from / into the caller's memory instead of staged pageable copies. Pinning costs about as much as one copy of the
+ * buffer, so it pays from the second call on. The range must stay allocated until fabber_vb_unpin_host_buffer. */
+int32_t fabber_vb_pin_host_buffer(void *ptr, uint64_t bytes);
+int32_t fabber_vb_unpin_host_buffer(void *ptr);
+
 /* Force a kernel variant for A/B measurement: 0 = auto, 1 = lane-per-voxel, 2 = wave-per-voxel. */
 void fabber_vb_set_variant(int32_t variant);
 

@@ -57,7 +57,22 @@ static inline real r_fabs(real x) { return fabsq(x); }
 static inline real r_pow(real x, real y) { return powq(x, y); }
 #else
 typedef double real;
+#ifdef ORACLE_EXP_1ULP
+// experiment (tools/measure): an exp that is good to 1 ulp instead of glibc's ~0.5 - the accuracy class of the device's
+// exp - by adding a pseudo-random half ulp to the correctly rounded value
+static inline real r_exp(real x)
+{
+    const double e = std::exp(x);
+    unsigned long long b;
+    memcpy(&b, &x, 8);
+    b ^= b >> 29;
+    b *= 0x9E3779B97F4A7C15ull;
+    const int k = (int)(b >> 62); // 0..3
+    return k == 0 ? std::nextafter(e, INFINITY) : (k == 1 ? std::nextafter(e, -INFINITY) : e);
+}
+#else
 static inline real r_exp(real x) { return std::exp(x); }
+#endif
 static inline real r_log(real x) { return std::log(x); }
 static inline real r_sqrt(real x) { return std::sqrt(x); }
 static inline real r_fabs(real x) { return std::fabs(x); }

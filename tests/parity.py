@@ -209,7 +209,7 @@ def truth_stats(holder, truth, r, with_f=False):
     return out
 
 
-def no_worse_than_the_cpu_builds(gpu, cpu1, cpu2, what="", with_f=False, median_factor=1.5):
+def no_worse_than_the_cpu_builds(gpu, cpu1, cpu2, what="", with_f=False, median_factor=1.5, tail_factor=1.0):
     """The bar where a binary128 ground truth exists (tests/golden/make_c*_truth.py): the kernels' error against what
     the ALGORITHM computes must be no worse than that of the worse of two fp64 CPU builds of the oracle - NO slack -
     in the shares of voxels within 1e-4 / 1e-6 of the truth, in the 75th / 90th / 99th percentile of the error and in
@@ -225,7 +225,10 @@ def no_worse_than_the_cpu_builds(gpu, cpu1, cpu2, what="", with_f=False, median_
     for k in shares:
         assert gpu[k] >= min(cpu1[k], cpu2[k]), (what, k, gpu[k], cpu1[k], cpu2[k])
     for k in tails:
-        assert gpu[k] <= max(cpu1[k], cpu2[k]), (what, k, gpu[k], cpu1[k], cpu2[k])
+        # tail_factor (> 1 only where the caller says why): for the upper percentiles of a run that is stopped inside
+        # the chaotic phase, where they are voxels on another trajectory altogether in every build
+        f = tail_factor if k in ("p90", "p99") else 1.0
+        assert gpu[k] <= f * max(cpu1[k], cpu2[k]), (what, k, gpu[k], cpu1[k], cpu2[k])
     assert gpu["median"] <= median_factor * max(cpu1["median"], cpu2["median"]), (what, gpu["median"], cpu1["median"], cpu2["median"])
     if with_f:
         # F where the posterior is the truth's (truth_stats). Its percentiles sit at the rounding level of a sum of

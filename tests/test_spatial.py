@@ -315,11 +315,22 @@ def test_c5_error_against_the_ground_truth(route, monkeypatch):
     truth, (h, sp, y) = parity.load_c5_truth()
     if route == "per-level":
         monkeypatch.setenv("FVB_SPATIAL_PER_LEVEL", "1")
-    got = hiplib.run_spatial_host(h, sp, y, devices=[0, 0] if route == "two slabs" else None)
+    devices = [0, 0] if route == "two slabs" else None
+    got = hiplib.run_spatial_host(h, sp, y, devices=devices)
     gpu_s = parity.truth_stats(h, truth, got, with_f=True)
     c1, c2 = (parity.truth_stats(h, truth, r(h, sp, y), with_f=True) for r in (oracle.run_spatial, oracle.run_spatial_fma))
     print("C5 vs binary128 truth [%s]: gpu %s | cpu %s | cpu_fma %s" % (route, gpu_s, c1, c2))
-    parity.no_worse_than_the_cpu_builds(gpu_s, c1, c2, what="C5 " + route, with_f=True)
+    # median, 75th percentile, failed share, F where the posterior is the truth's: no slack. The 90th / 99th
+    # percentile after 10 iterations are voxels 0.1 - 2 posterior sd off in every build (the run stops inside the
+    # chaotic phase): 10 % on those two.
+    parity.no_worse_than_the_cpu_builds(gpu_s, c1, c2, what="C5 " + route, with_f=True, median_factor=1.0, tail_factor=1.1)
+    # ... and on the way there: the median error of the means after 1 ... 9 iterations, as the C3 test (x 1.1)
+    import make_c5_truth as mt
+    for k, it in enumerate(truth["its"]):
+        hk, _, _ = mt.problem(max_iterations=int(it))
+        g = parity.truth_trace_stats(hk, truth["trace_means"][k], hiplib.run_spatial_host(hk, sp, y, devices=devices))["median"]
+        c = max(parity.truth_trace_stats(hk, truth["trace_means"][k], r(hk, sp, y))["median"] for r in (oracle.run_spatial, oracle.run_spatial_fma))
+        assert g <= 1.1 * c, (route, it, g, c)
 
 
 @gpu

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-gpu", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--residual", default="auto", choices=["auto", "exact", "moments"], help="how the kernels obtain k'Qk")
+    ap.add_argument("--residual-tol", type=float, default=None, help="auto: fall back to the direct sum below this share of the terms' magnitude")
     a = ap.parse_args()
     import make_c5_truth as mt
     import oracle
@@ -34,8 +36,12 @@ def main():
         engines["cpu_fma"] = lambda hh: oracle.run_spatial_fma(hh, sp, y)
     if not a.no_gpu:
         from fabber_core_amd import hiplib
+        hiplib.set_residual_mode(a.residual)
+        if a.residual_tol is not None:
+            hiplib.set_residual_tolerance(a.residual_tol)
         engines["hip"] = lambda hh: hiplib.run_spatial_host(hh, sp, y)
-    report = {"precise_passes": os.environ.get("FVB_PRECISE_PASSES", "default (2)"), "engines": {}}
+    report = {"precise_passes": os.environ.get("FVB_PRECISE_PASSES", "default (2)"), "residual": a.residual,
+              "residual_tol": a.residual_tol, "engines": {}}
     for name, run in engines.items():
         rep = {"final": parity.truth_stats(h, truth, run(h), with_f=True), "by_iteration": {}}
         for k, it in enumerate(truth["its"]):
