@@ -232,9 +232,9 @@ __device__ __forceinline__ int recentre(const KernelArgs &ka, const ModelArgs &m
             delta = 1e-10;
         const double c2 = centre[i] + delta;
         const double c3 = centre[i] - delta;
-        tp[i] = (ACC && precise) ? to_model_acc(tr, centre[i]) : to_model(tr, centre[i]); // fwdmodel.cc:375-379
-        tp2[i] = (ACC && precise) ? to_model_acc(tr, c2) : to_model(tr, c2);
-        tp3[i] = (ACC && precise) ? to_model_acc(tr, c3) : to_model(tr, c3);
+        tp[i] = (ACC && precise) ? to_model_acc(tr, centre[i], ma.exp_table) : to_model(tr, centre[i]); // fwdmodel.cc:375-379
+        tp2[i] = (ACC && precise) ? to_model_acc(tr, c2, ma.exp_table) : to_model(tr, c2);
+        tp3[i] = (ACC && precise) ? to_model_acc(tr, c3, ma.exp_table) : to_model(tr, c3);
         rden[i] = 1.0 / (c2 - c3);
         mo.ml[i] = centre[i];
     }
@@ -1251,11 +1251,17 @@ __device__ __forceinline__ bool calc_free_energy_cached(const KernelArgs &ka, Vo
     }
     if (!fc.prior_valid)
     {
-        double logdetPrior = 0;
+        // (one logarithm for the product of the precisions: mantissas multiplied, exponents added - see ldl_inverse)
+        double mant = 1.0;
+        int expo = 0;
 #pragma unroll
         for (int i = 0; i < P; i++)
-            logdetPrior += log(fabs(st.pprec[i]));
-        fc.prior_logdet = 0.5 * logdetPrior;
+        {
+            int e;
+            mant *= frexp(fabs(st.pprec[i]), &e);
+            expo += e;
+        }
+        fc.prior_logdet = 0.5 * (log(mant) + expo * 0.6931471805599453);
         fc.prior_valid = true;
     }
     double quad = 0, trSL0 = 0;

@@ -85,10 +85,13 @@ __device__
 // from 6 to 32 spilled registers and from 15.3 to 18.4 ms per launch; as a function called per exponential, 17.3 ms.
 // The kernels therefore reach it only through recentre_precise_fn (vb_lane_kernel.h): ONE out-of-line call per
 // pointwise pass.)
-FVB_HD double exp_acc(double x)
+// table: where the kernel keeps a copy of FVB_EXP_TABLE (LDS: a read from global memory per exponential would queue
+// behind the prefetched samples of a streaming pass and its wait would drain them), or NULL = the table itself
+FVB_HD double exp_acc(double x, const double *table = nullptr)
 {
     if (!(fabs(x) < 690.0)) // overflow / underflow / NaN: the library's answer
         return exp(x);
+    const double *tbl = table ? table : FVB_EXP_TABLE;
     const double INV = 0x1.71547652b82fep+5, C_HI = 0x1.62e42fefa0000p-6, C_LO = 0x1.cf79abc9e3b3ap-45;
     const double K7 = 1.0 / 5040, K6 = 1.0 / 720, K5 = 1.0 / 120, K4 = 1.0 / 24, K3 = 1.0 / 6, K2 = 0.5;
     const double kd = rint(x * INV);
@@ -98,7 +101,7 @@ FVB_HD double exp_acc(double x)
     const double r = r_hi - r_lo;
     const double c = (r_hi - r) - r_lo; // what the subtraction rounded away
     const int j = n & 31, m = n >> 5;
-    const double t_hi = FVB_EXP_TABLE[2 * j], t_lo = FVB_EXP_TABLE[2 * j + 1];
+    const double t_hi = tbl[2 * j], t_lo = tbl[2 * j + 1];
     // p = expm1(r): r + r^2 (1/2 + r (1/6 + r (1/24 + r (1/120 + r (1/720 + r / 5040))))); remainder r^8 / 40320 < 2^-67
     const double r2 = r * r;
     double q = __builtin_fma(r, K7, K6);
@@ -129,9 +132,9 @@ FVB_HD double to_model(int tr, double val)
     }
 }
 // the same with the half-ulp exp where the transform is the exponential (the pointwise passes, see exp_acc)
-FVB_HD double to_model_acc(int tr, double val)
+FVB_HD double to_model_acc(int tr, double val, const double *table = nullptr)
 {
-    return tr == FVB_TRANSFORM_LOG ? exp_acc(val) : to_model(tr, val);
+    return tr == FVB_TRANSFORM_LOG ? exp_acc(val, table) : to_model(tr, val);
 }
 FVB_HD double to_fabber(int tr, double val)
 {
@@ -240,8 +243,12 @@ FVB_HD bool ldl_inverse(const double (&a)[P * (P + 1) / 2], double (&inv)[P * (P
     // which matters more than the flop count here: the kernels hold the whole voxel state in
     // registers while they invert.
     bool ok = true;
-    logabs = 0;
     sign = 1;
+    // log|det| = sum of log|pivot| as ONE logarithm: the pivots' mantissas are multiplied ([0.5, 1) each: no
+    // under- or overflow for P <= 16), their exponents added (round 2: a logarithm per pivot, ~60 dependent
+    // instructions each, in the kernels that evaluate F). A zero, infinite or NaN pivot comes out as log() has it.
+    double mant = 1.0;
+    int expo = 0;
 #pragma unroll
     for (int i = 0; i < P * (P + 1) / 2; i++)
         inv[i] = a[i];
@@ -253,7 +260,9 @@ FVB_HD bool ldl_inverse(const double (&a)[P * (P + 1) / 2], double (&inv)[P * (P
             ok = false;
         if (d < 0)
             sign = -sign;
-        logabs += log(fabs(d));
+        int e;
+        mant *= frexp(fabs(d), &e);
+        expo += e;
         const double rd = 1.0 / d;
 #pragma unroll
         for (int i = 0; i < P; i++)
@@ -278,6 +287,7 @@ FVB_HD bool ldl_inverse(const double (&a)[P * (P + 1) / 2], double (&inv)[P * (P
 #pragma unroll
     for (int i = 0; i < P * (P + 1) / 2; i++)
         inv[i] = -inv[i];
+    logabs = log(mant) + expo * 0.6931471805599453;
     return ok;
 }
 

@@ -42,6 +42,8 @@ struct ModelArgs
     // the host's model code computed it about the centre the caller is working with
     const double *lin;
     int32_t lin_T;
+    // the kernel's copy of the table of exp_acc (vb_math.h) in LDS, or NULL (kernels built with recentre<..., ACC>)
+    const double *exp_table;
 };
 
 // A "sweep" produces, for t = 0, 1, 2, ... in order, the 2P + 1 predictions the central
@@ -367,9 +369,9 @@ struct ExpModel
 #pragma unroll
             for (int i = 0; i < N; i++)
             {
-                e0[i] = exp_acc(-tp[2 * i + 1] * tt);
-                e2[i] = exp_acc(-tp2[2 * i + 1] * tt);
-                e3[i] = exp_acc(-tp3[2 * i + 1] * tt);
+                e0[i] = exp_acc(-tp[2 * i + 1] * tt, a.exp_table);
+                e2[i] = exp_acc(-tp2[2 * i + 1] * tt, a.exp_table);
+                e3[i] = exp_acc(-tp3[2 * i + 1] * tt, a.exp_table);
             }
         }
         FVB_HD void multiply()

@@ -102,10 +102,26 @@ struct SpatialArgs
     uint32_t *sw_counter;    // (unused by the data-flow sweep; kept for the barrier variant)
     int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the
                              // sweep, a barrier timed out): the run is repeated with the per-level launches
+    // ---- the slab sweep across DEVICES (fabber_vb_run_spatial_host_multi): a device owns a range of z-planes of the
+    // volume and holds ghost copies of the planes next to it; in sw_npos a neighbour that is a ghost BELOW the owned
+    // range reads FVB_NP_BELOW (its mean of this sweep arrives in the voxel's inbox, written by the device below), one
+    // that is a ghost ABOVE reads FVB_NP_ABOVE (it contributes the mean the last halo exchange left, and this
+    // voxel's new mean goes into ITS inbox on the device above: sw_gran_up at position sw_up_pos[pos]) ----
+    unsigned long long *sw_gran_up; // the granules of the slab above (peer-mapped memory), or NULL
+    const int32_t *sw_up_pos;       // [n_pos] position of the z+1 neighbour in the numbering of the slab above, -1 = none
+    int32_t up_n_pos;               // n_pos of the slab above
+    int32_t sl_remote;              // 1: inboxes are written by another device: system-scope accesses
     // ---- noise models other than white noise with one precision (vb_spatial_noise.h) ----
     double nz_count[4];      // noise-pattern: timepoints of each class (trace of Q_k, noisemodel_white.cc:207-225)
     int32_t locked_linear;   // locked-linear-from-mvn: the second sweep does not re-centre (inference_vb.cc:695-696)
     const double *locked_centres; // [P][V] the fixed centres (set-up re-centre, inference_vb.cc:225-232), or NULL
+};
+
+enum
+{
+    FVB_NP_NONE = -1,
+    FVB_NP_BELOW = -2,
+    FVB_NP_ABOVE = -3
 };
 
 #if defined(__HIPCC__)
@@ -230,6 +246,14 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
 {
     const KernelArgs &ka = sa.ka;
     constexpr int PT = P * (P + 1) / 2;
+    // (the table of exp_acc in LDS, see vb_math.h: every lane of the workgroup takes part, before any leaves)
+    constexpr bool ACC = Model::model_id == FVB_MODEL_EXP;
+    __shared__ double exp_tab[ACC ? 64 : 1];
+    if (ACC)
+    {
+        exp_tab[threadIdx.x] = FVB_EXP_TABLE[threadIdx.x];
+        __syncthreads();
+    }
     const int v = blockIdx.x * 64 + threadIdx.x;
     const int T = ka.cfg.n_times;
     const size_t V = (size_t)ka.cfg.n_voxels;
@@ -239,6 +263,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
     ma.iopt0 = ka.cfg.model_iopt[0];
     ma.dopt0 = ka.cfg.model_dopt[0];
     ma.design = ka.cfg.design;
+    ma.exp_table = ACC ? exp_tab : nullptr;
     VoxelState<P> st;
     Moments<P> mo;
     if (ka.cfg.init_mvn)
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
     for (int i = 0; i < P; i++)
         centre[i] = sa.locked_centres ? sa.locked_centres[(size_t)i * V + v] : st.m[i];
     // (this kernel exists for the first linearisation alone: with the half-ulp exp where the model is exponential)
-    const int status = recentre<Model, P, Model::model_id == FVB_MODEL_EXP>(ka, ma, v, centre, mo, true);
+    const int status = recentre<Model, P, ACC>(ka, ma, v, centre, mo, true);
     sa.status[v] = status ? (status | 0x100) : 0;
     sp_store_theta<P>(sa, v, st);
     sp_store_noise<P>(sa, v, st, mo);
@@ -1120,8 +1145,16 @@ struct SlabRecord
                 for (int a = 0; a < 6; a++)
                     nbr[s][a] = sa.sw_nbr[((size_t)s * 6 + a) * NP + pos];
                 const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
-                in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sa.sl_remote) // (wave-uniform)
+                {
+                    in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                else
+                {
+                    in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         alive = have ? alive_word : 0;
     }
@@ -1138,7 +1171,7 @@ __device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecor
     bool from_below = false; // (at most one neighbour)
 #pragma unroll
     for (int a = 0; a < 6; a++)
-        from_below |= (r.np[a] >= 0) && (r.np[a] < slab_begin);
+        from_below |= ((r.np[a] >= 0) && (r.np[a] < slab_begin)) || (r.np[a] == FVB_NP_BELOW);
     if (!from_below || (sa.sl_debug & 1))
         return;
     const size_t NP = (size_t)sa.n_pos;
@@ -1158,8 +1191,16 @@ __device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecor
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
-                r.in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                r.in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sa.sl_remote)
+                {
+                    r.in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    r.in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                else
+                {
+                    r.in_lo[s] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    r.in_hi[s] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
 }
@@ -1199,7 +1240,7 @@ __device__ __forceinline__ void slab_step(const SpatialArgs &sa, SlabRecord<P, N
 #pragma unroll
             for (int a = 0; a < 6; a++)
             {
-                const bool below = (r.np[a] >= 0) && (r.np[a] < slab_begin);
+                const bool below = ((r.np[a] >= 0) && (r.np[a] < slab_begin)) || (r.np[a] == FVB_NP_BELOW);
                 contrib += in_prev[a] ? from_lds[a] : (below ? val_in : r.nbr[s][a]);
             }
             const double spatial_mean = contrib * r.rec[s];
@@ -1232,13 +1273,25 @@ __device__ __forceinline__ void slab_store(const SpatialArgs &sa, const SlabReco
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
     int above = -1;
+    bool ghost_above = false;
 #pragma unroll
     for (int a = 0; a < 6; a++)
+    {
         above = (r.np[a] >= slab_end) ? r.np[a] : above;
+        ghost_above |= (r.np[a] == FVB_NP_ABOVE);
+    }
+    const int up = (ghost_above && sa.sw_gran_up) ? sa.sw_up_pos[pos] : -1;
 #pragma unroll
     for (int s = 0; s < NS; s++)
         if (s < ns)
         {
+            if (up >= 0) // the z+1 neighbour lives on the device above: its inbox there
+            {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(m[s]);
+                unsigned long long *g = sa.sw_gran_up + ((size_t)s * (size_t)sa.up_n_pos + up) * 2;
+                __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (above >= 0)
             {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(m[s]);
@@ -1386,6 +1439,12 @@ template <class Model, int P, bool NEEDF, bool FAST = false, bool ACC = false>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(const SpatialArgs sa)
 {
     const KernelArgs &ka = sa.ka;
+    __shared__ double exp_tab[ACC ? 64 : 1]; // (the table of exp_acc in LDS, see vb_math.h)
+    if (ACC)
+    {
+        exp_tab[threadIdx.x] = FVB_EXP_TABLE[threadIdx.x];
+        __syncthreads();
+    }
     const int v = sa.owned_begin + blockIdx.x * 64 + threadIdx.x;
     if (v >= sa.owned_end)
         return;
@@ -1395,6 +1454,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_noise_kernel(c
     ma.iopt0 = ka.cfg.model_iopt[0];
     ma.dopt0 = ka.cfg.model_dopt[0];
     ma.design = ka.cfg.design;
+    ma.exp_table = ACC ? exp_tab : nullptr;
     VoxelState<P> st;
     Moments<P> mo;
     sp_load<P>(sa, v, st, mo);

@@ -175,15 +175,32 @@ struct DevMem
 {
     void *p = nullptr;
     hipStream_t stream = nullptr;
+    bool plain = false; // hipMalloc'ed (fine-grained memory another device writes into), not from the pool
     ~DevMem()
     {
         reset();
     }
     void reset()
     {
-        if (p)
+        if (p && plain)
+            (void)hipFree(p);
+        else if (p)
             (void)hipFreeAsync(p, stream);
         p = nullptr;
+        plain = false;
+    }
+    // memory that a kernel on ANOTHER device writes while a kernel on this one polls it (the inboxes of the slab sweep
+    // across devices): fine-grained, i.e. not held in this device's L2 between the polls
+    hipError_t alloc_fine(size_t bytes)
+    {
+        plain = true;
+        hipError_t e = hipExtMallocWithFlags(&p, bytes ? bytes : 8, hipDeviceMallocFinegrained);
+        if (e != hipSuccess)
+        {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes ? bytes : 8);
+        }
+        return e;
     }
     hipError_t alloc(size_t bytes, hipStream_t s = nullptr)
     {
@@ -424,6 +441,13 @@ struct fvb_spatial_run
     double t_geometry_ms = 0, t_neighbours_ms = 0;
     // the split first sweep (vb_spatial.h): whole-volume runs with first-neighbour priors (types M, m)
     bool allow_fast = false, fast = false;
+    bool multi_fast = false; // one of several slabs on several devices that sweep together (fabber_vb_run_spatial_host_multi)
+    DevMem d_up_pos;
+    std::vector<int32_t> h_pos_of; // (multi_fast: the numbering, for the slab below to address this slab's inboxes)
+    int fast_prep(int it);
+    int fast_sweep();
+    int fast_noise(int it);
+    int link_up(fvb_spatial_run &upper, int global_first, int upper_global_first);
     std::vector<int32_t> level_begin_counts; // voxels per level
     DevMem d_pos_of, d_level_pos, d_level_count, d_sw_f64, d_sw_i32, d_sw_sync, d_sw_gran, d_slab_first;
     int max_runs_per_slab = 0;
@@ -680,7 +704,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     for (int kk = 0; kk < P; kk++)
         if (cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M)
             spatial_param[n_spatial++] = kk;
-    const bool eligible = allow_fast && has_spatial && !second_neighbours && owned_begin == 0 && owned_end == V && n_owned > 0
+    const bool whole = owned_begin == 0 && owned_end == V;
+    const bool eligible = allow_fast && has_spatial && !second_neighbours && (whole || multi_fast) && n_owned > 0
         && !getenv("FVB_SPATIAL_PER_LEVEL");
     std::vector<int32_t> pos_of, level_pos, level_count, slab_first;
     int n_pos = 0, sl_width = 64, sl_max_run = 0, sl_dz = 0;
@@ -694,7 +719,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         // latency: measured at 128^3, 0.51 ms per sweep with dz = 1, 0.65 with 2, 0.94 with 3, 1.04 with 4.
         // (with the co-ordinates on the device - the usual case - the numbering is three small kernels there; the
         // host does it with its threads otherwise: 3 ms at 128^3 against 0.2)
-        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING");
+        // (a slab with ghost planes is numbered on the host: the device kernels number every local voxel)
+        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING") && whole;
         int zmin = Z[owned_begin], zmax = Z[owned_begin];
         if (on_dev)
         {
@@ -800,7 +826,17 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     if (!slab_form)
         build_level_order();
-    fast = slab_form || (eligible && level_begin.size() <= 6000); // (the data-flow sweep keeps the level table in LDS)
+    fast = slab_form || (eligible && whole && level_begin.size() <= 6000); // (the data-flow sweep keeps the level table in LDS)
+    if (slab_form && !whole)
+    {
+        // ghosts have no position: what stands in sw_npos for them says where their mean comes from (vb_spatial.h)
+        for (int v = 0; v < owned_begin; v++)
+            pos_of[(size_t)v] = FVB_NP_BELOW;
+        for (int v = owned_end; v < V; v++)
+            pos_of[(size_t)v] = FVB_NP_ABOVE;
+    }
+    if (multi_fast)
+        h_pos_of = pos_of;
     if (fast && !slab_form)
     {
         // level-major numbering for the data-flow sweep
@@ -898,8 +934,12 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64, stream));
         FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * 7 * NP, stream)); // npos [6][NP], alive [NP]
         FVB_HIP_CHECK(d_sw_sync.alloc(64, stream));                      // counter, flags[2]
-        FVB_HIP_CHECK(d_sw_gran.alloc(sizeof(unsigned long long) * 2 * ns * NP, stream));
+        if (multi_fast)
+            FVB_HIP_CHECK(d_sw_gran.alloc_fine(sizeof(unsigned long long) * 2 * ns * NP));
+        else
+            FVB_HIP_CHECK(d_sw_gran.alloc(sizeof(unsigned long long) * 2 * ns * NP, stream));
         FVB_HIP_CHECK(hipMemsetAsync(d_sw_gran.p, 0, sizeof(unsigned long long) * 2 * ns * NP, stream));
+        sa.sl_remote = multi_fast ? 1 : 0;
         sa.sw_gran = (unsigned long long *)d_sw_gran.p;
         sa.sw_serial = 0;
         FVB_HIP_CHECK(hipMemsetAsync(d_sw_i32.p, 0, sizeof(int32_t) * 7 * NP, stream));
@@ -1020,25 +1060,81 @@ int fvb_spatial_run::sweep_noise(int it)
 }
 
 // One iteration's first and second sweep with the split first sweep (see vb_spatial.h)
-int fvb_spatial_run::sweep_fast(int it)
+// the three launches of an iteration with the slab form of the split sweep, one by one (a run of several slabs on several
+// devices puts its exchanges between them; one device runs them back to back: sweep_fast)
+int fvb_spatial_run::fast_prep(int it)
 {
     sa.it = it;
     sa.sw_serial++; // this sweep's number
     const int n_owned = owned_end - owned_begin;
     // (a multiple of 8 workgroups: the kernel deals them out to the XCDs in contiguous eighths of the voxel list)
     hipLaunchKernelGGL(k.prep, dim3((unsigned)(((n_owned + 63) / 64 + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int fvb_spatial_run::fast_sweep()
+{
     const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
+    // one workgroup of 1024 lanes per slab (at most 224: resident together on any MI355X)
+    const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
+    if (lds > 48 * 1024)
+        FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k.slab_sweep[which], dim3((unsigned)sa.n_slabs), dim3(1024), lds, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int fvb_spatial_run::fast_noise(int it)
+{
+    sa.it = it;
+    const int n_owned = owned_end - owned_begin;
+    hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
+    FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// This slab's top plane hands its new means to the bottom plane of `upper` (another device, or another stream of this
+// one): where in upper's granule array the inbox of every top-plane voxel's z+1 neighbour is. global_first = the global
+// index of this slab's local voxel 0 (upper_global_first: of upper's).
+int fvb_spatial_run::link_up(fvb_spatial_run &upper, int global_first, int upper_global_first)
+{
+    std::vector<int32_t> nn((size_t)V * 6);
+    FVB_HIP_CHECK(hipMemcpyAsync(nn.data(), d_nn.p, sizeof(int32_t) * nn.size(), hipMemcpyDeviceToHost, stream));
+    FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<int32_t> up_pos((size_t)sa.n_pos, -1);
+    for (int v = owned_begin; v < owned_end; v++)
+        for (int a = 0; a < 6; a++)
+        {
+            const int u = nn[(size_t)v * 6 + a];
+            if (u < owned_end)
+                continue; // (none, or not a ghost above)
+            const long long in_upper = (long long)global_first + u - upper_global_first;
+            if (in_upper < upper.owned_begin || in_upper >= upper.owned_end)
+                return api_fail(-49, "slab decomposition: a ghost voxel is not owned by the slab above");
+            up_pos[(size_t)h_pos_of[(size_t)v]] = upper.h_pos_of[(size_t)in_upper];
+        }
+    FVB_HIP_CHECK(d_up_pos.alloc(sizeof(int32_t) * up_pos.size(), stream));
+    FVB_HIP_CHECK(hipMemcpyAsync(d_up_pos.p, up_pos.data(), sizeof(int32_t) * up_pos.size(), hipMemcpyHostToDevice, stream));
+    sa.sw_up_pos = (const int32_t *)d_up_pos.p;
+    sa.sw_gran_up = upper.sa.sw_gran;
+    sa.up_n_pos = upper.sa.n_pos;
+    FVB_HIP_CHECK(hipMemcpyAsync(d_sa.p, &sa, sizeof(SpatialArgs), hipMemcpyHostToDevice, stream));
+    FVB_HIP_CHECK(hipStreamSynchronize(stream)); // (up_pos is a local)
+    return 0;
+}
+
+int fvb_spatial_run::sweep_fast(int it)
+{
     if (slab_form)
     {
-        // one workgroup of 1024 lanes per slab (at most 224: resident together on any MI355X)
-        const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
-        if (lds > 48 * 1024)
-            FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k.slab_sweep[which], dim3((unsigned)sa.n_slabs), dim3(1024), lds, stream, sa);
-        hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
-        FVB_HIP_CHECK(hipGetLastError());
-        return 0;
+        int rc = fast_prep(it);
+        if (rc == 0)
+            rc = fast_sweep();
+        return rc ? rc : fast_noise(it);
     }
+    sa.it = it;
+    sa.sw_serial++; // this sweep's number
+    const int n_owned = owned_end - owned_begin;
+    hipLaunchKernelGGL(k.prep, dim3((unsigned)(((n_owned + 63) / 64 + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
     // few workgroups, all resident at once on any MI355X (256 CUs): the level barrier is a counter
     const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
     const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane
@@ -1576,7 +1672,23 @@ int slab_transfer(SlabRun &from, int v_from, SlabRun &to, int v_to, int n, int P
 }
 } // namespace
 
+static thread_local bool s_multi_no_fast = false;
+
+static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int));
+
 int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int))
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t rc = run_spatial_host_multi_impl(cfg, sp, data, out, devices, n_devices, progress_cb);
+    if (getenv("FVB_SPATIAL_TIMING"))
+        fprintf(stderr, "[fvb spatial] fabber_vb_run_spatial_host_multi: %.1f ms in all\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
+}
+
+static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
     const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int))
 {
     int rc = api_validate(cfg, true);
@@ -1625,6 +1737,14 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         has_spatial |= cfg->prior_type[k] >= FVB_PRIOR_SPATIAL_M;
     }
     const int halo = second ? 2 : 1;
+    const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    // all slabs sweep together with the slab form of the split sweep (first-neighbour priors; vb_spatial.h) unless
+    // that was tried and abandoned (s_multi_no_fast) or FVB_SPATIAL_PER_LEVEL asks for the level-chunk pipeline
+    const bool try_fast = has_spatial && !second && !s_multi_no_fast && !getenv("FVB_SPATIAL_PER_LEVEL") && !getenv("FVB_SPATIAL_MULTI_PIPELINE");
     // ---- the slabs: cuts on z-plane boundaries, balanced by voxel count; fewer slabs if the planes do not go round ----
     std::vector<int> plane_start;
     for (int v = 0; v < V; v++)
@@ -1757,10 +1877,133 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         sl.sp.owned_end = sl.e - sl.g0;
         sl.sp.n_voxels_global = V;
         sl.run = new fvb_spatial_run;
+        sl.run->allow_fast = sl.run->multi_fast = try_fast;
         if ((rc = sl.run->open(&sl.d, &sl.sp, sl.b_data.p, &sl.dout, st)) != 0)
             return rc;
     }
-    // ---- the global level range and the pipeline's ticks ----
+    const double ms_open = since(t_begin);
+    const auto t_loop = std::chrono::steady_clock::now();
+    // ---- all slabs sweep together: every slab's top plane writes into the inboxes of the slab above ----
+    bool all_fast = try_fast;
+    for (int r = 0; r < world; r++)
+        all_fast = all_fast && slabs[r]->run->slab_form;
+    if (try_fast && !all_fast) // (a slab the slab form does not take: the level-chunk pipeline for the whole run)
+    {
+        slabs.clear();
+        s_multi_no_fast = true;
+        rc = fabber_vb_run_spatial_host_multi(cfg, sp, data, out, devices, n_devices, progress_cb);
+        s_multi_no_fast = false;
+        return rc;
+    }
+    if (all_fast)
+    {
+        for (int r = 0; r + 1 < world; r++)
+        {
+            FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+            if (slabs[r]->dev != slabs[r + 1]->dev)
+            {
+                hipError_t e = hipDeviceEnablePeerAccess(slabs[r + 1]->dev, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return api_fail(-100 - (int)e, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+            if ((rc = slabs[r]->run->link_up(*slabs[r + 1]->run, slabs[r]->g0, slabs[r + 1]->g0)) != 0)
+                return rc;
+        }
+        std::vector<double> partials_f, sums_f((size_t)P * 2);
+        for (int it = 0; it < cfg->max_iterations; it++)
+        {
+            if (progress_cb)
+                progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
+            if (has_spatial && (it > 0 || sp->update_first_iter))
+            {
+                std::fill(sums_f.begin(), sums_f.end(), 0.0);
+                for (int r = 0; r < world; r++)
+                {
+                    SlabRun &sl = *slabs[r];
+                    FVB_HIP_CHECK(hipSetDevice(sl.dev));
+                    partials_f.assign((size_t)std::max(sl.run->n_segments, 1) * P * 2, 0.0);
+                    if ((rc = sl.run->ak_segment_sums(partials_f.data())) != 0)
+                        return rc;
+                    for (int seg = 0; seg < sl.run->n_segments; seg++)
+                        for (int j = 0; j < 2 * P; j++)
+                            sums_f[j] = sums_f[j] + partials_f[(size_t)seg * 2 * P + j];
+                }
+                for (int r = 0; r < world; r++)
+                {
+                    FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                    if ((rc = slabs[r]->run->set_ak_sums(sums_f.data())) != 0)
+                        return rc;
+                }
+            }
+            // records of every slab, then ALL slabs' ordered sweeps at once (slab r + 1's lowest plane waits, voxel by
+            // voxel, for what slab r's highest plane puts into its inboxes), then the second sweep
+            for (int r = 0; r < world; r++)
+            {
+                FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                if ((rc = slabs[r]->run->fast_prep(it)) != 0)
+                    return rc;
+            }
+            for (int r = 0; r < world; r++)
+            {
+                FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                if ((rc = slabs[r]->run->fast_sweep()) != 0)
+                    return rc;
+            }
+            if (cfg->need_f) // the F term of the priors of the LAST voxel of the sweep is the last slab's
+            {
+                double fp = 0;
+                FVB_HIP_CHECK(hipSetDevice(slabs[world - 1]->dev));
+                if ((rc = fabber_vb_spatial_fprior(slabs[world - 1]->run, &fp, 0)) != 0)
+                    return rc;
+                for (int r = 0; r + 1 < world; r++)
+                {
+                    FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                    if ((rc = fabber_vb_spatial_fprior(slabs[r]->run, &fp, 1)) != 0)
+                        return rc;
+                }
+            }
+            for (int r = 0; r < world; r++)
+            {
+                FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+                if ((rc = slabs[r]->run->fast_noise(it)) != 0)
+                    return rc;
+            }
+            if (has_spatial)
+                for (int r = 0; r + 1 < world; r++) // boundary planes both ways (the ghosts' means for the next iteration)
+                {
+                    SlabRun &lo = *slabs[r], &hi = *slabs[r + 1];
+                    const int up_from = std::max(lo.b, hi.g0);
+                    if ((rc = slab_transfer(lo, up_from - lo.g0, hi, up_from - hi.g0, lo.e - up_from, P)) != 0)
+                        return rc;
+                    const int down_to = std::min(hi.e, lo.g1);
+                    if ((rc = slab_transfer(hi, hi.b - hi.g0, lo, hi.b - lo.g0, down_to - hi.b, P)) != 0)
+                        return rc;
+                }
+        }
+        bool any_failed = false;
+        for (int r = 0; r < world; r++)
+        {
+            bool failed = false;
+            FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+            if ((rc = slabs[r]->run->fast_failed(failed)) != 0)
+                return rc;
+            any_failed |= failed;
+        }
+        if (any_failed)
+        {
+            // a voxel failed during a first sweep (or an inbox never arrived): as on one device, the run is repeated
+            // with the launches the split sweep does not need - here the level-chunk pipeline
+            if (getenv("FVB_SPATIAL_VERBOSE"))
+                fprintf(stderr, "[fvb spatial] slab sweep across devices abandoned, repeating the run with the level-chunk pipeline\n");
+            slabs.clear();
+            s_multi_no_fast = true;
+            rc = fabber_vb_run_spatial_host_multi(cfg, sp, data, out, devices, n_devices, progress_cb);
+            s_multi_no_fast = false;
+            return rc;
+        }
+    }
+    // ---- (otherwise) the global level range and the pipeline's ticks ----
     const long long w0 = slabs[0]->run->level_w[0], w1 = slabs[0]->run->level_w[1], w2 = slabs[0]->run->level_w[2];
     long long lmin = LLONG_MAX, lmax = LLONG_MIN;
     for (int v = 0; v < V; v++)
@@ -1774,7 +2017,7 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         chunk_levels = std::max(1, atoi(forced));
     const long long nchunks = std::max(1LL, (lmax - lmin + chunk_levels) / chunk_levels);
     std::vector<double> partials, sums((size_t)P * 2);
-    for (int it = 0; it < cfg->max_iterations; it++)
+    for (int it = 0; it < (all_fast ? 0 : cfg->max_iterations); it++)
     {
         if (progress_cb)
             progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
@@ -1858,6 +2101,13 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
     // ---- results: every slab packs its voxels, the owned ones go to the caller's images ----
     for (int r = 0; r < world; r++)
     {
+        FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
+        FVB_HIP_CHECK(hipStreamSynchronize(slabs[r]->stream));
+    }
+    const double ms_loop = since(t_loop);
+    const auto t_out = std::chrono::steady_clock::now();
+    for (int r = 0; r < world; r++)
+    {
         SlabRun &sl = *slabs[r];
         FVB_HIP_CHECK(hipSetDevice(sl.dev));
         if ((rc = sl.run->finish()) != 0)
@@ -1875,6 +2125,13 @@ int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatia
         if (sl.dout.iterations)
             FVB_HIP_CHECK(download_rows(out->iterations, sl.dout.iterations, sizeof(int32_t), 1));
     }
+    const double ms_out = since(t_out);
+    const auto t_free = std::chrono::steady_clock::now();
+    slabs.clear();
+    if (timing)
+        fprintf(stderr, "[fvb spatial] %d slabs (%s): upload + geometry + set-up %.1f ms, %d iterations %.1f ms, results %.1f ms, "
+                        "giving the slabs' memory back %.1f ms\n", world,
+            all_fast ? "all slabs sweep together" : "level-chunk pipeline", ms_open, cfg->max_iterations, ms_loop, ms_out, since(t_free));
     return 0;
 }
 

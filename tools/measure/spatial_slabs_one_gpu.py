@@ -11,11 +11,16 @@ its = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 h, coords, y, _ = cases.c5_problem((n, n, n), max_iterations=its)
 sp = vbabi.SpatialHolder(coords)
 ref = hiplib.run_spatial_host(h, sp, y)
+t0 = time.perf_counter()
+ref = hiplib.run_spatial_host(h, sp, y)
+print("1 device: %.1f ms (the same Python call: result arrays allocated and filled inside it)" % ((time.perf_counter() - t0) * 1e3), flush=True)
 for devs in ([0, 0], [0, 0, 0], [0, 0, 0, 0], [0] * 8):
+    hiplib.run_spatial_host(h, sp, y, devices=devs)
     t0 = time.perf_counter()
     r = hiplib.run_spatial_host(h, sp, y, devices=devs)
+    ms = (time.perf_counter() - t0) * 1e3
     same = np.array_equal(ref["mvn"], r["mvn"], equal_nan=True)
-    print(len(devs), "slabs: %.1f ms" % ((time.perf_counter() - t0) * 1e3), "identical" if same else "DIFFERENT", flush=True)
+    print(len(devs), "slabs: %.1f ms" % ms, "identical" if same else "DIFFERENT", flush=True)
     if not same:
         bad = np.flatnonzero(np.any(ref["mvn"] != r["mvn"], axis=0))
         z = coords[2][bad]
