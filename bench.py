@@ -85,7 +85,9 @@ def pmc_profile(workload, V, kernel, args, kernel_ms):
     tools/pmc_calib on the kernels' own access widths; the fp64 instruction counters and GRBM_GUI_ACTIVE in a third).
     Counters cannot be read from inside the timed run, so the figures are attached only when the committed profile
     is of the same workload, size, kernel and default engine settings; rates use the LIVE kernel time."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
+    path = os.path.join(ROOT, "profiles", "r3_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r2_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
     if not os.path.exists(path) or V != WORKLOADS[workload]["voxels"] or args.variant != "auto" \
             or args.residual != "auto" or args.residual_tol is not None:
         return {"traffic": None}
@@ -153,7 +155,19 @@ def bench_spatial(args, world, rank, device):
                 "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dev_ms,
                 "note": "device time of one run between HIP events (all its kernels; the host builds no tables in between); "
-                        "per-kernel durations: profiles/r2_kernel_stats_c5.csv"}
+                        "per-kernel durations: profiles/r3_kernel_stats_c5.csv"}
+    # HBM bytes of one run from the committed counter passes of this very command (tools/r3_profiles.sh ->
+    # tools/pmc_c5_merge.py): attached when the profile is of the same problem
+    pmc = os.path.join(ROOT, "profiles", "r3_pmc_c5.json")
+    if os.path.exists(pmc) and n == w["grid"] and not args.need_f:
+        prof = json.load(open(pmc))
+        roofline["traffic"] = prof["per_run"]["traffic"]
+        roofline["traffic_detail"] = {"source": "profiles/r3_pmc_c5.json", "fetch_bytes": prof["per_run"]["fetch_bytes"],
+                                      "write_bytes": prof["per_run"]["write_bytes"],
+                                      "profiled_kernel_ms": prof["per_run"]["kernel_ms"],
+                                      "by_kernel_gb": {k: (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_run"] / 1e9
+                                                       for k, v in prof["kernels"].items()},
+                                      "note": prof["per_run"]["note"]}
     cpu = None
     if args.cpu_sample > 0:
         import oracle

@@ -5,11 +5,13 @@
 // There is no CPU path.
 #include "inference_nlls.h"
 
+#include "host_model.h"
 #include "version.h"
 
 #include "../../../include/fabber_vb.h"
 
 #include <cstring>
+#include <memory>
 
 using namespace std;
 
@@ -22,11 +24,14 @@ struct NLLSInferenceTechnique::EngineStorage
     Matrix design;
     vector<unsigned char> phi_index;
     vector<Parameter> params;
+    bool host_model = false;
 };
 
 static OptionSpec NLLS_OPTIONS[] = {
     { "vb-init", OPT_BOOL, "Whether NLLS is being run in isolation or as a pre-step for VB", OPT_NONREQ, "" },
     { "lm", OPT_BOOL, "Whether to use LM convergence (default is L)", OPT_NONREQ, "" },
+    { "host-model-threads", OPT_INT, "Host threads evaluating a host-side model (0 = as many as the hardware has, at most 16)", OPT_NONREQ, "0" },
+    { "host-model", OPT_BOOL, "Evaluate the forward model on the host even if it has a device body (always the case for models from a model library)", OPT_NONREQ, "" },
     { "" },
 };
 
@@ -116,9 +121,15 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
         throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters are not supported by the MI355X engine");
     cfg.n_params = P;
     DeviceModelSpec spec;
-    if (!m_model->GetDeviceModel(spec))
-        throw FabberInternalError("method=nlls needs a forward model with a device body (FwdModel::GetDeviceModel); "
-                                  "models from a model library run with method=vb");
+    // A model without a device body (any model library written for the reference), or any model when host-model is
+    // set, is evaluated on the host - the minimiser's iterations stay on the GPU (fabber_nlls_run_hostmodel_host).
+    const bool device_model = m_model->GetDeviceModel(spec) && !rundata.GetBool("host-model");
+    if (!device_model)
+    {
+        spec = DeviceModelSpec();
+        spec.model = FVB_MODEL_HOSTJAC;
+    }
+    st.host_model = !device_model;
     cfg.model = spec.model;
     for (int i = 0; i < 4; i++)
     {
@@ -169,7 +180,21 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
     out.iterations = iterations.data();
     LOG << "NLLSInferenceTechnique::Calculations on the MI355X engine, " << V << " voxels x " << cfg.n_times << " timepoints, "
         << (m_lm ? "Levenberg-Marquardt" : "Levenberg") << " damping" << endl;
-    const int rc = fabber_nlls_run_host(&cfg, &nl, series, &out, rundata.GetIntDefault("device", 0, 0));
+    const int device = rundata.GetIntDefault("device", 0, 0);
+    int rc;
+    if (device_model)
+        rc = fabber_nlls_run_host(&cfg, &nl, series, &out, device);
+    else
+    {
+        HostModelContext ctx = { this, m_model, &rundata, NULL, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
+        std::vector<std::unique_ptr<FwdModel> > copies;
+        const int nthreads = host_model_instances(ctx, copies, m_model, rundata, m_log);
+        LOG << "NLLSInferenceTechnique::The model is evaluated on the host, " << nthreads << " thread(s)" << endl;
+        series = engine_series(rundata, true, cfg.data_f64, series_rows, series_cols); // (the models read the Matrix form)
+        rc = fabber_nlls_run_hostmodel_host(&cfg, &nl, series, &out, device, &host_model_linearise, &ctx);
+        if (rc == -54 && ctx.error != "")
+            throw FabberInternalError(ctx.error);
+    }
     if (rc != 0)
         throw FabberInternalError(string("MI355X engine failed: ") + fabber_vb_last_error());
     rundata.Progress(V, V);
@@ -197,5 +222,5 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
 
 void NLLSInferenceTechnique::SaveResults(FabberRunData &rundata) const
 {
-    SaveEngineResults(rundata, m_store->cfg, m_store->params, 0, 0, false);
+    SaveEngineResults(rundata, m_store->cfg, m_store->params, 0, 0, m_store->host_model);
 }

@@ -12,6 +12,7 @@
 
 #include "convergence.h"
 #include "priors.h"
+#include "host_model.h"
 #include "version.h"
 
 #include "../../../include/fabber_vb.h"
@@ -378,16 +379,6 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
 }
 
 // ---- host-evaluated models ----------------------------------------------------------------------
-struct HostModelContext
-{
-    Vb *self;
-    FwdModel *model;
-    FabberRunData *rundata;
-    const Matrix *data, *coords, *suppdata;
-    int T, P;
-    string error;
-    std::vector<FwdModel *> models; // [0] = the technique's own instance, the rest are per-thread copies
-};
 
 // The initial posterior of every voxel as an MVN image (FwdModel::GetInitialPosterior needs the
 // voxel's data, fwdmodel.cc:284-313; noise from the noise model's initial posterior)
@@ -439,6 +430,28 @@ void Vb::BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg)
     cfg.init_mvn = img.Store();
 }
 
+// one model instance per host thread (host-model-threads, default: the hardware's, at most 16): a FwdModel holds the
+// current voxel's data, so instances cannot be shared
+int host_model_instances(HostModelContext &ctx, std::vector<std::unique_ptr<FwdModel> > &copies, FwdModel *model, FabberRunData &rundata,
+    EasyLog *log)
+{
+    int nthreads = rundata.GetIntDefault("host-model-threads", 0, 0, 256);
+    if (nthreads == 0)
+        nthreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+    ctx.models.push_back(model);
+    for (int k = 1; k < nthreads; k++)
+    {
+        copies.emplace_back(FwdModel::NewFromName(rundata.GetString("model")));
+        copies.back()->SetLogger(log);
+        copies.back()->Initialize(rundata);
+        vector<Parameter> tmp;
+        copies.back()->GetParameters(rundata, tmp); // resolves the transforms EvaluateFabber applies
+        ctx.models.push_back(copies.back().get());
+    }
+    ctx.data = &rundata.GetMainVoxelData();
+    return nthreads;
+}
+
 // LinearizedFwdModel::ReCentre (fwdmodel_linear.cc:126-182) for active voxels [a0, a1) with one model instance
 static void linearise_range(HostModelContext &cx, FwdModel *model, int a0, int a1, const int32_t *ids, const double *means, double *lin)
 {
@@ -484,6 +497,11 @@ static void linearise_range(HostModelContext &cx, FwdModel *model, int a0, int a
 // fvb_linearise_fn: the active voxels shared out over the host threads, one model instance each
 // (a FwdModel holds the current voxel's data, so instances cannot be shared)
 int32_t Vb::LineariseCallback(void *user, int32_t n_active, const int32_t *ids, const double *means, double *lin)
+{
+    return host_model_linearise(user, n_active, ids, means, lin);
+}
+
+int32_t host_model_linearise(void *user, int32_t n_active, const int32_t *ids, const double *means, double *lin)
 {
     HostModelContext &cx = *static_cast<HostModelContext *>(user);
     const int nthreads = std::max(1, std::min((int)cx.models.size(), n_active / 64 + 1));
@@ -601,21 +619,8 @@ void Vb::DoCalculations(FabberRunData &rundata)
     HostModelContext ctx = { this, m_model, &rundata, NULL, &coords, &rundata.GetVoxelSuppData(), cfg.n_times, cfg.n_params, "", {} };
     std::vector<std::unique_ptr<FwdModel> > copies;
     auto prepare_host_model = [&]() {
-        int nthreads = rundata.GetIntDefault("host-model-threads", 0, 0, 256);
-        if (nthreads == 0)
-            nthreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-        ctx.models.push_back(m_model);
-        for (int k = 1; k < nthreads; k++)
-        {
-            copies.emplace_back(FwdModel::NewFromName(rundata.GetString("model")));
-            copies.back()->SetLogger(m_log);
-            copies.back()->Initialize(rundata);
-            vector<Parameter> tmp;
-            copies.back()->GetParameters(rundata, tmp); // resolves the transforms EvaluateFabber applies
-            ctx.models.push_back(copies.back().get());
-        }
+        const int nthreads = host_model_instances(ctx, copies, m_model, rundata, m_log);
         LOG << "Vb::Model evaluations on " << nthreads << " host thread(s)" << endl;
-        ctx.data = &rundata.GetMainVoxelData();
         series = engine_series(rundata, true, cfg.data_f64, series_rows, series_cols);
     };
     if (m_locked_linear)

@@ -1017,6 +1017,10 @@ double fabber_vb_digamma(double x)
 {
     return digamma(x);
 }
+double fabber_vb_exp_acc(double x) // (the host twin of the kernels' half-ulp exp, for tests/test_math_host.py)
+{
+    return exp_acc(x);
+}
 double fabber_vb_transform(int32_t which, int32_t tr, double x)
 {
     switch (which)

@@ -263,7 +263,7 @@ __device__ __forceinline__ void exact_residual_ar_feed(const KernelArgs &ka, con
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
-            FVB_NO_CONTRACT
+            FVB_MODEL_FP
             Jd += J[i] * nd[i];
         }
         const double k = y_cur - g + Jd;

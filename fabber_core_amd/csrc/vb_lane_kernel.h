@@ -762,7 +762,7 @@ __device__ __forceinline__ double exact_residual(
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
-            FVB_NO_CONTRACT
+            FVB_MODEL_FP
             Jd += J[i] * nd[i];
         }
         const bool unmasked = phi_index ? (phi_index[t] != 255) : true;
@@ -840,7 +840,7 @@ __device__ __forceinline__ double rescue_residual(const KernelArgs &ka, const Mo
 #pragma unroll
                     for (int i = 0; i < P; i++)
                     {
-                        FVB_NO_CONTRACT
+                        FVB_MODEL_FP
                         Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
                     }
                     const double k = y - g + Jd;
@@ -1043,7 +1043,7 @@ __device__ __forceinline__ double rescue_tiles(const KernelArgs &ka, const Model
 #pragma unroll
             for (int i = 0; i < P; i++)
             {
-                FVB_NO_CONTRACT
+                FVB_MODEL_FP
                 Jd += ((f2[i] - f3[i]) * rden[i]) * nd[i];
             }
             const double k = y - g + Jd;

@@ -274,7 +274,7 @@ __device__ __forceinline__ void exact_residual_pattern(const KernelArgs &ka, con
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
-            FVB_NO_CONTRACT
+            FVB_MODEL_FP
             Jd += J[i] * nd[i];
         }
         const double r = y_cur - g + Jd;

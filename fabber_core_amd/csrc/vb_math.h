@@ -25,8 +25,12 @@ constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
 FVB_HD bool is_finite(double x)
 {
-    // the reference's test "0 * x == 0 * x" (fwdmodel_linear.cc:134,174)
-    return (x - x) == 0.0;
+    // the reference's test "0 * x == 0 * x" (fwdmodel_linear.cc:134,174): false for NaN and the infinities. Asked of
+    // the value's class, not computed as x - x == 0: where x is a product and contraction is allowed the compiler
+    // turns x - x into fma(a, b, -x), the product's rounding error, which is not zero (gfx950 fuses across several
+    // uses of the product) - every Jacobian entry of the wave kernel read "not finite" when its quotient was first
+    // compiled with contraction (round 3).
+    return __builtin_isfinite(x);
 }
 
 // ---- exp to half an ulp ------------------------------------------------------------------------------------------
@@ -82,9 +86,10 @@ __device__
       };
 // (Inlined into the lane kernels at its 30 sites - the transforms of a re-centre's prologue, the pointwise pass - its
 // constants and temporaries stayed live across the streaming loop, which has no register to spare: lane<exp,4> went
-// from 6 to 32 spilled registers and from 15.3 to 18.4 ms per launch; as a function called per exponential, 17.3 ms.
-// The kernels therefore reach it only through recentre_precise_fn (vb_lane_kernel.h): ONE out-of-line call per
-// pointwise pass.)
+// from 6 to 32 spilled registers and from 15.3 to 18.4 ms per launch; as a function called per exponential, 17.3 ms;
+// as one out-of-line pointwise pass, 17.8. The kernels therefore use it only in instances that exist for pointwise
+// linearisations alone: recentre<Model, P, ACC = true> in the spatial set-up kernel and in the second-sweep kernel
+// of a spatial run's first iteration; profiles/r3_exp_accuracy.md.)
 // table: where the kernel keeps a copy of FVB_EXP_TABLE (LDS: a read from global memory per exponential would queue
 // behind the prefetched samples of a streaming pass and its wait would drain them), or NULL = the table itself
 FVB_HD double exp_acc(double x, const double *table = nullptr)

@@ -81,6 +81,8 @@ struct SpatialArgs
     double *sw_sig;          // [n_spatial][P][n_pos] the spatial parameters' rows of Sigma
     int32_t *sw_npos;        // [6][n_pos] positions of the live first neighbours, -1 = none
     int32_t *sw_alive;       // [n_pos] 1 = the voxel takes part in the sweep
+    int32_t *sw_npos2;       // types P, p: [36][n_pos] positions of the live second neighbours in list order - slot
+                             // a * 6 + b = neighbour b of neighbour a (priors.cc:377-385) -, -1 = none; else NULL
     const int32_t *sw_level_pos;   // [n_levels] first position of a level
     const int32_t *sw_level_count; // [n_levels] voxels in it
     int32_t n_levels;
@@ -196,6 +198,19 @@ __device__ __forceinline__ void sp_store_noise(const SpatialArgs &sa, int v, con
     for (int i = 0; i < L::PT; i++)
         p[(size_t)(L::A + i) * V] = mo.A[i];
     p[(size_t)L::S * V] = mo.s;
+}
+
+// SpatialPrior::ApplyToMVN with second neighbours (types P, p; priors.cc:441-482), the two expressions every form
+// of the first sweep shares (written with explicit fused operations so that they round the same everywhere):
+//   mean of the MRF = (8 sum(first neighbours) - sum(second neighbours)) / (8 nn - nn2)
+//   prior mean      = (1 / prior precision) (spatial precision x that mean + prec0 mean0)
+__device__ __forceinline__ double second_order_mean(double contrib_nn, double contrib_nn2, double rec)
+{
+    return __builtin_fma(8.0, contrib_nn, contrib_nn2) * rec;
+}
+__device__ __forceinline__ double second_order_pm(double pcov, double spatial_prec, double spatial_mean, double prec0, double mean0)
+{
+    return pcov * __builtin_fma(spatial_prec, spatial_mean, prec0 * mean0);
 }
 
 __device__ __forceinline__ bool is_spatial_type(int t)
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             else if (nn != 0)
             {
                 const double rec = 1 / double(8 * nn - nn2);
-                spatial_mean = (8 * contrib_nn + contrib_nn2) * rec;
+                spatial_mean = second_order_mean(contrib_nn, contrib_nn2, rec);
             }
             else
                 spatial_mean = 0;
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             if (type == FVB_PRIOR_SPATIAL_m || type == FVB_PRIOR_SPATIAL_M)
                 st.pm[k] = pcov * spatial_prec * spatial_mean;
             else
-                st.pm[k] = pcov * (spatial_prec * spatial_mean + prec0 * mean0);
+                st.pm[k] = second_order_pm(pcov, spatial_prec, spatial_mean, prec0, mean0);
         }
         else if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
@@ -751,21 +766,44 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     sp_load<P>(sa, v, st, mo);
     const int dims = sa.spatial_dims;
     int n1[6];
-    bool live1[6];
+    bool ok1[6], live1[6];
 #pragma unroll
     for (int a = 0; a < 6; a++)
     {
         const int u = sa.nn[(size_t)v * 6 + a];
         n1[a] = (u < 0) ? v : u;
-        live1[a] = (u >= 0);
+        ok1[a] = (u >= 0);
     }
 #pragma unroll
     for (int a = 0; a < 6; a++)
-        live1[a] = live1[a] && (sa.status[n1[a]] == 0);
+        live1[a] = ok1[a] && (sa.status[n1[a]] == 0);
     int nn_live = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++)
         nn_live += live1[a] ? 1 : 0;
+    // types P, p: the second-neighbour list - the neighbours of every first neighbour that exists (alive or not: the
+    // list was fixed when it was built and reaches across a failed voxel), except v itself and the ones that have
+    // failed (Vb::IgnoreVoxel, inference_vb.cc:266-297) - in list order, as positions
+    int nn2_live = 0;
+    if (sa.sw_npos2) // (uniform)
+    {
+        for (int a = 0; a < 6; a++)
+        {
+            int n2[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++)
+                n2[b] = sa.nn[(size_t)n1[a] * 6 + b];
+#pragma unroll
+            for (int b = 0; b < 6; b++)
+            {
+                const int w = (n2[b] < 0) ? v : n2[b];
+                const bool live2 = ok1[a] && (n2[b] >= 0) && (n2[b] != v) && (sa.status[w] == 0);
+                nn2_live += live2 ? 1 : 0;
+                if (!ignored)
+                    sa.sw_npos2[(size_t)(a * 6 + b) * NP + pos] = live2 ? sa.pos_of[w] : -1;
+            }
+        }
+    }
     double Fprior = 0;
     int si = 0; // index among the spatial parameters
 #pragma unroll
@@ -774,16 +812,20 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         const int type = ka.cfg.prior_type[k];
         if (is_spatial_type(type)) // SpatialPrior::ApplyToMVN (priors.cc:362-482), types M and m
         {
-            const int nn = (type == FVB_PRIOR_SPATIAL_m) ? 2 * dims : nn_live;
+            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
+            const bool dirichlet = (type == FVB_PRIOR_SPATIAL_m || type == FVB_PRIOR_SPATIAL_p);
+            const int nn = dirichlet ? 2 * dims : nn_live;
+            const int nn2 = dirichlet ? 4 * dims * dims - nn : nn2_live;
             const double aK = sa.aK[k];
-            const double spatial_prec = (type == FVB_PRIOR_SPATIAL_M) ? aK * (nn + 1e-8) : aK * nn;
-            st.pprec[k] = (type == FVB_PRIOR_SPATIAL_m) ? spatial_prec : ka.cfg.prior_prec[k] + spatial_prec;
+            const double spatial_prec = second ? aK * (nn * nn + nn) : ((type == FVB_PRIOR_SPATIAL_M) ? aK * (nn + 1e-8) : aK * nn);
+            st.pprec[k] = dirichlet ? spatial_prec : ka.cfg.prior_prec[k] + spatial_prec;
             const double pcov = 1.0 / st.pprec[k];
             if (!ignored)
             {
+                // (types P, p: the sweep forms the prior mean with second_order_pm from the spatial precision itself)
                 sa.sw_pprec[si * NP + pos] = st.pprec[k];
-                sa.sw_q[si * NP + pos] = pcov * spatial_prec;
-                sa.sw_rec[si * NP + pos] = 1 / double(nn);
+                sa.sw_q[si * NP + pos] = second ? spatial_prec : pcov * spatial_prec;
+                sa.sw_rec[si * NP + pos] = second ? ((nn != 0) ? 1 / double(8 * nn - nn2) : 0.0) : 1 / double(nn);
                 sa.sw_x[si * NP + pos] = st.m[k];
                 if (sa.sl_mode)
                 {
@@ -1093,6 +1135,158 @@ __global__ __launch_bounds__(256) void vb_spatial_sweep_kernel(const SpatialArgs
         }
         r[0] = nx[0];
         r[1] = nx[1];
+        begin = nbegin;
+        count = ncount;
+    }
+}
+
+// ---- the data-flow sweep with second neighbours (types P and p, next to any M / m) ------------------------
+// The same single launch for priors that also read the neighbours' neighbours (priors.cc:377-385): with
+// level = x + 2y + 3z every one of the 6 + 18 stencil offsets to a smaller voxel index lowers the level, so a voxel
+// polls the granules of its first neighbours and of the (up to 30, with repeats) entries of its second-neighbour
+// list and waits for those of earlier levels to carry this sweep's serial number. One voxel per lane and level
+// (the polls are 84 loads per spatial parameter); everything else as above.
+template <int P, int NS>
+struct SweepRecord2
+{
+    SweepRecord<P, NS> r;
+    int np2[36];
+    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
+    {
+        r.load(sa, pos, ns);
+        const size_t NP = (size_t)sa.n_pos;
+        pos = pos >= 0 ? pos : 0;
+#pragma unroll
+        for (int e = 0; e < 36; e++)
+            np2[e] = sa.sw_npos2[(size_t)e * NP + pos];
+    }
+};
+
+template <int P, int NS>
+__device__ __forceinline__ void sweep2_step(const SpatialArgs &sa, const SweepRecord2<P, NS> &rec, int pos, int ns, int level_begin,
+    SweepRecord2<P, NS> *next, int next_pos)
+{
+    const SweepRecord<P, NS> &r = rec.r;
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+    double rhs[P];
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        rhs[j] = r.rhs0[j];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            const int k = sa.spatial_param[s];
+            const int type = sa.ka.cfg.prior_type[k];
+            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p); // (uniform)
+            const unsigned long long *g = sa.sw_gran + (size_t)s * NP * 2;
+            unsigned long long lo[42], hi[42];
+            int spins = 0;
+            for (;;)
+            {
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                {
+                    const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
+                    const bool want = r.alive && np >= 0 && (e < 6 || second);
+                    const size_t at = (size_t)(want ? np : 0) * 2;
+                    lo[e] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[e] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (next && s == 0 && spins == 0)
+                    next->load(sa, next_pos, ns);
+                bool ready = true;
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                {
+                    const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
+                    if (r.alive && np >= 0 && np < level_begin && (e < 6 || second))
+                        ready = ready && ((lo[e] >> 32) == serial) && ((hi[e] >> 32) == serial);
+                }
+                if (ready)
+                    break;
+                if (++spins > (1 << 22)) // never (every wave of the grid is resident); the run is repeated
+                {
+                    sa.sw_flags[0] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!r.alive)
+                continue;
+            double contrib = 0, contrib2 = 0;
+#pragma unroll
+            for (int e = 0; e < 6; e++)
+                if (r.np[e] >= 0)
+                    contrib += __longlong_as_double((long long)((hi[e] << 32) | (lo[e] & 0xffffffffull)));
+            double pm;
+            if (second)
+            {
+#pragma unroll
+                for (int e = 6; e < 42; e++)
+                    if (rec.np2[e - 6] >= 0)
+                        contrib2 += -__longlong_as_double((long long)((hi[e] << 32) | (lo[e] & 0xffffffffull)));
+                const double spatial_mean = (r.rec[s] != 0) ? second_order_mean(contrib, contrib2, r.rec[s]) : 0.0;
+                pm = second_order_pm(1.0 / r.pprec[s], r.q[s], spatial_mean, sa.ka.cfg.prior_prec[k], sa.ka.cfg.prior_mean[k]);
+            }
+            else
+            {
+                const double spatial_mean = contrib * r.rec[s];
+                pm = r.q[s] * spatial_mean;
+            }
+            sa.sw_pm[s * NP + pos] = pm;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                if (j == k)
+                    rhs[j] = theta_rhs(rhs[j], r.pprec[s], pm);
+        }
+    if (!r.alive)
+        return;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            double m = 0;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                m = __builtin_fma(r.sig[s][j], rhs[j], m);
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+            unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
+            __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sa.sw_x[s * NP + pos] = m;
+        }
+}
+
+template <int P, int NS>
+__global__ __launch_bounds__(256) void vb_spatial_sweep2_kernel(const SpatialArgs sa)
+{
+    const int ns = sa.n_spatial;
+    const int nl = sa.n_levels;
+    const int stride = gridDim.x * 256;
+    const int lane0 = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ int s_tab[]; // [2][n_levels]: first position, voxel count
+    for (int i = threadIdx.x; i < nl; i += 256)
+    {
+        s_tab[i] = sa.sw_level_pos[i];
+        s_tab[nl + i] = sa.sw_level_count[i];
+    }
+    __syncthreads();
+    SweepRecord2<P, NS> r, nx;
+    int begin = s_tab[0], count = s_tab[nl];
+    r.load(sa, lane0 < count ? begin + lane0 : -1, ns);
+    for (int l = 0; l < nl; l++)
+    {
+        const int nbegin = (l + 1 < nl) ? s_tab[l + 1] : 0, ncount = (l + 1 < nl) ? s_tab[nl + l + 1] : 0;
+        sweep2_step<P, NS>(sa, r, begin + lane0, ns, begin, &nx, lane0 < ncount ? nbegin + lane0 : -1);
+        for (int i = lane0 + stride; i < count; i += stride) // (huge levels only)
+        {
+            SweepRecord2<P, NS> one;
+            one.load(sa, begin + i, ns);
+            sweep2_step<P, NS>(sa, one, begin + i, ns, begin, nullptr, -1);
+        }
+        r = nx;
         begin = nbegin;
         count = ncount;
     }
@@ -1557,6 +1751,7 @@ struct SpatialKernels
     SpatialSweepFn slab_sweep[3]; // the slab form of the sweep, same three builds
     int lds_classes;              // 1: setup / noise / noise_fast keep cfg.phi_index in LDS (n_times bytes of dynamic LDS)
     SpatialKernelFn noise_acc, noise_fast_acc; // the second sweep of the iterations that end in a pointwise re-centre, or NULL
+    SpatialSweepFn sweep2[3];                  // the data-flow sweep with second neighbours (types P, p)
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
@@ -1591,6 +1786,8 @@ SpatialKernelFn spatial_noise_acc(bool need_f)
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true>,                   \
             { vb_spatial_slab_sweep_kernel<PP, 1>, vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>,        \
                 vb_spatial_slab_sweep_kernel<PP, PP> }, 0,                                                   \
-            spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f) };
+            spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f),    \
+            { vb_spatial_sweep2_kernel<PP, 1>, vb_spatial_sweep2_kernel<PP, (PP < 2 ? PP : 2)>,                \
+                vb_spatial_sweep2_kernel<PP, PP> } };
 
 } // namespace fvb

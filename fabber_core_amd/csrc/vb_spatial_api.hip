@@ -442,6 +442,8 @@ struct fvb_spatial_run
     // the split first sweep (vb_spatial.h): whole-volume runs with first-neighbour priors (types M, m)
     bool allow_fast = false, fast = false;
     bool multi_fast = false; // one of several slabs on several devices that sweep together (fabber_vb_run_spatial_host_multi)
+    int device_share = 1;    // how many such slabs run on THIS device at once (a device listed several times)
+    bool fast_second = false; // the split sweep with second neighbours (types P, p): vb_spatial_sweep2_kernel
     DevMem d_up_pos;
     std::vector<int32_t> h_pos_of; // (multi_fast: the numbering, for the slab below to address this slab's inboxes)
     int fast_prep(int it);
@@ -734,9 +736,18 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 zmax = std::max(zmax, (int)Z[v]);
             }
         const long long nz = (long long)zmax - zmin + 1;
-        long long dz = std::max(1LL, (nz + 191) / 192);
+        // The sweep's workgroups (1024 lanes, up to 128 KB of LDS: one per compute unit) wait for the slab below.
+        // Workgroups are dispatched in index order, so the one waited for is resident or finished; all the same the
+        // count stays within what THIS device (a partition of the chip in CPX mode has 32 compute units, not 256)
+        // holds at once, three quarters of it at most, shared between the runs that sweep on it together. A wait
+        // that does not end gives up (slab_wait_inbox) and the run is repeated with the per-level launches.
+        int cus = 256, dev_now = 0;
+        if (hipGetDevice(&dev_now) == hipSuccess)
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_now);
+        const long long slab_cap = std::max(1LL, std::min(192LL, (long long)cus * 3 / 4 / std::max(1, device_share)));
+        long long dz = std::max(1LL, (nz + slab_cap - 1) / slab_cap);
         if (const char *forced = getenv("FVB_SPATIAL_SLAB_DZ"))
-            dz = std::max((nz + 191) / 192, (long long)std::max(1, atoi(forced)));
+            dz = std::max((nz + slab_cap - 1) / slab_cap, (long long)std::max(1, atoi(forced)));
         const long long n_slabs = (nz + dz - 1) / dz;
         const size_t nl = (size_t)(lmax - lmin + 1);
         if (sp.spatial_dims <= 3 && n_slabs * (long long)nl <= (1LL << 21))
@@ -785,7 +796,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 }
             }
             slab_first[(size_t)n_slabs] = (int32_t)level_pos.size();
-            if (sl_max_run <= 8192 && n_slabs <= 224)
+            if (sl_max_run <= 8192 && n_slabs <= slab_cap)
             {
                 if (on_dev)
                 {
@@ -826,7 +837,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     if (!slab_form)
         build_level_order();
-    fast = slab_form || (eligible && whole && level_begin.size() <= 6000); // (the data-flow sweep keeps the level table in LDS)
+    // (the data-flow sweep keeps the level table in LDS; it is also what takes the second-neighbour priors, types P and p)
+    const bool eligible2 = allow_fast && has_spatial && second_neighbours && whole && n_owned > 0 && !getenv("FVB_SPATIAL_PER_LEVEL");
+    fast = slab_form || ((eligible || eligible2) && whole && level_begin.size() <= 6000);
+    fast_second = fast && second_neighbours;
     if (slab_form && !whole)
     {
         // ghosts have no position: what stands in sw_npos for them says where their mean comes from (vb_spatial.h)
@@ -932,7 +946,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; slab form: nbr [ns][6][NP]
         const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P + (slab_form ? 6 * ns : 0)) * NP;
         FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64, stream));
-        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * 7 * NP, stream)); // npos [6][NP], alive [NP]
+        const size_t n_i32 = (fast_second ? 43 : 7) * NP;
+        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * n_i32, stream)); // npos [6][NP], alive [NP], types P / p: npos2 [36][NP]
         FVB_HIP_CHECK(d_sw_sync.alloc(64, stream));                      // counter, flags[2]
         if (multi_fast)
             FVB_HIP_CHECK(d_sw_gran.alloc_fine(sizeof(unsigned long long) * 2 * ns * NP));
@@ -942,7 +957,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sl_remote = multi_fast ? 1 : 0;
         sa.sw_gran = (unsigned long long *)d_sw_gran.p;
         sa.sw_serial = 0;
-        FVB_HIP_CHECK(hipMemsetAsync(d_sw_i32.p, 0, sizeof(int32_t) * 7 * NP, stream));
+        FVB_HIP_CHECK(hipMemsetAsync(d_sw_i32.p, 0, sizeof(int32_t) * n_i32, stream));
         FVB_HIP_CHECK(hipMemsetAsync(d_sw_f64.p, 0, sizeof(double) * n_f64, stream));
         FVB_HIP_CHECK(hipMemsetAsync(d_sw_sync.p, 0, 64, stream));
         double *f = (double *)d_sw_f64.p;
@@ -970,6 +985,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         }
         sa.sw_npos = (int32_t *)d_sw_i32.p;
         sa.sw_alive = (int32_t *)d_sw_i32.p + 6 * NP;
+        sa.sw_npos2 = fast_second ? (int32_t *)d_sw_i32.p + 7 * NP : nullptr;
         sa.sw_counter = (uint32_t *)d_sw_sync.p;
         sa.sw_flags = (int32_t *)d_sw_sync.p + 4;
         sa.pos_of = (const int32_t *)d_pos_of.p;
@@ -1075,7 +1091,7 @@ int fvb_spatial_run::fast_prep(int it)
 int fvb_spatial_run::fast_sweep()
 {
     const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
-    // one workgroup of 1024 lanes per slab (at most 224: resident together on any MI355X)
+    // one workgroup of 1024 lanes per slab (within the device's compute units, see the numbering)
     const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
     if (lds > 48 * 1024)
         FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1137,8 +1153,18 @@ int fvb_spatial_run::sweep_fast(int it)
     hipLaunchKernelGGL(k.prep, dim3((unsigned)(((n_owned + 63) / 64 + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
     // few workgroups, all resident at once on any MI355X (256 CUs): the level barrier is a counter
     const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
-    const unsigned nwg = (unsigned)std::max(1, std::min(64, (max_level + 511) / 512)); // two voxels per lane
-    hipLaunchKernelGGL(k.sweep[sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2)], dim3(nwg), dim3(256), 2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
+    const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
+    int wg_cap = 64;
+    if (const char *forced = getenv("FVB_SPATIAL_SWEEP_WGS")) // tests: levels with more voxels than the launch has lanes
+        wg_cap = std::max(1, std::min(64, atoi(forced)));
+    if (fast_second) // one voxel per lane
+        hipLaunchKernelGGL(k.sweep2[which], dim3((unsigned)std::max(1, std::min(wg_cap, (max_level + 255) / 256))), dim3(256),
+            2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
+    else
+    {
+        const unsigned nwg = (unsigned)std::max(1, std::min(wg_cap, (max_level + 511) / 512)); // two voxels per lane
+        hipLaunchKernelGGL(k.sweep[which], dim3(nwg), dim3(256), 2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
+    }
     hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1878,6 +1904,7 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
         sl.sp.n_voxels_global = V;
         sl.run = new fvb_spatial_run;
         sl.run->allow_fast = sl.run->multi_fast = try_fast;
+        sl.run->device_share = (int)std::count(devs.begin(), devs.begin() + world, sl.dev);
         if ((rc = sl.run->open(&sl.d, &sl.sp, sl.b_data.p, &sl.dout, st)) != 0)
             return rc;
     }

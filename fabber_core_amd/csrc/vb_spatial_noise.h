@@ -679,6 +679,9 @@ SpatialKernels spatial_nz_table(bool need_f, const char *name)
     k.slab_sweep[0] = vb_spatial_slab_sweep_kernel<PP, 1>;
     k.slab_sweep[1] = vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
     k.slab_sweep[2] = vb_spatial_slab_sweep_kernel<PP, PP>;
+    k.sweep2[0] = vb_spatial_sweep2_kernel<PP, 1>;
+    k.sweep2[1] = vb_spatial_sweep2_kernel<PP, (PP < 2 ? PP : 2)>;
+    k.sweep2[2] = vb_spatial_sweep2_kernel<PP, PP>;
     k.lds_classes = NZ::LDS_CLASSES ? 1 : 0;
     return k;
 }

@@ -267,7 +267,7 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
         bad_offset |= !is_finite(g);
         for (int i = 0; i < P; i++)
         {
-            FVB_NO_CONTRACT
+            FVB_MODEL_FP
             const double f2 = eval_model_runtime(ka.cfg.model, ma, P, t, sh + L.pv + (1 + 2 * i) * P);
             const double f3 = eval_model_runtime(ka.cfg.model, ma, P, t, sh + L.pv + (2 + 2 * i) * P);
             const double Jti = (f2 - f3) * sh[L.rden + i];

@@ -59,7 +59,7 @@ def lib():
         L.fabber_vb_convergence_trace.restype = C.c_int32
         L.fabber_vb_convergence_trace.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
-        for name in ("fabber_vb_gammaln", "fabber_vb_digamma"):
+        for name in ("fabber_vb_gammaln", "fabber_vb_digamma", "fabber_vb_exp_acc"):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
         L.fabber_vb_transform.restype = C.c_double
@@ -177,6 +177,62 @@ def nlls_run_host(holder, data, lm=False, start=None, settings=None, device=0):
     for k, a in arrs.items():
         setattr(out, k, a.ctypes.data)
     _check(lib().fabber_nlls_run_host(C.byref(cfg), C.byref(nl), data.ctypes.data, C.byref(out), device))
+    arrs["cost"] = arrs.pop("free_energy")
+    return arrs
+
+
+LINEARISE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def recentre_callback(model, T, P):
+    """fvb_linearise_fn from a Python model: model(params [n][P] Fabber space, voxel ids [n]) -> [n][T]. The offset and
+    the Jacobian as LinearizedFwdModel::ReCentre computes them (fwdmodel_linear.cc:126-182): central differences,
+    delta = max(|centre| 1e-5, 1e-10). Keep the returned object alive for the duration of the call."""
+    def cb(user, n, ids, means, lin):
+        try:
+            v = np.ctypeslib.as_array(ids, (n,))
+            m = np.ctypeslib.as_array(means, (n * P,)).reshape(n, P)
+            out = np.ctypeslib.as_array(lin, (n * T * (P + 1),)).reshape(n, T * (P + 1))
+            out[:, :T] = model(m, v)
+            J = np.empty((n, T, P))
+            for i in range(P):
+                delta = np.maximum(np.abs(m[:, i] * 1e-5), 1e-10)
+                up, dn = m.copy(), m.copy()
+                up[:, i] = m[:, i] + delta
+                dn[:, i] = m[:, i] - delta
+                J[:, :, i] = (model(up, v) - model(dn, v)) / (up[:, i] - dn[:, i])[:, None]
+            out[:, T:] = J.reshape(n, -1)
+            return 0
+        except Exception:  # noqa: BLE001 (the engine reports -54)
+            return 1
+    return LINEARISE_FN(cb)
+
+
+def nlls_run_hostmodel_host(holder, data, model, lm=False, start=None, settings=None, device=0):
+    """method=nlls with the model evaluated by the caller (fabber_nlls_run_hostmodel_host): `model` as for
+    recentre_callback. The holder's model fields are not read."""
+    cfg = holder.cfg
+    data = _prepare_data(holder, data)
+    V, P, T = cfg.n_voxels, cfg.n_params, cfg.n_times
+    for p in range(P):
+        cfg.post_mean[p] = 0.0 if start is None else float(start[p])
+    nl = settings or vbabi.FvbNlls.defaults(lm)
+    arrs = dict(mvn=np.full((vbabi.mvn_rows(P), V), np.nan), status=np.full(V, -1, dtype=np.int32),
+                iterations=np.full(V, -1, dtype=np.int32), free_energy=np.full(V, np.nan))
+    out = vbabi.FvbOutputs()
+    for k, a in arrs.items():
+        setattr(out, k, a.ctypes.data)
+    cb = recentre_callback(model, T, P)
+    L = lib()
+    L.fabber_nlls_run_hostmodel_host.restype = C.c_int32
+    L.fabber_nlls_run_hostmodel_host.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbNlls), C.c_void_p,
+                                                 C.POINTER(vbabi.FvbOutputs), C.c_int32, LINEARISE_FN, C.c_void_p]
+    saved = cfg.model
+    cfg.model = vbabi.MODEL_HOSTJAC
+    try:
+        _check(L.fabber_nlls_run_hostmodel_host(C.byref(cfg), C.byref(nl), data.ctypes.data, C.byref(out), device, cb, None))
+    finally:
+        cfg.model = saved
     arrs["cost"] = arrs.pop("free_energy")
     return arrs
 

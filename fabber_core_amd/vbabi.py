@@ -12,9 +12,9 @@ import math
 
 import numpy as np
 
-FVB_MAX_PARAMS = 16
+FVB_MAX_PARAMS = 32
 FVB_MAX_PHIS = 8
-FVB_ABI_VERSION = 6
+FVB_ABI_VERSION = 7
 
 MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
 TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)

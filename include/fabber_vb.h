@@ -42,9 +42,9 @@
 extern "C" {
 #endif
 
-#define FVB_MAX_PARAMS 16
+#define FVB_MAX_PARAMS 32
 #define FVB_MAX_PHIS 8
-#define FVB_ABI_VERSION 6
+#define FVB_ABI_VERSION 7
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
@@ -406,6 +406,12 @@ int32_t fabber_nlls_run_device(const fvb_config *cfg, const fvb_nlls *nl, const 
     void *stream, int32_t n_unmasked);
 int32_t fabber_nlls_run_host(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
     int32_t device);
+/* method=nlls with a forward model that exists only as host code (cfg->model = FVB_MODEL_HOSTJAC; the reference's
+ * NLLS works with any FwdModel, inference_nlls.cc:94-214): the minimiser runs on the device, `linearise` (as for
+ * fabber_vb_run_hostmodel_host) is called once per trial point with the voxels still running. Reads of fvb_config
+ * what fabber_nlls_run_host reads except model* / design. -54: the callback returned non-zero. */
+int32_t fabber_nlls_run_hostmodel_host(const fvb_config *cfg, const fvb_nlls *nl, const void *data, const fvb_outputs *out,
+    int32_t device, fvb_linearise_fn linearise, void *user);
 
 /* The engine's work buffers (the re-laid series, the spatial run's state) come from the current device's
  * stream-ordered memory pool, which keeps them between runs (a caller that fits volume after volume allocates

@@ -229,3 +229,88 @@ def test_spatial_vb_without_device_kernels_falls_back_to_the_host_model():
     assert "no device kernels for spatial VB" in auto["log"]
     forced = fabber.run(data, dict(opts, **{"host-model": True}))
     assert np.array_equal(auto["finalMVN"], forced["finalMVN"])
+
+
+# ---- method=nlls with a model evaluated on the host (fabber_nlls_run_hostmodel_host) ----------------
+@pytest.mark.gpu
+def test_nlls_with_a_host_evaluated_copy_of_a_builtin_model(plugin):
+    """NLLSInferenceTechnique works with any FwdModel (inference_nlls.cc:94-214): the library's 'mypoly' and a
+    built-in nonlinear model forced onto the host route against the device route of the same model"""
+    rng = np.random.default_rng(11)
+    shape, T = (6, 5, 4), 12
+    t = np.arange(1, T + 1)
+    c = rng.uniform(-3, 3, shape + (3,))
+    data = (c[..., 0:1] + c[..., 1:2] * t + c[..., 2:3] * t * t + rng.normal(0, 0.1, shape + (T,))).astype(np.float32)
+    opts = {"degree": 2, "noise": "white", "method": "nlls", "save-mean": True, "save-mvn": True, "save-model-fit": True}
+    dev = fabber.run(data, dict(opts, model="poly"))
+    host = fabber.run(data, dict(opts, model="mypoly"), model_libs=[plugin])
+    assert "evaluated on the host" in host["log"]
+    for k in ("mean_c0", "mean_c1", "mean_c2", "modelfit"):
+        assert np.allclose(host[k], dev[k], rtol=1e-5, atol=1e-5), k
+    assert np.allclose(host["finalMVN"], dev["finalMVN"], rtol=1e-4, atol=1e-7)
+    te = np.arange(50) * 0.04
+    amp = np.where(rng.random(shape) < 0.5, 1.0, 0.5)
+    data = (amp[..., None] * np.exp(-te) + rng.normal(0, 0.05, shape + (50,))).astype(np.float32)
+    opts = {"model": "exp", "num-exps": 1, "dt": 0.04, "noise": "white", "method": "nlls", "save-mean": True, "save-mvn": True, "mt1": 7}
+    dev = fabber.run(data, opts)
+    host = fabber.run(data, dict(opts, **{"host-model": True, "host-model-threads": 3}))
+    assert np.allclose(host["mean_amp1"], dev["mean_amp1"], rtol=1e-5)
+    assert np.allclose(host["mean_r1"], dev["mean_r1"], rtol=1e-5)
+    assert np.allclose(host["finalMVN"], dev["finalMVN"], rtol=1e-3, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_nlls_third_party_model_against_an_independent_least_squares_fit(plugin, tmp_path):
+    """tests/plugins/fwdmodel_bump.cc under method=nlls: the minimum of the sum of squares is what SciPy's
+    least-squares solver finds for the same model. The reference starts NLLS from HardcodedInitialDists' posterior
+    (inference_nlls.cc:68-82), which models that describe themselves through GetParameterDefaults leave at zero
+    (fwdmodel.h:305) - a zero width here, where the model is not finite: every voxel takes the catch branch
+    (:186-207). With a starting estimate from a file (fwd-inital-posterior) the fit runs."""
+    import scipy.optimize
+    rng = np.random.default_rng(12)
+    shape, T = (4, 4, 3), 24
+    t = np.arange(1, T + 1)
+    amp = rng.uniform(2, 4, shape)
+    mu = rng.uniform(9, 12, shape)
+    width = rng.uniform(2.5, 4, shape)
+    clean = amp[..., None] * np.exp(-(t - mu[..., None]) ** 2 / (2 * width[..., None] ** 2))
+    data = (clean + rng.normal(0, 0.02, shape + (T,))).astype(np.float32)
+    opts = {"model": "bump", "noise": "white", "method": "nlls", "save-mean": True, "save-mvn": True, "save-model-fit": True}
+    out = fabber.run(data, opts, model_libs=[plugin])
+    assert "evaluated on the host" in out["log"]
+    assert np.all(out["mean_mu"] == 0) and np.all(out["mean_width"] == 0) and np.all(out["mean_amp"] == 1)
+    assert np.allclose(out["finalMVN"][..., 0], 1e12)  # precisions 1e-12
+    start = np.zeros((4, 4))
+    start[:3, :3] = np.eye(3)
+    start[:3, 3] = start[3, :3] = [np.log(2.0), 10.0, 3.0]  # Fabber space: amp is LOG-transformed
+    start[3, 3] = 1.0
+    np.savetxt(str(tmp_path / "start.mat"), start)
+    out = fabber.run(data, dict(opts, **{"fwd-inital-posterior": str(tmp_path / "start.mat")}), model_libs=[plugin])
+    for idx in np.ndindex(shape):
+        y = data[idx].astype(np.float64)
+
+        def resid(p):
+            return p[0] * np.exp(-(t - p[1]) ** 2 / (2 * p[2] ** 2)) - y
+        sol = scipy.optimize.least_squares(resid, [amp[idx], mu[idx], width[idx]], xtol=1e-14, ftol=1e-14, gtol=1e-14)
+        got = np.array([out["mean_amp"][idx], out["mean_mu"][idx], abs(out["mean_width"][idx])])
+        assert np.allclose(got, sol.x, rtol=2e-4), (idx, got, sol.x)
+    assert np.sqrt(np.mean((out["modelfit"] - clean) ** 2)) < 0.02
+
+
+@pytest.mark.gpu
+def test_twenty_parameter_linear_model_through_the_c_api(tmp_path):
+    """the engine took 16 parameters at most: a 20-column design under vb and nlls against the closed-form
+    least-squares solution (flat priors: the VB means are the least-squares means, test_inference.cc:353-429 style)"""
+    rng = np.random.default_rng(13)
+    T, P, shape = 120, 20, (5, 4, 3)
+    tt = np.arange(T)
+    X = np.stack([np.cos(np.pi * (tt + 0.5) * k / T) for k in range(P)], axis=1)
+    np.savetxt(str(tmp_path / "design.mat"), X)
+    theta = rng.normal(0, 3, shape + (P,))
+    data = (theta @ X.T + rng.normal(0, 0.3, shape + (T,))).astype(np.float32)
+    want = np.linalg.lstsq(X, data.reshape(-1, T).T.astype(np.float64), rcond=None)[0].T.reshape(shape + (P,))
+    for method in ("vb", "nlls"):
+        out = fabber.run(data, {"model": "linear", "basis": str(tmp_path / "design.mat"), "noise": "white", "method": method,
+                                "save-mean": True, "max-iterations": 10})
+        for k in range(P):
+            assert np.allclose(out["mean_Parameter_%d" % (k + 1)], want[..., k], rtol=1e-4, atol=1e-4), (method, k)

@@ -67,3 +67,27 @@ def test_ldl_indefinite_sign():
     assert ok and sign == -1
     assert math.isclose(logabs, math.log(24.0), rel_tol=1e-14)
     assert np.allclose(inv, np.diag([0.5, -1 / 3.0, 0.25]))
+
+
+def test_exp_acc_is_good_to_about_half_an_ulp():
+    """vb_math.h exp_acc: what the spatial path's pointwise linearisations use instead of the device library's exp
+    (1 ulp), because the first central differences of a run amplify every rounding of the model prediction
+    (DESIGN 5.4). Against the x87 long double exp (64-bit mantissa): 0.52 ulp at most, glibc's own exp 0.51."""
+    if np.finfo(np.longdouble).nmant < 63:
+        pytest.skip("no extended precision on this host")
+    L = hiplib.lib()
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.uniform(-40, 40, 150000), rng.uniform(-1, 1, 50000), rng.uniform(-700, 700, 20000),
+                         [0.0, -0.0, 1e-300, -1e-300, 689.9, -689.9, 709.0, -745.0, 1e-10, -1e-10]])
+    worst = 0.0
+    for x in xs:
+        got = L.fabber_vb_exp_acc(float(x))
+        want = np.exp(np.longdouble(x))
+        if not np.isfinite(want) or want == 0 or float(want) < 2.3e-308:
+            assert got == float(want) or math.isclose(got, float(want), rel_tol=1e-15)
+            continue
+        ulp = np.longdouble(math.ulp(float(want)))
+        worst = max(worst, float(abs(np.longdouble(got) - want) / ulp))
+    assert worst < 0.53, worst
+    assert math.isnan(L.fabber_vb_exp_acc(float("nan"))) and L.fabber_vb_exp_acc(float("inf")) == float("inf")
+    assert L.fabber_vb_exp_acc(float("-inf")) == 0.0

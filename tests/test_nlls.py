@@ -238,6 +238,74 @@ def test_parameter_counts_without_a_lane_kernel_run_on_the_wave_kernel():
     assert_parity(h, data, variant="auto")
 
 
+# ---- models evaluated by the caller (fabber_nlls_run_hostmodel_host) --------------------------------
+def exp_model_in_numpy(h):
+    """examples/fwdmodel_exp.cc:65-85 with the holder's transforms (fwdmodel.cc:375-379): the model a library would hold"""
+    T, P, dt = h.cfg.n_times, h.cfg.n_params, h.cfg.model_dopt[0]
+    t = np.arange(T) * dt
+
+    def model(params, ids):
+        with np.errstate(over="ignore", invalid="ignore"):
+            q = np.stack([np.exp(params[:, i]) if h.cfg.transform[i] == vbabi.TRANSFORM_LOG else params[:, i] for i in range(P)], axis=1)
+            return sum(q[:, 2 * k:2 * k + 1] * np.exp(-q[:, 2 * k + 1:2 * k + 2] * t[None, :]) for k in range(P // 2))
+    return model
+
+
+def assert_close_to_the_oracle(h, ref, got, tol=1e-6):
+    assert np.array_equal(ref["status"] != 0, got["status"] != 0)
+    ok = ref["status"] == 0
+    P = h.cfg.n_params
+    off = P * (P + 1) // 2
+    sd = np.sqrt(np.abs(np.stack([ref["mvn"][p * (p + 1) // 2 + p] for p in range(P)])))
+    scale = np.maximum(np.abs(ref["mvn"][off:off + P]), sd)
+    err = (np.abs(got["mvn"][off:off + P] - ref["mvn"][off:off + P]) / np.maximum(scale, 1e-300))[:, ok]
+    assert err.max() < 1e-4 and np.quantile(err.max(axis=0), 0.99) < tol, (err.max(), np.quantile(err.max(axis=0), 0.99))
+    assert np.allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lm", [False, True])
+def test_host_evaluated_model_against_the_oracle(lm, monkeypatch):
+    """inference_nlls.cc:94-214 works with any FwdModel: here the single exponential evaluated by the caller (NumPy),
+    the minimiser on the device one trial point per launch, against the oracle's run of the built-in model; several
+    batches per step (FVB_HOSTMODEL_BATCH) and masked timepoints."""
+    h, data = cases.exp_problem(700, 50, 1, 0.04, seed=20260110, masked_timepoints=(3, 30))
+    ref = oracle.run_nlls(h, data, lm=lm)
+    monkeypatch.setenv("FVB_HOSTMODEL_BATCH", "256")
+    got = hiplib.nlls_run_hostmodel_host(h, data, exp_model_in_numpy(h), lm=lm)
+    assert_close_to_the_oracle(h, ref, got)
+    # ... and a starting point where the model overflows: the voxel's catch branch (inference_nlls.cc:186-207)
+    h2, d2 = cases.exp_problem(70, 20, 1, 0.04, seed=1)
+    h2.cfg.transform[1] = vbabi.TRANSFORM_IDENTITY
+    ref = oracle.run_nlls(h2, d2, start=[0.0, -1e6])
+    got = hiplib.nlls_run_hostmodel_host(h2, d2, exp_model_in_numpy(h2), start=[0.0, -1e6])
+    assert np.array_equal(ref["status"] != 0, got["status"] != 0)
+    assert np.array_equal(ref["mvn"], got["mvn"])
+
+
+@pytest.mark.gpu
+def test_host_evaluated_model_callback_failure_is_reported():
+    h, data = cases.exp_problem(64, 20, 1, 0.04, seed=2)
+
+    def broken(params, ids):
+        raise RuntimeError("model library failure")
+    with pytest.raises(hiplib.HipEngineError, match="callback failed"):
+        hiplib.nlls_run_hostmodel_host(h, data, broken)
+
+
+@pytest.mark.gpu
+def test_twenty_parameters():
+    """More parameters than the lane kernels are built for (and than the 16 the engine stopped at before): the
+    wave-per-voxel kernels take any count up to FVB_MAX_PARAMS = 32 (the reference has no limit: stated in DESIGN.md)."""
+    rng = np.random.default_rng(6)
+    T, P, V = 120, 20, 300
+    t = np.arange(T)
+    X = np.stack([np.cos(np.pi * (t + 0.5) * k / T) for k in range(P)], axis=1)
+    data = (X @ rng.normal(0, 3, (P, V)) + rng.normal(0, 0.5, (T, V))).astype(np.float32)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X)
+    assert_parity(h, data, variant="auto")
+
+
 # ---- through the reference's API (fabber_capi.h, method=nlls; setup.cc:31-33) ------------------
 from fabber_core_amd import fabber  # noqa: E402
 

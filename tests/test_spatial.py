@@ -465,6 +465,62 @@ def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch)
 
 
 @gpu
+@pytest.mark.parametrize("case", ["P exp", "p exp masked", "P + M + ARD + F", "p, dims 2, speed", "failing voxel with F", "NaN cascade without F",
+                                  "more voxels in a level than lanes"])
+def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch):
+    """Types P and p (priors.cc:377-385, 441-482: the prior mean also reads the neighbours' neighbours) take the split
+    first sweep too: the data-flow form with level = x + 2y + 3z, every voxel polling its 6 first and up to 30 listed
+    second neighbours (vb_spatial_sweep2_kernel). Same operation sequence as the per-level launches: identical output,
+    including next to first-neighbour priors in the same run, masked volumes (lists that reach across a missing voxel)
+    and the fallback when a voxel fails during a sweep."""
+    rng = np.random.default_rng(43)
+    sp_kw = {}
+    if case == "P exp":
+        mask, coords = masked_volume((13, 11, 9), seed=31, keep=1.0)
+        _, y = smooth_exp_data(coords, 40, 0.04, seed=32)
+        h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 40, num_exps=1, dt=0.04, max_iterations=7, param_overrides={"amp1": dict(type="P")})
+    elif case == "p exp masked":
+        mask, coords = masked_volume((12, 10, 8), seed=33, keep=0.8)
+        _, y = smooth_exp_data(coords, 40, 0.04, seed=34)
+        h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 40, num_exps=1, dt=0.04, max_iterations=6, param_overrides={"r1": dict(type="p")})
+    elif case in ("P + M + ARD + F", "p, dims 2, speed"):
+        mask, coords = masked_volume((10, 8, 6), seed=5)
+        V = coords.shape[1]
+        t = np.arange(1, 21.0)
+        c0 = 2.0 + np.sin(coords[0] / 2.0)
+        y = c0[None, :] + 0.3 * t[:, None] + 0.01 * t[:, None] ** 2 + rng.normal(0, 0.2, (20, V))
+        if case.startswith("P +"):
+            h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6, need_f=True,
+                                   param_overrides={"c0": dict(type="P"), "c1": dict(type="A"), "c2": dict(type="M")})
+            sp_kw = dict(update_first_iter=True)
+        else:
+            h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6, param_overrides={"c0": dict(type="p")})
+            sp_kw = dict(spatial_dims=2, spatial_speed=1.5, q1=5.0, q2=2.0)
+    elif case == "failing voxel with F":
+        h, sp0, y, bad = failing_voxel_problem("P")
+        coords = sp0.coords
+    elif case == "NaN cascade without F":
+        h, sp0, y, bad = failing_voxel_problem("P", need_f=False)
+        coords = sp0.coords
+    else:
+        # one workgroup (256 lanes) for levels of up to ~280 voxels: the rest of a level is taken in turns
+        monkeypatch.setenv("FVB_SPATIAL_SWEEP_WGS", "1")
+        mask, coords = masked_volume((560, 290, 1), seed=35, keep=0.97)
+        _, y = smooth_exp_data(coords, 20, 0.04, seed=36)
+        h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 20, num_exps=1, dt=0.04, max_iterations=3, param_overrides={"amp1": dict(type="P")})
+    sp = vbabi.SpatialHolder(coords, **sp_kw)
+    split = hiplib.run_spatial_host(h, sp, y)
+    monkeypatch.setenv("FVB_SPATIAL_HOST_GEOMETRY", "1")
+    split_host = hiplib.run_spatial_host(h, sp, y)
+    monkeypatch.delenv("FVB_SPATIAL_HOST_GEOMETRY")
+    monkeypatch.setenv("FVB_SPATIAL_PER_LEVEL", "1")
+    per_level = hiplib.run_spatial_host(h, sp, y)
+    for k in ("mvn", "status", "iterations", "free_energy"):
+        assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, k)
+        assert np.array_equal(split_host[k], per_level[k], equal_nan=True), (case, k)
+
+
+@gpu
 def test_slab_sweep_with_runs_longer_than_a_workgroup(monkeypatch):
     """a 40 x 40 x 3 volume swept as ONE slab of three planes: its longest run (the voxels of one level) has more
     than 64 voxels, and with FVB_SPATIAL_SLAB_WIDTH=64 the group's lanes take several voxels each"""

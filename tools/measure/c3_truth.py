@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="the HIP kernels only (FVB_LIB_PATH chooses an experiment build)")
     a = ap.parse_args()
     import make_c3_truth as mt
     import oracle
@@ -33,7 +34,7 @@ def main():
     truth = parity.load_c3_truth()
     V = truth["n_voxels"]
     h, y = mt.problem(V)
-    engines = {"cpu": lambda hh: oracle.run(hh, y), "cpu_fma": lambda hh: oracle.run_fma(hh, y)}
+    engines = {} if a.no_cpu else {"cpu": lambda hh: oracle.run(hh, y), "cpu_fma": lambda hh: oracle.run_fma(hh, y)}
     if not a.no_gpu:
         from fabber_core_amd import hiplib
 
@@ -50,6 +51,10 @@ def main():
     report = {"n_voxels": V, "engines": {}}
     for name, run in engines.items():
         final = run(h)
+        if not np.any(final["status"] == 0):
+            print(name, "every voxel failed")
+            report["engines"][name] = {"final": {"failed": 1.0}}
+            continue
         rep = {"final": parity.truth_stats(h, truth, final), "by_iteration": {}}
         for k, it in enumerate(truth["its"]):
             hk, _ = mt.problem(V)

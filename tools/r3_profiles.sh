@@ -14,9 +14,13 @@ for w in c3 c3_needf c5; do
     esac
     BENCH_ARGS="$A" bash tools/pmc_passes.sh r3$w > $OUT/pmc_$w.log 2>&1
     if [ $w = c5 ]; then
-        for k in vb_spatial_prep_kernel vb_spatial_slab_sweep_kernel vb_spatial_noise_kernel vb_spatial_setup_kernel; do
+        for k in vb_spatial_prep_kernel vb_spatial_slab_sweep_kernel vb_spatial_setup_kernel; do
             python3 tools/pmc_summary.py gpurun_out/pmc_r3$w $k > $OUT/r3_pmc_c5_$k.json
         done
+        # the second sweep's two instances: the streaming one (9 of 10 iterations) and the one with the half-ulp exp
+        python3 tools/pmc_summary.py gpurun_out/pmc_r3$w "4, false, true, false>" > $OUT/r3_pmc_c5_vb_spatial_noise_kernel.json
+        python3 tools/pmc_summary.py gpurun_out/pmc_r3$w "4, false, true, true>" > $OUT/r3_pmc_c5_vb_spatial_noise_kernel_acc.json
+        python3 tools/pmc_c5_merge.py $OUT/r3_pmc_c5_vb_*.json > $OUT/r3_pmc_c5.json
     else
         python3 tools/pmc_summary.py gpurun_out/pmc_r3$w vb_lane > $OUT/r3_pmc_$w.json
     fi
