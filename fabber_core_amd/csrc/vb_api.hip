@@ -113,7 +113,27 @@ constexpr int WAVE_KERNEL_BELOW_VOXELS = 4096;
 
 LaneKernelInfo select_lane(const fvb_config *cfg)
 {
-    if (g_variant == 2 || (cfg->n_phis != 1 && (cfg->noise != FVB_NOISE_WHITE || cfg->n_phis > 4)))
+    if (g_variant == 2 || (cfg->n_phis != 1 && cfg->noise == FVB_NOISE_WHITE && cfg->n_phis > 4))
+        return LaneKernelInfo{ nullptr, 0, nullptr };
+    if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 2) // two echoes: the two-pass kernel of vb_lane_arn_kernel.h
+    {
+        if (cfg->n_times % 2 != 0 || cfg->n_times < 8 || (g_variant == 0 && cfg->n_voxels < WAVE_KERNEL_BELOW_VOXELS))
+            return LaneKernelInfo{ nullptr, 0, nullptr };
+        const int n_alphas = 2 + cfg->ar_cross_terms;
+        const bool f = cfg->need_f != 0;
+        switch (cfg->model)
+        {
+        case FVB_MODEL_POLY:
+            return get_lane_arn_kernel_poly(cfg->n_params, n_alphas, f);
+        case FVB_MODEL_LINEAR:
+            return get_lane_arn_kernel_linear(cfg->n_params, n_alphas, f);
+        case FVB_MODEL_EXP:
+            return get_lane_arn_kernel_exp(cfg->n_params, n_alphas, f);
+        default:
+            return LaneKernelInfo{ nullptr, 0, nullptr };
+        }
+    }
+    if (cfg->n_phis != 1 && cfg->noise != FVB_NOISE_WHITE)
         return LaneKernelInfo{ nullptr, 0, nullptr };
     // ... for models whose re-linearisation is long enough to be worth sharing out over 64 lanes: T (2P + 1) model
     // evaluations per pass, an exponential counted twice. Below ~400 of them (C1: a quadratic over 10 timepoints = 70)

@@ -29,6 +29,10 @@ LaneKernelInfo get_lane_kernel_wide(int model, int P, bool need_f); // P = 7, 8 
 LaneKernelInfo get_lane_ar_kernel_poly(int P, bool need_f);
 LaneKernelInfo get_lane_ar_kernel_linear(int P, bool need_f);
 LaneKernelInfo get_lane_ar_kernel_exp(int P, bool need_f);
+// AR(1) noise, two echoes, 2 / 3 / 4 AR coefficients (vb_lane_arn_kernel.h)
+LaneKernelInfo get_lane_arn_kernel_poly(int P, int n_alphas, bool need_f);
+LaneKernelInfo get_lane_arn_kernel_linear(int P, int n_alphas, bool need_f);
+LaneKernelInfo get_lane_arn_kernel_exp(int P, int n_alphas, bool need_f);
 // white noise with several precisions (vb_lane_pattern_kernel.h): N = 2 or 4 moment sets, n_phis <= N used
 LaneKernelInfo get_lane_pattern_kernel_poly_2(int P);
 LaneKernelInfo get_lane_pattern_kernel_poly_4(int P);
@@ -62,3 +66,28 @@ LaneKernelInfo get_lane_pattern_kernel_exp_4(int P);
         return LaneKernelInfo{ nullptr, lane_ar_save_rows<PP>(), "lane_ar1<" TAG "," #PP ">",                \
             vb_lane_ar_kernel<MODEL<PP>, PP, false, FEED_TILES_F32>,                                         \
             vb_lane_ar_kernel<MODEL<PP>, PP, false, FEED_TILES_F64> };
+
+#define FVB_LANE_ARN_ONE(MODEL, TAG, PP, NA, FLAG, SUFFIX)                                                   \
+    return LaneKernelInfo{ nullptr, lane_arn_save_rows<PP, NA>(), "lane_ar2<" TAG "," #PP "," #NA SUFFIX ">",  \
+        vb_lane_arn_kernel<MODEL<PP>, PP, NA, FLAG, FEED_TILES_F32>, vb_lane_arn_kernel<MODEL<PP>, PP, NA, FLAG, FEED_TILES_F64> };
+#define FVB_LANE_ARN_CASE(MODEL, TAG, PP)                                                                    \
+    case PP:                                                                                                 \
+        if (n_alphas == 2)                                                                                   \
+        {                                                                                                    \
+            if (need_f)                                                                                      \
+                FVB_LANE_ARN_ONE(MODEL, TAG, PP, 2, true, ",F")                                              \
+            FVB_LANE_ARN_ONE(MODEL, TAG, PP, 2, false, "")                                                   \
+        }                                                                                                    \
+        if (n_alphas == 3)                                                                                   \
+        {                                                                                                    \
+            if (need_f)                                                                                      \
+                FVB_LANE_ARN_ONE(MODEL, TAG, PP, 3, true, ",F")                                              \
+            FVB_LANE_ARN_ONE(MODEL, TAG, PP, 3, false, "")                                                   \
+        }                                                                                                    \
+        if (n_alphas == 4)                                                                                   \
+        {                                                                                                    \
+            if (need_f)                                                                                      \
+                FVB_LANE_ARN_ONE(MODEL, TAG, PP, 4, true, ",F")                                              \
+            FVB_LANE_ARN_ONE(MODEL, TAG, PP, 4, false, "")                                                   \
+        }                                                                                                    \
+        return LaneKernelInfo{ nullptr, 0, nullptr };

@@ -1182,36 +1182,50 @@ __device__ __forceinline__ void sweep2_step(const SpatialArgs &sa, const SweepRe
             const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p); // (uniform)
             const unsigned long long *g = sa.sw_gran + (size_t)s * NP * 2;
             unsigned long long lo[42], hi[42];
-            int spins = 0;
-            for (;;)
+            // every listed granule once (the later neighbours hold the previous sweep's means and cannot change before
+            // this voxel is done: they wait for it) ...
+#pragma unroll
+            for (int e = 0; e < 42; e++)
             {
+                const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
+                const bool want = r.alive && np >= 0 && (e < 6 || second);
+                const size_t at = (size_t)(want ? np : 0) * 2;
+                lo[e] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[e] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (next && s == 0)
+                next->load(sa, next_pos, ns);
+            // ... then only the neighbours of earlier levels that do not carry this sweep's serial number yet, again
+            unsigned long long pending = 0;
 #pragma unroll
-                for (int e = 0; e < 42; e++)
-                {
-                    const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
-                    const bool want = r.alive && np >= 0 && (e < 6 || second);
-                    const size_t at = (size_t)(want ? np : 0) * 2;
-                    lo[e] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi[e] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (next && s == 0 && spins == 0)
-                    next->load(sa, next_pos, ns);
-                bool ready = true;
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                {
-                    const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
-                    if (r.alive && np >= 0 && np < level_begin && (e < 6 || second))
-                        ready = ready && ((lo[e] >> 32) == serial) && ((hi[e] >> 32) == serial);
-                }
-                if (ready)
-                    break;
+            for (int e = 0; e < 42; e++)
+            {
+                const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
+                if (r.alive && np >= 0 && np < level_begin && (e < 6 || second)
+                    && (((lo[e] >> 32) != serial) || ((hi[e] >> 32) != serial)))
+                    pending |= 1ull << e;
+            }
+            int spins = 0;
+            while (__any(pending != 0))
+            {
                 if (++spins > (1 << 22)) // never (every wave of the grid is resident); the run is repeated
                 {
                     sa.sw_flags[0] = 1;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                    if ((pending >> e) & 1)
+                    {
+                        const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
+                        lo[e] = __hip_atomic_load(g + (size_t)np * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[e] = __hip_atomic_load(g + (size_t)np * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                    if (((pending >> e) & 1) && ((lo[e] >> 32) == serial) && ((hi[e] >> 32) == serial))
+                        pending &= ~(1ull << e);
             }
             if (!r.alive)
                 continue;

@@ -358,11 +358,15 @@ int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const void *data, co
  * fabber_vb_run_spatial_host on several devices of the node, driven by the calling process: the volume is cut
  * into z-slabs (cuts on plane boundaries, balanced by voxel count; ghost planes each side: one, two with priors
  * of type P / p), slab r on devices[r] (NULL / 0 = every visible device; a device may be listed several times).
- * The first sweep keeps the reference's order across the cuts - the slabs step through the SAME global levels as a
- * pipeline, slab r one chunk of levels behind slab r - 1, boundary planes handed upwards device to device after
- * every chunk -, the a_K sums are added over the segments of the voxel list in voxel order: the images are those of
- * the one-device run bit for bit. Fewer slabs than devices where the volume has too few planes. Host pointers
- * throughout; models evaluated on the host are not taken (-56).
+ * The first sweep keeps the reference's order across the cuts. First-neighbour priors (types M, m): every slab runs the
+ * slab sweep of the one-device run (one launch per slab and iteration, all at once); a voxel whose z+1 neighbour lives on
+ * the device above writes its new mean into that neighbour's inbox there (fine-grained peer memory, system-scope stores,
+ * self-validating granules), where the lowest plane waits for it as it waits for a workgroup of its own device.
+ * Second-neighbour priors (P, p), or a decomposition the slab form does not take: the slabs step through the SAME global
+ * levels as a pipeline, slab r one chunk of levels behind slab r - 1, boundary planes handed upwards after every chunk.
+ * Either way the a_K sums are added over the segments of the voxel list in voxel order: the images are those of the
+ * one-device run bit for bit. Fewer slabs than devices where the volume has too few planes. Host pointers throughout;
+ * models evaluated on the host are not taken (-56); with locked linearisation centres the run uses devices[0] alone.
  */
 int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
     const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int));

@@ -202,6 +202,92 @@ def test_two_echoes_on_the_gpu(cross, need_f):
     assert_close_to_oracle(h, y.astype(np.float32))
 
 
+# ---- the lane-per-voxel kernel for two echoes (csrc/vb_lane_arn_kernel.h: two streaming passes per iteration) ----
+def run_on_the_lane_kernel(h, y):
+    hiplib.set_variant("lane")
+    try:
+        assert "lane_ar2" in hiplib.kernel_name(h), hiplib.kernel_name(h)
+        return hipengine.run(h, y)
+    finally:
+        hiplib.set_variant("auto")
+
+
+def assert_lane_close_to_oracle(h, y, rtol=1e-6):
+    ref = oracle.run(h, y)
+    got = run_on_the_lane_kernel(h, y)
+    assert np.array_equal(ref["status"], got["status"])
+    assert np.array_equal(ref["iterations"], got["iterations"])
+    ok = ref["status"] == 0
+    n = h.cfg.n_params + h.n_noise_outputs
+    off = n * (n + 1) // 2
+    sd = np.sqrt(np.abs(np.stack([ref["mvn"][p * (p + 1) // 2 + p] for p in range(n)])))
+    scale = np.maximum(np.abs(ref["mvn"][off:off + n]), sd)
+    err = np.abs(got["mvn"][off:off + n] - ref["mvn"][off:off + n]) / scale
+    assert err[:, ok].max() < rtol, err[:, ok].max()
+    row = 0
+    for r in range(n):
+        for c in range(r + 1):
+            d = np.abs(got["mvn"][row] - ref["mvn"][row])[ok] / np.maximum(sd[r] * sd[c], 1e-300)[ok]
+            assert d.max() < 10 * rtol, (r, c, d.max())
+            row += 1
+    if h.cfg.need_f:
+        assert np.allclose(got["free_energy"][ok], ref["free_energy"][ok], rtol=1e-7, atol=1e-6)
+    return ref, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross", ["none", "same", "dual"])
+@pytest.mark.parametrize("need_f", [False, True])
+def test_two_echoes_on_the_lane_kernel(cross, need_f):
+    """strict per-voxel parity with vb_oracle_arn.inc: every cross-term variant (2 / 3 / 4 AR coefficients), with and
+    without the free energy (evaluated four times per iteration, inference_vb.cc:468-495); also the automatic choice
+    from 4096 voxels up"""
+    h, y, _ = two_echo_problem(200, 60, seed=7, cross=cross, max_iterations=8, need_f=need_f)
+    assert_lane_close_to_oracle(h, y.astype(np.float32))
+    h, y, _ = two_echo_problem(4100, 40, seed=17, cross=cross, max_iterations=4, need_f=need_f)
+    assert "lane_ar2" in hiplib.kernel_name(h)
+    ref, got = oracle.run(h, y.astype(np.float32)), hipengine.run(h, y.astype(np.float32))
+    n = 4 + 2 + {"none": 0, "same": 1, "dual": 2}[cross] + 2
+    off = n * (n + 1) // 2
+    assert np.array_equal(ref["status"], got["status"])
+    assert np.allclose(got["mvn"][off:off + n], ref["mvn"][off:off + n], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv", ["pointzeroone", "freduce", "trialmode", "lm"])
+def test_two_echoes_lane_kernel_with_free_energy_detectors(conv):
+    """detectors that save and revert (the alpha posterior and both precisions travel with the saved state)"""
+    h, y, _ = two_echo_problem(150, 60, seed=8, cross="dual", max_iterations=20, convergence=conv, min_fchange=0.01)
+    ref = oracle.run(h, y.astype(np.float32))
+    got = run_on_the_lane_kernel(h, y.astype(np.float32))
+    same = ref["iterations"] == got["iterations"]
+    assert same.mean() > 0.97
+    n = 4 + 4 + 2
+    off = n * (n + 1) // 2
+    assert np.allclose(got["mvn"][off:off + n, same], ref["mvn"][off:off + n, same], rtol=1e-5, atol=1e-7)
+    assert np.allclose(got["free_energy"][same], ref["free_energy"][same], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_two_echoes_lane_kernel_continue_from_mvn_models_and_float64_series():
+    h, y, X = two_echo_problem(64, 60, seed=9, cross="same", max_iterations=3)
+    first = run_on_the_lane_kernel(h, y.astype(np.float32))
+    h2 = vbabi.build_config(vbabi.MODEL_LINEAR, 64, 60, design=X, noise=AR, num_echoes=2, ar_cross_terms="same",
+                            max_iterations=3, init_mvn=first["mvn"])
+    assert_lane_close_to_oracle(h2, y.astype(np.float32))
+    he, ye = cases.exp_problem(128, 60, 1, 0.04, seed=3, noise_sd=0.05, noise=AR, num_echoes=2, max_iterations=8, need_f=True)
+    assert_lane_close_to_oracle(he, ye, rtol=1e-5)
+    hp, yp = cases.poly_problem(100, 24, 2, seed=5, noise=AR, num_echoes=2, ar_cross_terms="dual", max_iterations=6, need_f=True)
+    assert_lane_close_to_oracle(hp, yp, rtol=1e-5)
+    h64, y64, _ = two_echo_problem(90, 60, seed=10, cross="dual", max_iterations=5, need_f=True)
+    assert_lane_close_to_oracle(h64, y64.astype(np.float64))
+    # a failing voxel (non-finite sample) stops alone
+    yb = y.astype(np.float32).copy()
+    yb[5, 3] = np.nan
+    ref, got = oracle.run(h, yb), run_on_the_lane_kernel(h, yb)
+    assert np.array_equal(ref["status"] != 0, got["status"] != 0) and got["status"][3] != 0
+
+
 @pytest.mark.gpu
 def test_one_echo_wave_kernel_matches_oracle_and_lane_kernel():
     h, y = cases.linear_problem(300, 80, seed=3, max_iterations=8, noise=AR, need_f=True)

@@ -264,8 +264,9 @@ def test_nlls_third_party_model_against_an_independent_least_squares_fit(plugin,
     """tests/plugins/fwdmodel_bump.cc under method=nlls: the minimum of the sum of squares is what SciPy's
     least-squares solver finds for the same model. The reference starts NLLS from HardcodedInitialDists' posterior
     (inference_nlls.cc:68-82), which models that describe themselves through GetParameterDefaults leave at zero
-    (fwdmodel.h:305) - a zero width here, where the model is not finite: every voxel takes the catch branch
-    (:186-207). With a starting estimate from a file (fwd-inital-posterior) the fit runs."""
+    (fwdmodel.h:305) - a zero width here, where the model and its Jacobian are identically zero: no step lowers the
+    cost, the damping runs up to its limit, the start comes back with the floor precision 1e-6 (:164-170). With a
+    starting estimate from a file (fwd-inital-posterior) the fit runs."""
     import scipy.optimize
     rng = np.random.default_rng(12)
     shape, T = (4, 4, 3), 24
@@ -279,7 +280,7 @@ def test_nlls_third_party_model_against_an_independent_least_squares_fit(plugin,
     out = fabber.run(data, opts, model_libs=[plugin])
     assert "evaluated on the host" in out["log"]
     assert np.all(out["mean_mu"] == 0) and np.all(out["mean_width"] == 0) and np.all(out["mean_amp"] == 1)
-    assert np.allclose(out["finalMVN"][..., 0], 1e12)  # precisions 1e-12
+    assert np.allclose(out["finalMVN"][..., 0], 1e6)  # J'J = 0: the diagonal is raised to 1e-6
     start = np.zeros((4, 4))
     start[:3, :3] = np.eye(3)
     start[:3, 3] = start[3, :3] = [np.log(2.0), 10.0, 3.0]  # Fabber space: amp is LOG-transformed

@@ -270,7 +270,9 @@ def test_failed_voxels_are_ignored_as_in_the_reference(typ):
     """With F evaluated, the non-finite sample is caught by the first CalculateF of the sweep,
     before the voxel's means change: exactly the three voxels fail."""
     h, sp, y, bad = failing_voxel_problem(typ)
-    spatial_check(h, sp, y, "IgnoreVoxel " + typ, check_f=True)
+    # (type p: 1.5e-6 on one mean where the two CPU builds differ by 2.0e-6 - the kernels contract multiply-adds as the
+    # FMA build of the oracle does, DESIGN 5.1)
+    spatial_check(h, sp, y, "IgnoreVoxel " + typ, check_f=True, allow_floor=(typ == "p"))
     got = hiplib.run_spatial_host(h, sp, y)
     assert sorted(np.flatnonzero(got["status"]).tolist()) == sorted(bad)
 
