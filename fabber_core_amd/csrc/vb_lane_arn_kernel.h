@@ -486,8 +486,13 @@ __device__ __forceinline__ void restore_arn(const KernelArgs &ka, int v, ArnAlph
 
 // FEED: FEED_TILES_F32 / FEED_TILES_F64 - the series is always read from the tiled copy (AR noise rejects masked
 // timepoints, noisemodel_ar.cc:351-355)
+// Registers: the two passes' accumulators, the three-row window and the alpha posterior next to the voxel state do
+// not fit 256 VGPRs (363 - 2164 spilled with two waves per SIMD). With ONE wave per SIMD the spills land in the
+// other half of the register file (AGPRs) instead of scratch: measured at T = 200, P = 4, 262 144 voxels, 10
+// iterations (tools/measure/ar_wave_rate.py) 36.9 against 24.9 M voxels/s with four AR coefficients, 19.1 against
+// 9.3 with F; only the smallest variant (no cross terms, no F) is faster with two waves (54.5 against 43.7).
 template <class Model, int P, int NA, bool NEEDF, int FEED>
-__global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_arn_kernel(const KernelArgs ka)
+__global__ __launch_bounds__(64, (NA == 2 && !NEEDF) ? 2 : 1) void vb_lane_arn_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
     constexpr int NT = NA * (NA + 1) / 2;

@@ -1832,8 +1832,10 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
     int max_halo = 1;
     for (int r = 0; r < world; r++)
         max_halo = std::max(max_halo, std::max(slabs[r]->b - slabs[r]->g0, slabs[r]->g1 - slabs[r]->e));
-    for (int r = 0; r < world; r++)
-    {
+    // every slab is opened (buffers, uploads, neighbour table, numbering, set-up) by a host thread of its own: the
+    // devices work side by side, and on one device the uploads of one slab overlap the numbering of another
+    auto open_slab = [&](int r) -> int {
+        int rc = 0;
         SlabRun &sl = *slabs[r];
         const size_t Vl = (size_t)(sl.g1 - sl.g0);
         FVB_HIP_CHECK(hipSetDevice(sl.dev));
@@ -1907,6 +1909,28 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
         sl.run->device_share = (int)std::count(devs.begin(), devs.begin() + world, sl.dev);
         if ((rc = sl.run->open(&sl.d, &sl.sp, sl.b_data.p, &sl.dout, st)) != 0)
             return rc;
+        return 0;
+    };
+    {
+        std::vector<int> rcs((size_t)world, 0);
+        std::vector<std::string> errs((size_t)world);
+        auto work = [&](int r) {
+            rcs[(size_t)r] = open_slab(r);
+            if (rcs[(size_t)r] != 0)
+                errs[(size_t)r] = fabber_vb_last_error(); // (thread-local: carried to the caller's thread)
+        };
+        std::vector<std::thread> pool;
+        const bool threads = !getenv("FVB_SPATIAL_MULTI_SERIAL");
+        for (int r = 1; r < world && threads; r++)
+            pool.emplace_back(work, r);
+        work(0);
+        for (int r = 1; r < world && !threads; r++)
+            work(r);
+        for (auto &th : pool)
+            th.join();
+        for (int r = 0; r < world; r++)
+            if (rcs[(size_t)r] != 0)
+                return api_fail(rcs[(size_t)r], errs[(size_t)r]);
     }
     const double ms_open = since(t_begin);
     const auto t_loop = std::chrono::steady_clock::now();
@@ -2154,6 +2178,15 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
     }
     const double ms_out = since(t_out);
     const auto t_free = std::chrono::steady_clock::now();
+    {
+        // (giving a slab's memory back unmaps it: a thread per slab here too)
+        std::vector<std::thread> pool;
+        for (int r = 1; r < world; r++)
+            pool.emplace_back([&slabs, r]() { slabs[(size_t)r].reset(); });
+        slabs[0].reset();
+        for (auto &th : pool)
+            th.join();
+    }
     slabs.clear();
     if (timing)
         fprintf(stderr, "[fvb spatial] %d slabs (%s): upload + geometry + set-up %.1f ms, %d iterations %.1f ms, results %.1f ms, "
