@@ -365,6 +365,31 @@ def test_two_echoes_through_the_c_abi(cross, n_alphas, tmp_path):
     assert np.allclose(out["noise_means"].reshape(48, 2, order="F").T, eng["mvn"][off + 4:off + 6], rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.gpu
+def test_two_echoes_through_the_c_abi_at_a_volume_that_takes_the_lane_kernel(tmp_path):
+    """from 4096 voxels up fabber_dorun runs the same options on lane_ar2 (vb_lane_arn_kernel.h): the logfile names the
+    kernel, the images are the engine call's, and a few voxels are checked against the oracle"""
+    V = 17 * 16 * 16
+    h, y, X = two_echo_problem(V, 60, seed=12, cross="dual", max_iterations=5, need_f=True)
+    design = tmp_path / "design.mat"
+    np.savetxt(design, X)
+    vol = y.astype(np.float32).T.reshape(17, 16, 16, 60, order="F")
+    out = fabber.run(vol, {"model": "linear", "basis": str(design), "noise": "ar", "num-echoes": 2, "ar1-cross-terms": "dual",
+                           "method": "vb", "max-iterations": 5, "save-mean": True, "save-mvn": True, "save-free-energy": True})
+    assert "lane_ar2<linear,4,4,F>" in out["log"]
+    eng = hipengine.run(h, y.astype(np.float32))
+    assert np.allclose(out["finalMVN"].reshape(V, -1, order="F").T, eng["mvn"], rtol=2e-6, atol=1e-10)
+    assert np.allclose(out["freeEnergy"].reshape(V, order="F"), eng["free_energy"], rtol=1e-6)
+    hs, ys, _ = two_echo_problem(V, 60, seed=12, cross="dual", max_iterations=5, need_f=True)
+    pick = np.arange(0, V, 97)
+    hs.cfg.n_voxels = len(pick)
+    ref = oracle.run(hs, np.ascontiguousarray(ys.astype(np.float32)[:, pick]))
+    n = 4 + 4 + 2
+    off = n * (n + 1) // 2
+    assert np.allclose(eng["mvn"][off:off + n, pick], ref["mvn"][off:off + n], rtol=1e-5, atol=1e-7)
+    assert np.allclose(eng["free_energy"][pick], ref["free_energy"], rtol=1e-7, atol=1e-6)
+
+
 def test_echo_options_are_validated():
     with fabber.Fabber() as f:
         f.set_extent((2, 2, 1))
