@@ -1278,10 +1278,13 @@ __global__ __launch_bounds__(256) void vb_spatial_sweep2_kernel(const SpatialArg
 {
     const int ns = sa.n_spatial;
     const int nl = sa.n_levels;
-    const int stride = gridDim.x * 256;
-    const int lane0 = blockIdx.x * 256 + threadIdx.x;
+    // (launched with ONE wave per workgroup: the 150 gathered loads per voxel and level go through the texture
+    // addresser of the compute unit, which four waves of one workgroup would share)
+    const int W = blockDim.x;
+    const int stride = gridDim.x * W;
+    const int lane0 = blockIdx.x * W + threadIdx.x;
     extern __shared__ int s_tab[]; // [2][n_levels]: first position, voxel count
-    for (int i = threadIdx.x; i < nl; i += 256)
+    for (int i = threadIdx.x; i < nl; i += W)
     {
         s_tab[i] = sa.sw_level_pos[i];
         s_tab[nl + i] = sa.sw_level_count[i];

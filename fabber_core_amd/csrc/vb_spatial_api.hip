@@ -1157,9 +1157,12 @@ int fvb_spatial_run::sweep_fast(int it)
     int wg_cap = 64;
     if (const char *forced = getenv("FVB_SPATIAL_SWEEP_WGS")) // tests: levels with more voxels than the launch has lanes
         wg_cap = std::max(1, std::min(64, atoi(forced)));
-    if (fast_second) // one voxel per lane
-        hipLaunchKernelGGL(k.sweep2[which], dim3((unsigned)std::max(1, std::min(wg_cap, (max_level + 255) / 256))), dim3(256),
+    if (fast_second) // one voxel per lane, one wave per workgroup, as many workgroups as the longest level needs (all resident)
+    {
+        const int wgs = getenv("FVB_SPATIAL_SWEEP_WGS") ? wg_cap : 256;
+        hipLaunchKernelGGL(k.sweep2[which], dim3((unsigned)std::max(1, std::min(wgs, (max_level + 63) / 64))), dim3(64),
             2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
+    }
     else
     {
         const unsigned nwg = (unsigned)std::max(1, std::min(wg_cap, (max_level + 511) / 512)); // two voxels per lane
