@@ -93,7 +93,7 @@ struct SpatialArgs
     // z-planes, inside a slab level-major; sw_level_pos / sw_level_count then describe the RUNS (one slab's
     // voxels of one level), sl_first_run[s] .. sl_first_run[s + 1] are slab s's, and a granule is the INBOX of its
     // voxel: the mean of the z-1 neighbour when that lives in the slab below ----
-    int32_t sl_mode;         // 1 = slab form
+    int32_t sl_mode;         // 1 = slab form; 2 = slab form with second neighbours (granules are the voxels' own, as in the data-flow sweep)
     int32_t n_slabs;
     const int32_t *sl_first_run; // [n_slabs + 1]
     int32_t sl_width;        // lanes that work on one run (a multiple of 64 that divides 1024)
@@ -707,7 +707,7 @@ __device__ __forceinline__ void store_sc1(double *p, double x)
 __device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, uint32_t serial, int v = -1)
 {
     const size_t NP = (size_t)sa.n_pos;
-    if (sa.sl_mode)
+    if (sa.sl_mode == 1)
     {
         // slab form: the granules are inboxes - give every later neighbour's inbox this voxel's old mean
         if (v < 0)
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
                 sa.sw_q[si * NP + pos] = second ? spatial_prec : pcov * spatial_prec;
                 sa.sw_rec[si * NP + pos] = second ? ((nn != 0) ? 1 / double(8 * nn - nn2) : 0.0) : 1 / double(nn);
                 sa.sw_x[si * NP + pos] = st.m[k];
-                if (sa.sl_mode)
+                if (sa.sl_mode == 1)
                 {
                     // what each neighbour contributes if the sweep reaches it AFTER this voxel: its mean now
 #pragma unroll
@@ -1250,6 +1250,11 @@ __device__ __forceinline__ void sweep2_step(const SpatialArgs &sa, const SweepRe
                 pm = r.q[s] * spatial_mean;
             }
             sa.sw_pm[s * NP + pos] = pm;
+#ifdef FVB_SLAB2_DEBUG
+            if (sa.sw_serial == 1 && pos < 3)
+                printf("sweep2 pos %d: contrib %.17g contrib2 %.17g rec %.17g q %.17g pprec %.17g pm %.17g rhs0 %.17g np %d %d %d %d %d %d\n", pos, contrib, contrib2,
+                    r.rec[s], r.q[s], r.pprec[s], pm, r.rhs0[k], r.np[0], r.np[1], r.np[2], r.np[3], r.np[4], r.np[5]);
+#endif
 #pragma unroll
             for (int j = 0; j < P; j++)
                 if (j == k)
@@ -1585,6 +1590,285 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
     }
 }
 
+// ---- the ordered part, slab form, second neighbours (types P and p) -------------------------------------------
+// As the slab sweep above, for the stencil of priors.cc:377-385: with level = x + 2y + 3z the 3 + 15 listed neighbours
+// of EARLIER levels are up to 6 levels back. A workgroup (512 lanes) owns a slab of z-planes and keeps the means of
+// its last 8 runs in LDS; the slab's runs are its levels one by one, empty ones included, so the run of a neighbour
+// follows from the slot it has in the list (directions +x -x +y -y +z -z change the level by +1 -1 +2 -2 +3 -3: known
+// at compile time). Per slot:
+//   level change > 0 (3 + 15 slots): a later neighbour - its mean of the previous sweep, read from sw_x (nobody
+//       overwrites it before this voxel is done: it waits for this voxel);
+//   level change < 0, position inside the slab: LDS, run li + change, offset position - first position of that run;
+//   level change < 0, position below the slab: the neighbour's own granule in device-scope memory, polled until it
+//       carries this sweep's serial number (every voxel writes its granule when it is done, as in the data-flow form).
+// Sums in list order, the expressions of the other forms (second_order_mean / second_order_pm): the same bits.
+__device__ __forceinline__ constexpr int slab2_dir_level(int a)
+{
+    return a == 0 ? 1 : a == 1 ? -1 : a == 2 ? 2 : a == 3 ? -2 : a == 4 ? 3 : -3;
+}
+// slot e: 0..5 the first neighbours, 6 + a * 6 + b neighbour b of neighbour a
+__device__ __forceinline__ constexpr int slab2_slot_level(int e)
+{
+    return e < 6 ? slab2_dir_level(e) : slab2_dir_level((e - 6) / 6) + slab2_dir_level((e - 6) % 6);
+}
+
+template <int P, int NS>
+struct Slab2Record
+{
+    SweepRecord<P, NS> r;
+    int np2[36];
+    double later[NS][42]; // (only the slots of later levels are loaded and used)
+    unsigned long long lo[NS][42], hi[NS][42]; // (only the slots of earlier levels below the slab)
+    __device__ __forceinline__ int slot_pos(int e) const
+    {
+        return e < 6 ? r.np[e] : np2[e - 6];
+    }
+    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
+    {
+        r.load(sa, pos, ns);
+        const size_t NP = (size_t)sa.n_pos;
+        pos = pos >= 0 ? pos : 0;
+#pragma unroll
+        for (int e = 0; e < 36; e++)
+            np2[e] = sa.sw_npos2[(size_t)e * NP + pos];
+    }
+    // the second stage, once the positions have arrived: the later neighbours' means and a first look at the granules
+    // of the neighbours below the slab
+    __device__ __forceinline__ void gather(const SpatialArgs &sa, int ns, int slab_begin)
+    {
+        const size_t NP = (size_t)sa.n_pos;
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+            if (s < ns)
+            {
+                const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
+                const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                {
+                    const int np = slot_pos(e);
+                    const bool want = r.alive && np >= 0 && (e < 6 || second);
+                    if (slab2_slot_level(e) > 0)
+                        later[s][e] = sa.sw_x[(size_t)s * NP + (want ? np : 0)];
+                    else if (slab2_slot_level(e) < 0)
+                    {
+                        const bool below = want && np < slab_begin;
+                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + (below ? np : 0)) * 2;
+                        lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+    }
+};
+
+// wait until every neighbour below the slab carries this sweep's serial number
+template <int P, int NS>
+__device__ __forceinline__ void slab2_wait_below(const SpatialArgs &sa, Slab2Record<P, NS> &rec, int ns, int slab_begin)
+{
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
+            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
+            unsigned long long pending = 0;
+#pragma unroll
+            for (int e = 0; e < 42; e++)
+                if (slab2_slot_level(e) < 0)
+                {
+                    const int np = rec.slot_pos(e);
+                    if (rec.r.alive && np >= 0 && np < slab_begin && (e < 6 || second)
+                        && (((rec.lo[s][e] >> 32) != serial) || ((rec.hi[s][e] >> 32) != serial)))
+                        pending |= 1ull << e;
+                }
+            int spins = 0;
+            while (__any(pending != 0))
+            {
+                if (++spins > (1 << 22)) // never (a slab waits for the slabs below only); the run is repeated
+                {
+                    sa.sw_flags[0] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1))
+                    {
+                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + rec.slot_pos(e)) * 2;
+                        rec.lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rec.hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1) && ((rec.lo[s][e] >> 32) == serial)
+                        && ((rec.hi[s][e] >> 32) == serial))
+                        pending &= ~(1ull << e);
+            }
+        }
+}
+
+// one voxel's step: li = its run, tab = the slab's run table (first positions), ring = the LDS means [8][ns][stride]
+template <int P, int NS>
+__device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Record<P, NS> &rec, int pos, int slot, int ns, int li,
+    const int *tab, int slab_begin, double *ring, int stride)
+{
+    const SweepRecord<P, NS> &r = rec.r;
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+    double rhs[P], pm_out[NS];
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        rhs[j] = r.rhs0[j];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            const int k = sa.spatial_param[s];
+            const int type = sa.ka.cfg.prior_type[k];
+            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
+            double contrib = 0, contrib2 = 0;
+#pragma unroll
+            for (int e = 0; e < 42; e++)
+            {
+                const int np = rec.slot_pos(e);
+                if (np < 0 || (e >= 6 && !second))
+                    continue;
+                double val;
+                if (slab2_slot_level(e) > 0)
+                    val = rec.later[s][e];
+                else if (slab2_slot_level(e) < 0)
+                {
+                    if (np < slab_begin)
+                        val = __longlong_as_double((long long)((rec.hi[s][e] << 32) | (rec.lo[s][e] & 0xffffffffull)));
+                    else
+                    {
+                        const int run = li + slab2_slot_level(e);
+                        val = ring[((size_t)(run & 7) * ns + s) * stride + (np - tab[run])];
+                    }
+                }
+                else
+                    val = 0; // (a neighbour's neighbour that is the voxel itself: never listed)
+#ifdef FVB_SLAB2_DEBUG
+                {
+                    const unsigned long long *gq = sa.sw_gran + ((size_t)s * NP + np) * 2;
+                    const unsigned long long l0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long h0 = __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double vg = __longlong_as_double((long long)((h0 << 32) | (l0 & 0xffffffffull)));
+                    if ((sa.sl_debug & 16) && slab2_slot_level(e) > 0)
+                        val = vg;
+                    if ((sa.sl_debug & 32) && slab2_slot_level(e) < 0 && np >= slab_begin)
+                        val = vg;
+                    if ((sa.sl_debug & 64) && vg != val && ((h0 >> 32) == serial || slab2_slot_level(e) > 0))
+                        printf("slab2 pos %d slot %d level %d np %d: %.17g, granule %.17g (li %d tab %d)\n", pos, e, slab2_slot_level(e), np, val, vg, li,
+                            slab2_slot_level(e) < 0 ? tab[li + slab2_slot_level(e)] : -1);
+                }
+#endif
+                if (e < 6)
+                    contrib += val;
+                else
+                    contrib2 += -val;
+            }
+            double pm;
+            if (second)
+            {
+                const double spatial_mean = (r.rec[s] != 0) ? second_order_mean(contrib, contrib2, r.rec[s]) : 0.0;
+                pm = second_order_pm(1.0 / r.pprec[s], r.q[s], spatial_mean, sa.ka.cfg.prior_prec[k], sa.ka.cfg.prior_mean[k]);
+            }
+            else
+            {
+                const double spatial_mean = contrib * r.rec[s];
+                pm = r.q[s] * spatial_mean;
+            }
+            pm_out[s] = pm;
+#ifdef FVB_SLAB2_DEBUG
+            if (sa.sw_serial == 1 && pos < 3)
+                printf("slab2 pos %d: contrib %.17g contrib2 %.17g rec %.17g q %.17g pprec %.17g pm %.17g rhs0 %.17g np %d %d %d %d %d %d\n", pos, contrib, contrib2,
+                    r.rec[s], r.q[s], r.pprec[s], pm, r.rhs0[k], r.np[0], r.np[1], r.np[2], r.np[3], r.np[4], r.np[5]);
+#endif
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                if (j == k)
+                    rhs[j] = theta_rhs(rhs[j], r.pprec[s], pm);
+        }
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            double m = 0;
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                m = __builtin_fma(r.sig[s][j], rhs[j], m);
+            ring[((size_t)(li & 7) * ns + s) * stride + slot] = m;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+            unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
+            __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sa.sw_x[s * NP + pos] = m;
+            sa.sw_pm[s * NP + pos] = pm_out[s];
+        }
+}
+
+template <int P, int NS>
+__global__ __launch_bounds__(512) void vb_spatial_slab2_sweep_kernel(const SpatialArgs sa)
+{
+    extern __shared__ double s_mem[]; // [8][ns][sl_max_run] means of the last eight runs, then the slab's run table
+    const int ns = sa.n_spatial;
+    const int W = sa.sl_width, G = 512 / W;
+    const int g = threadIdx.x / W, lane = threadIdx.x % W; // (W is a multiple of 64: g is wave-uniform)
+    const int stride = sa.sl_max_run;
+    const int run0 = sa.sl_first_run[blockIdx.x], n_runs = sa.sl_first_run[blockIdx.x + 1] - run0;
+    int *tab = (int *)(s_mem + (size_t)8 * ns * stride); // [2][n_runs]: first position, count; then the counter
+    for (int i = threadIdx.x; i < n_runs; i += 512)
+    {
+        tab[i] = sa.sw_level_pos[run0 + i];
+        tab[n_runs + i] = sa.sw_level_count[run0 + i];
+    }
+    if (threadIdx.x == 0)
+        tab[2 * n_runs] = 0;
+    __syncthreads();
+    if (n_runs == 0)
+        return;
+    const int slab_begin = tab[0];
+    int *progress = tab + 2 * n_runs; // waves that have finished a run (every run gets W / 64 of them, in run order)
+    const int waves_per_group = W / 64;
+    Slab2Record<P, NS> rec;
+    if (g < n_runs)
+        rec.load(sa, lane < tab[n_runs + g] ? tab[g] + lane : -1, ns);
+    for (int li = g; li < n_runs; li += G)
+    {
+        const int begin = tab[li], count = tab[n_runs + li];
+        // second stage of this run's record (its positions were requested G runs ago), then the neighbours below
+        rec.gather(sa, ns, slab_begin);
+        if (lane < count)
+            slab2_wait_below<P, NS>(sa, rec, ns, slab_begin);
+        // runs 0 .. li - 1 complete? (the ring slot this run overwrites held run li - 8: read by runs up to li - 1)
+        const int need = li * waves_per_group;
+        while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        if (lane < count && rec.r.alive)
+            slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, slab_begin, s_mem, stride);
+        for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide)
+        {
+            Slab2Record<P, NS> one;
+            one.load(sa, begin + i, ns);
+            one.gather(sa, ns, slab_begin);
+            slab2_wait_below<P, NS>(sa, one, ns, slab_begin);
+            if (one.r.alive)
+                slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, slab_begin, s_mem, stride);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int nx = li + G;
+        if (nx < n_runs)
+            rec.load(sa, lane < tab[n_runs + nx] ? tab[nx] + lane : -1, ns);
+    }
+}
+
 // The rest of UpdateTheta after the split first sweep: the state holds this iteration's priors, Sigma and
 // log|det Lambda| (prep) and still the OLD means; the sweep left the spatial parameters' new means and prior means at
 // the voxel's level-major position. Returns false for a voxel that failed in prep (the run is being repeated anyway).
@@ -1769,6 +2053,7 @@ struct SpatialKernels
     int lds_classes;              // 1: setup / noise / noise_fast keep cfg.phi_index in LDS (n_times bytes of dynamic LDS)
     SpatialKernelFn noise_acc, noise_fast_acc; // the second sweep of the iterations that end in a pointwise re-centre, or NULL
     SpatialSweepFn sweep2[3];                  // the data-flow sweep with second neighbours (types P, p)
+    SpatialSweepFn slab_sweep2[3];             // ... and its slab form
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
@@ -1805,6 +2090,8 @@ SpatialKernelFn spatial_noise_acc(bool need_f)
                 vb_spatial_slab_sweep_kernel<PP, PP> }, 0,                                                   \
             spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f),    \
             { vb_spatial_sweep2_kernel<PP, 1>, vb_spatial_sweep2_kernel<PP, (PP < 2 ? PP : 2)>,                \
-                vb_spatial_sweep2_kernel<PP, PP> } };
+                vb_spatial_sweep2_kernel<PP, PP> },                                                          \
+            { vb_spatial_slab2_sweep_kernel<PP, 1>, vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)>,      \
+                vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)> } };
 
 } // namespace fvb

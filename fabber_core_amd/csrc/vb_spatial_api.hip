@@ -444,6 +444,7 @@ struct fvb_spatial_run
     bool multi_fast = false; // one of several slabs on several devices that sweep together (fabber_vb_run_spatial_host_multi)
     int device_share = 1;    // how many such slabs run on THIS device at once (a device listed several times)
     bool fast_second = false; // the split sweep with second neighbours (types P, p): vb_spatial_sweep2_kernel
+    bool slab2 = false;       // ... in its slab form: vb_spatial_slab2_sweep_kernel
     DevMem d_up_pos;
     std::vector<int32_t> h_pos_of; // (multi_fast: the numbering, for the slab below to address this slab's inboxes)
     int fast_prep(int it);
@@ -712,7 +713,17 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     std::vector<int32_t> pos_of, level_pos, level_count, slab_first;
     int n_pos = 0, sl_width = 64, sl_max_run = 0, sl_dz = 0;
     slab_form = false;
-    if (eligible && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll")) && lmax - lmin < (1LL << 22))
+    // (second-neighbour priors: the slab form with the last levels' means in LDS - vb_spatial_slab2_sweep_kernel -, whole
+    // volumes on one device; its runs are numbered on the host and include the EMPTY levels of a slab, so that a
+    // neighbour's run follows from its level)
+    // NOT what runs yet: FVB_SPATIAL_SLAB2=1 only. The kernel is 2.6 x faster than the data-flow form (4.9 against
+    // 12.8 ms per iteration at 128^3) but its results differ from the per-level sweep's for voxels whose +x neighbour is
+    // missing and for every voxel of a 2-D / 3-D volume: until that is found, types P / p keep the
+    // data-flow sweep.
+    const bool eligible_slab2 = allow_fast && has_spatial && second_neighbours && whole && !multi_fast && n_owned > 0
+        && !getenv("FVB_SPATIAL_PER_LEVEL") && getenv("FVB_SPATIAL_SLAB2") != nullptr;
+    if ((eligible || eligible_slab2) && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll"))
+        && lmax - lmin < (1LL << 22))
     {
         // Slab-major numbering: a slab = dz z-planes, inside a slab the voxels level by level (index order in a
         // level). dz: as few planes as keep the slabs within the chip's workgroups (every slab is one resident
@@ -722,7 +733,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         // (with the co-ordinates on the device - the usual case - the numbering is three small kernels there; the
         // host does it with its threads otherwise: 3 ms at 128^3 against 0.2)
         // (a slab with ghost planes is numbered on the host: the device kernels number every local voxel)
-        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING") && whole;
+        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING") && whole && !second_neighbours;
         int zmin = Z[owned_begin], zmax = Z[owned_begin];
         if (on_dev)
         {
@@ -777,10 +788,29 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 });
             slab_first.assign((size_t)n_slabs + 1, 0);
             int32_t running = 0;
+            // (second neighbours: the last level of each slab that has voxels, so that the empty ones before it get runs)
+            std::vector<size_t> last_key((size_t)n_slabs, 0);
+            std::vector<char> any_key((size_t)n_slabs, 0);
+            if (second_neighbours)
+                for (size_t key = 0; key < nk; key++)
+                {
+                    int32_t n = 0;
+                    for (int t = 0; t < nth; t++)
+                        n += count[t][key];
+                    if (n > 0)
+                    {
+                        last_key[key / nl] = key;
+                        any_key[key / nl] = 1;
+                    }
+                }
+            bool started = false;
             for (size_t key = 0; key < nk; key++)
             {
                 if (key % nl == 0)
+                {
                     slab_first[key / nl] = (int32_t)level_pos.size();
+                    started = false;
+                }
                 const int32_t begin = running;
                 for (int t = 0; t < nth; t++) // thread order = index order
                 {
@@ -788,7 +818,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                     count[t][key] = running;
                     running += n;
                 }
-                if (running > begin)
+                started = started || running > begin;
+                if (running > begin || (second_neighbours && started && any_key[key / nl] && key <= last_key[key / nl]))
                 {
                     level_pos.push_back(begin);
                     level_count.push_back(running - begin);
@@ -796,7 +827,16 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 }
             }
             slab_first[(size_t)n_slabs] = (int32_t)level_pos.size();
-            if (sl_max_run <= 8192 && n_slabs <= slab_cap)
+            int most_runs = 0;
+            for (size_t b = 0; b + 1 < slab_first.size(); b++)
+                most_runs = std::max(most_runs, (int)(slab_first[b + 1] - slab_first[b]));
+            int n_sp = 0;
+            for (int kk = 0; kk < P; kk++)
+                n_sp += cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M;
+            // (second neighbours: 8 runs of means and the run table in at most 144 KB of LDS, runs within the 512 lanes)
+            const bool slab2_fits = !second_neighbours
+                || (n_sp <= 2 && sizeof(double) * 8 * (size_t)n_sp * sl_max_run + sizeof(int32_t) * (2 * (size_t)most_runs + 2) <= 144 * 1024 && sl_max_run <= 512);
+            if (sl_max_run <= 8192 && n_slabs <= slab_cap && slab2_fits)
             {
                 if (on_dev)
                 {
@@ -819,10 +859,12 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 }
                 n_pos = (n_owned + 15) / 16 * 16;
                 // lanes per run: the next power of two from 64 that holds the longest run, 1024 at most
-                while (sl_width < sl_max_run && sl_width < 1024)
+                while (sl_width < sl_max_run && sl_width < (second_neighbours ? 512 : 1024))
                     sl_width *= 2;
                 if (const char *forced = getenv("FVB_SPATIAL_SLAB_WIDTH")) // tests: lanes that take several voxels of a run
-                    sl_width = std::max(64, std::min(1024, atoi(forced) / 64 * 64));
+                    sl_width = std::max(64, std::min(second_neighbours ? 512 : 1024, atoi(forced) / 64 * 64));
+                if (second_neighbours && 512 % sl_width != 0) // (the 512 lanes are whole groups)
+                    sl_width = 64;
                 sl_dz = (int)dz;
                 slab_form = true;
                 level_begin_counts = level_count;
@@ -841,6 +883,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     const bool eligible2 = allow_fast && has_spatial && second_neighbours && whole && n_owned > 0 && !getenv("FVB_SPATIAL_PER_LEVEL");
     fast = slab_form || ((eligible || eligible2) && whole && level_begin.size() <= 6000);
     fast_second = fast && second_neighbours;
+    slab2 = slab_form && second_neighbours;
     if (slab_form && !whole)
     {
         // ghosts have no position: what stands in sw_npos for them says where their mean comes from (vb_spatial.h)
@@ -973,7 +1016,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             sa.sw_nbr = f + (5 * ns + (size_t)P + ns * (size_t)P) * NP;
             FVB_HIP_CHECK(d_slab_first.alloc(sizeof(int32_t) * slab_first.size(), stream));
             FVB_HIP_CHECK(hipMemcpyAsync(d_slab_first.p, slab_first.data(), sizeof(int32_t) * slab_first.size(), hipMemcpyHostToDevice, stream));
-            sa.sl_mode = 1;
+            sa.sl_mode = second_neighbours ? 2 : 1;
             sa.n_slabs = (int32_t)slab_first.size() - 1;
             sa.sl_first_run = (const int32_t *)d_slab_first.p;
             sa.sl_width = sl_width;
@@ -1092,6 +1135,15 @@ int fvb_spatial_run::fast_sweep()
 {
     const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
     // one workgroup of 1024 lanes per slab (within the device's compute units, see the numbering)
+    if (slab2) // second neighbours: 512 lanes, the last 8 runs' means in LDS
+    {
+        const size_t lds2 = sizeof(double) * 8 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
+        if (lds2 > 48 * 1024)
+            FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep2[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k.slab_sweep2[which], dim3((unsigned)sa.n_slabs), dim3(512), lds2, stream, sa);
+        FVB_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
     if (lds > 48 * 1024)
         FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -682,6 +682,9 @@ SpatialKernels spatial_nz_table(bool need_f, const char *name)
     k.sweep2[0] = vb_spatial_sweep2_kernel<PP, 1>;
     k.sweep2[1] = vb_spatial_sweep2_kernel<PP, (PP < 2 ? PP : 2)>;
     k.sweep2[2] = vb_spatial_sweep2_kernel<PP, PP>;
+    k.slab_sweep2[0] = vb_spatial_slab2_sweep_kernel<PP, 1>;
+    k.slab_sweep2[1] = vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
+    k.slab_sweep2[2] = vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
     k.lds_classes = NZ::LDS_CLASSES ? 1 : 0;
     return k;
 }

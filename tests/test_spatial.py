@@ -511,15 +511,20 @@ def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, m
         _, y = smooth_exp_data(coords, 20, 0.04, seed=36)
         h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 20, num_exps=1, dt=0.04, max_iterations=3, param_overrides={"amp1": dict(type="P")})
     sp = vbabi.SpatialHolder(coords, **sp_kw)
-    split = hiplib.run_spatial_host(h, sp, y)
-    monkeypatch.setenv("FVB_SPATIAL_HOST_GEOMETRY", "1")
-    split_host = hiplib.run_spatial_host(h, sp, y)
-    monkeypatch.delenv("FVB_SPATIAL_HOST_GEOMETRY")
+    # (the slab form of this sweep - FVB_SPATIAL_SLAB2=1, vb_spatial_slab2_sweep_kernel - is not correct yet and not
+    # what runs: DESIGN 3.4)
+    forms = {}
+    for name, env in (("default", {}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        forms[name] = hiplib.run_spatial_host(h, sp, y)
+        for k in env:
+            monkeypatch.delenv(k)
     monkeypatch.setenv("FVB_SPATIAL_PER_LEVEL", "1")
     per_level = hiplib.run_spatial_host(h, sp, y)
-    for k in ("mvn", "status", "iterations", "free_energy"):
-        assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, k)
-        assert np.array_equal(split_host[k], per_level[k], equal_nan=True), (case, k)
+    for name, split in forms.items():
+        for k in ("mvn", "status", "iterations", "free_energy"):
+            assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, name, k)
 
 
 @gpu
