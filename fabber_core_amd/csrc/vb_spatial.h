@@ -1250,11 +1250,14 @@ __device__ __forceinline__ void sweep2_step(const SpatialArgs &sa, const SweepRe
                 pm = r.q[s] * spatial_mean;
             }
             sa.sw_pm[s * NP + pos] = pm;
-#ifdef FVB_SLAB2_DEBUG
-            if (sa.sw_serial == 1 && pos < 3)
-                printf("sweep2 pos %d: contrib %.17g contrib2 %.17g rec %.17g q %.17g pprec %.17g pm %.17g rhs0 %.17g np %d %d %d %d %d %d\n", pos, contrib, contrib2,
-                    r.rec[s], r.q[s], r.pprec[s], pm, r.rhs0[k], r.np[0], r.np[1], r.np[2], r.np[3], r.np[4], r.np[5]);
-#endif
+            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe (tools/measure/slab2_debug.py)
+            {
+                sa.sw_nbr[0 * NP + pos] = contrib;
+                sa.sw_nbr[1 * NP + pos] = contrib2;
+                sa.sw_nbr[2 * NP + pos] = pm;
+                sa.sw_nbr[4 * NP + pos] = r.q[s];
+                sa.sw_nbr[5 * NP + pos] = r.pprec[s];
+            }
 #pragma unroll
             for (int j = 0; j < P; j++)
                 if (j == k)
@@ -1275,6 +1278,8 @@ __device__ __forceinline__ void sweep2_step(const SpatialArgs &sa, const SweepRe
             __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sa.sw_x[s * NP + pos] = m;
+            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1)
+                sa.sw_nbr[3 * NP + pos] = m;
         }
 }
 
@@ -1747,25 +1752,15 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                     {
                         const int run = li + slab2_slot_level(e);
                         val = ring[((size_t)(run & 7) * ns + s) * stride + (np - tab[run])];
+                        if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe: the last LDS value, where from
+                        {
+                            sa.sw_nbr[5 * NP + pos] = val;
+                            sa.sw_nbr[4 * NP + pos] = 1000.0 * e + 100.0 * run + (np - tab[run]) + 0.001 * tab[run];
+                        }
                     }
                 }
                 else
                     val = 0; // (a neighbour's neighbour that is the voxel itself: never listed)
-#ifdef FVB_SLAB2_DEBUG
-                {
-                    const unsigned long long *gq = sa.sw_gran + ((size_t)s * NP + np) * 2;
-                    const unsigned long long l0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long h0 = __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double vg = __longlong_as_double((long long)((h0 << 32) | (l0 & 0xffffffffull)));
-                    if ((sa.sl_debug & 16) && slab2_slot_level(e) > 0)
-                        val = vg;
-                    if ((sa.sl_debug & 32) && slab2_slot_level(e) < 0 && np >= slab_begin)
-                        val = vg;
-                    if ((sa.sl_debug & 64) && vg != val && ((h0 >> 32) == serial || slab2_slot_level(e) > 0))
-                        printf("slab2 pos %d slot %d level %d np %d: %.17g, granule %.17g (li %d tab %d)\n", pos, e, slab2_slot_level(e), np, val, vg, li,
-                            slab2_slot_level(e) < 0 ? tab[li + slab2_slot_level(e)] : -1);
-                }
-#endif
                 if (e < 6)
                     contrib += val;
                 else
@@ -1783,11 +1778,12 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 pm = r.q[s] * spatial_mean;
             }
             pm_out[s] = pm;
-#ifdef FVB_SLAB2_DEBUG
-            if (sa.sw_serial == 1 && pos < 3)
-                printf("slab2 pos %d: contrib %.17g contrib2 %.17g rec %.17g q %.17g pprec %.17g pm %.17g rhs0 %.17g np %d %d %d %d %d %d\n", pos, contrib, contrib2,
-                    r.rec[s], r.q[s], r.pprec[s], pm, r.rhs0[k], r.np[0], r.np[1], r.np[2], r.np[3], r.np[4], r.np[5]);
-#endif
+            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe (tools/measure/slab2_debug.py)
+            {
+                sa.sw_nbr[0 * NP + pos] = contrib;
+                sa.sw_nbr[1 * NP + pos] = contrib2;
+                sa.sw_nbr[2 * NP + pos] = pm;
+            }
 #pragma unroll
             for (int j = 0; j < P; j++)
                 if (j == k)
@@ -1802,6 +1798,8 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
             for (int j = 0; j < P; j++)
                 m = __builtin_fma(r.sig[s][j], rhs[j], m);
             ring[((size_t)(li & 7) * ns + s) * stride + slot] = m;
+            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1)
+                sa.sw_nbr[3 * NP + pos] = m;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
             unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
             __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1848,7 +1846,7 @@ __global__ __launch_bounds__(512) void vb_spatial_slab2_sweep_kernel(const Spati
         const int need = li * waves_per_group;
         while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
             __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (lane < count && rec.r.alive)
             slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, slab_begin, s_mem, stride);
         for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide)
@@ -1860,7 +1858,7 @@ __global__ __launch_bounds__(512) void vb_spatial_slab2_sweep_kernel(const Spati
             if (one.r.alive)
                 slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, slab_begin, s_mem, stride);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((threadIdx.x & 63) == 0)
             __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int nx = li + G;

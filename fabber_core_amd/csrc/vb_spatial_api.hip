@@ -987,7 +987,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_pos.p, level_pos.data(), sizeof(int32_t) * level_pos.size(), hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_count.p, level_count.data(), sizeof(int32_t) * level_count.size(), hipMemcpyHostToDevice, stream));
         // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; slab form: nbr [ns][6][NP]
-        const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P + (slab_form ? 6 * ns : 0)) * NP;
+        const bool probe = getenv("FVB_SLAB_DEBUG") && (atoi(getenv("FVB_SLAB_DEBUG")) & 256);
+        const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P + ((slab_form || probe) ? 6 * ns : 0)) * NP;
         FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64, stream));
         const size_t n_i32 = (fast_second ? 43 : 7) * NP;
         FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * n_i32, stream)); // npos [6][NP], alive [NP], types P / p: npos2 [36][NP]
@@ -1011,6 +1012,11 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sw_rec = f + 4 * ns * NP;
         sa.sw_rhs0 = f + 5 * ns * NP;
         sa.sw_sig = f + (5 * ns + (size_t)P) * NP;
+        if (probe)
+        {
+            sa.sw_nbr = f + (5 * ns + (size_t)P + ns * (size_t)P) * NP;
+            sa.sl_debug = atoi(getenv("FVB_SLAB_DEBUG"));
+        }
         if (slab_form)
         {
             sa.sw_nbr = f + (5 * ns + (size_t)P + ns * (size_t)P) * NP;
@@ -1190,8 +1196,21 @@ int fvb_spatial_run::link_up(fvb_spatial_run &upper, int global_first, int upper
     return 0;
 }
 
+// probe of the second-neighbour sweeps (FVB_SLAB_DEBUG & 256): what the first sweep summed for every voxel, by voxel
+static int dump_probe(fvb_spatial_run &run, hipStream_t stream);
+
 int fvb_spatial_run::sweep_fast(int it)
 {
+    struct AtExit
+    {
+        fvb_spatial_run &r;
+        int it;
+        ~AtExit()
+        {
+            if (it == 0 && (r.sa.sl_debug & 256))
+                (void)dump_probe(r, r.stream);
+        }
+    } at_exit{ *this, it };
     if (slab_form)
     {
         int rc = fast_prep(it);
@@ -1222,6 +1241,22 @@ int fvb_spatial_run::sweep_fast(int it)
     }
     hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
     FVB_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int dump_probe(fvb_spatial_run &run, hipStream_t stream)
+{
+    const size_t NP = (size_t)run.sa.n_pos;
+    const int V = run.V;
+    std::vector<double> h(6 * NP);
+    std::vector<int32_t> pos((size_t)V);
+    FVB_HIP_CHECK(hipStreamSynchronize(stream));
+    FVB_HIP_CHECK(hipMemcpy(h.data(), run.sa.sw_nbr, sizeof(double) * 6 * NP, hipMemcpyDeviceToHost));
+    FVB_HIP_CHECK(hipMemcpy(pos.data(), run.sa.pos_of, sizeof(int32_t) * (size_t)V, hipMemcpyDeviceToHost));
+    for (int v = 0; v < V && v < 64; v++)
+        fprintf(stderr, "[probe] v %d pos %d contrib %.17g contrib2 %.17g pm %.17g m %.17g q %.17g pprec %.17g\n", v, pos[(size_t)v],
+            h[0 * NP + pos[(size_t)v]], h[1 * NP + pos[(size_t)v]], h[2 * NP + pos[(size_t)v]], h[3 * NP + pos[(size_t)v]], h[4 * NP + pos[(size_t)v]],
+            h[5 * NP + pos[(size_t)v]]);
     return 0;
 }
 
