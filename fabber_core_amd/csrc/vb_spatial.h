@@ -1596,34 +1596,25 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
 }
 
 // ---- the ordered part, slab form, second neighbours (types P and p) -------------------------------------------
-// As the slab sweep above, for the stencil of priors.cc:377-385: with level = x + 2y + 3z the 3 + 15 listed neighbours
-// of EARLIER levels are up to 6 levels back. A workgroup (512 lanes) owns a slab of z-planes and keeps the means of
-// its last 8 runs in LDS; the slab's runs are its levels one by one, empty ones included, so the run of a neighbour
-// follows from the slot it has in the list (directions +x -x +y -y +z -z change the level by +1 -1 +2 -2 +3 -3: known
-// at compile time). Per slot:
-//   level change > 0 (3 + 15 slots): a later neighbour - its mean of the previous sweep, read from sw_x (nobody
-//       overwrites it before this voxel is done: it waits for this voxel);
-//   level change < 0, position inside the slab: LDS, run li + change, offset position - first position of that run;
-//   level change < 0, position below the slab: the neighbour's own granule in device-scope memory, polled until it
-//       carries this sweep's serial number (every voxel writes its granule when it is done, as in the data-flow form).
+// As the slab sweep above, for the stencil of priors.cc:377-385: with level = x + 2y + 3z the listed neighbours of
+// EARLIER levels are up to 6 levels back. A workgroup (512 lanes) owns a slab of z-planes and keeps the means of its
+// last 8 runs in LDS; the slab's runs are its levels one by one, empty ones included, so an earlier neighbour inside
+// the slab sits in one of the six runs before the voxel's. Where a listed neighbour's mean comes from follows from
+// its POSITION alone (the neighbour table lists the neighbours that exist one after the other, not by direction):
+//   position >= the first position of the voxel's run: a later neighbour (same slab or a slab above) - its mean of
+//       the previous sweep, read from sw_x (nobody overwrites it before this voxel is done: it waits for this voxel);
+//   position < the slab's first position: a neighbour below the slab (always an earlier one: a step in z outweighs
+//       the steps in x and y) - its own granule in device-scope memory, polled until it carries this sweep's serial
+//       number (every voxel writes its granule when it is done, as in the data-flow form);
+//   else: LDS, the run among the last six that holds the position.
 // Sums in list order, the expressions of the other forms (second_order_mean / second_order_pm): the same bits.
-__device__ __forceinline__ constexpr int slab2_dir_level(int a)
-{
-    return a == 0 ? 1 : a == 1 ? -1 : a == 2 ? 2 : a == 3 ? -2 : a == 4 ? 3 : -3;
-}
-// slot e: 0..5 the first neighbours, 6 + a * 6 + b neighbour b of neighbour a
-__device__ __forceinline__ constexpr int slab2_slot_level(int e)
-{
-    return e < 6 ? slab2_dir_level(e) : slab2_dir_level((e - 6) / 6) + slab2_dir_level((e - 6) % 6);
-}
-
 template <int P, int NS>
 struct Slab2Record
 {
     SweepRecord<P, NS> r;
     int np2[36];
-    double later[NS][42]; // (only the slots of later levels are loaded and used)
-    unsigned long long lo[NS][42], hi[NS][42]; // (only the slots of earlier levels below the slab)
+    double val[NS][42];             // the means known before the voxel's turn: later neighbours, neighbours below
+    unsigned long long pending[NS]; // slots below the slab whose granule did not carry this sweep's number yet
     __device__ __forceinline__ int slot_pos(int e) const
     {
         return e < 6 ? r.np[e] : np2[e - 6];
@@ -1637,92 +1628,92 @@ struct Slab2Record
         for (int e = 0; e < 36; e++)
             np2[e] = sa.sw_npos2[(size_t)e * NP + pos];
     }
-    // the second stage, once the positions have arrived: the later neighbours' means and a first look at the granules
-    // of the neighbours below the slab
-    __device__ __forceinline__ void gather(const SpatialArgs &sa, int ns, int slab_begin)
+    // the second stage, once the positions have arrived (run_begin = first position of the voxel's run)
+    __device__ __forceinline__ void gather(const SpatialArgs &sa, int ns, int slab_begin, int run_begin)
     {
         const size_t NP = (size_t)sa.n_pos;
+        const unsigned long long serial = sa.sw_serial;
 #pragma unroll
         for (int s = 0; s < NS; s++)
             if (s < ns)
             {
                 const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
                 const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
+                pending[s] = 0;
 #pragma unroll
                 for (int e = 0; e < 42; e++)
                 {
                     const int np = slot_pos(e);
                     const bool want = r.alive && np >= 0 && (e < 6 || second);
-                    if (slab2_slot_level(e) > 0)
-                        later[s][e] = sa.sw_x[(size_t)s * NP + (want ? np : 0)];
-                    else if (slab2_slot_level(e) < 0)
+                    const bool later = want && np >= run_begin, below = want && np < slab_begin;
+                    double x = 0;
+                    if (later)
+                        x = sa.sw_x[(size_t)s * NP + np];
+                    else if (below)
                     {
-                        const bool below = want && np < slab_begin;
-                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + (below ? np : 0)) * 2;
-                        lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + np) * 2;
+                        const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        x = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                        if (((lo >> 32) != serial) || ((hi >> 32) != serial))
+                            pending[s] |= 1ull << e;
                     }
+                    val[s][e] = x;
+                }
+            }
+    }
+    // wait until every neighbour below the slab carries this sweep's serial number
+    __device__ __forceinline__ void wait_below(const SpatialArgs &sa, int ns)
+    {
+        const size_t NP = (size_t)sa.n_pos;
+        const unsigned long long serial = sa.sw_serial;
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+            if (s < ns)
+            {
+                int spins = 0;
+                while (__any(pending[s] != 0))
+                {
+                    if (++spins > (1 << 22)) // never (a slab waits for the slabs below only); the run is repeated
+                    {
+                        sa.sw_flags[0] = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int e = 0; e < 42; e++)
+                        if ((pending[s] >> e) & 1)
+                        {
+                            const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + slot_pos(e)) * 2;
+                            const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (((lo >> 32) == serial) && ((hi >> 32) == serial))
+                            {
+                                val[s][e] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                                pending[s] &= ~(1ull << e);
+                            }
+                        }
                 }
             }
     }
 };
 
-// wait until every neighbour below the slab carries this sweep's serial number
-template <int P, int NS>
-__device__ __forceinline__ void slab2_wait_below(const SpatialArgs &sa, Slab2Record<P, NS> &rec, int ns, int slab_begin)
-{
-    const size_t NP = (size_t)sa.n_pos;
-    const unsigned long long serial = sa.sw_serial;
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
-            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
-            unsigned long long pending = 0;
-#pragma unroll
-            for (int e = 0; e < 42; e++)
-                if (slab2_slot_level(e) < 0)
-                {
-                    const int np = rec.slot_pos(e);
-                    if (rec.r.alive && np >= 0 && np < slab_begin && (e < 6 || second)
-                        && (((rec.lo[s][e] >> 32) != serial) || ((rec.hi[s][e] >> 32) != serial)))
-                        pending |= 1ull << e;
-                }
-            int spins = 0;
-            while (__any(pending != 0))
-            {
-                if (++spins > (1 << 22)) // never (a slab waits for the slabs below only); the run is repeated
-                {
-                    sa.sw_flags[0] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1))
-                    {
-                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + rec.slot_pos(e)) * 2;
-                        rec.lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        rec.hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1) && ((rec.lo[s][e] >> 32) == serial)
-                        && ((rec.hi[s][e] >> 32) == serial))
-                        pending &= ~(1ull << e);
-            }
-        }
-}
-
-// one voxel's step: li = its run, tab = the slab's run table (first positions), ring = the LDS means [8][ns][stride]
+// one voxel's step: li = its run, tab = the slab's run table ([n_runs] first positions, [n_runs] counts), ring = the LDS
+// means [8][ns][stride]
 template <int P, int NS>
 __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Record<P, NS> &rec, int pos, int slot, int ns, int li,
-    const int *tab, int slab_begin, double *ring, int stride)
+    const int *tab, int n_runs, int slab_begin, double *ring, int stride)
 {
     const SweepRecord<P, NS> &r = rec.r;
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
+    const int run_begin = tab[li];
+    // the first positions of the six runs before this one (descending; nothing before the slab's first run)
+    int pb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        pb[k] = li - 1 - k >= 0 ? tab[li - 1 - k] : slab_begin;
+    (void)n_runs;
     double rhs[P], pm_out[NS];
 #pragma unroll
     for (int j = 0; j < P; j++)
@@ -1741,30 +1732,24 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 const int np = rec.slot_pos(e);
                 if (np < 0 || (e >= 6 && !second))
                     continue;
-                double val;
-                if (slab2_slot_level(e) > 0)
-                    val = rec.later[s][e];
-                else if (slab2_slot_level(e) < 0)
+                double v = rec.val[s][e];
+                if (np >= slab_begin && np < run_begin) // an earlier neighbour inside the slab: one of the last six runs
                 {
-                    if (np < slab_begin)
-                        val = __longlong_as_double((long long)((rec.hi[s][e] << 32) | (rec.lo[s][e] & 0xffffffffull)));
-                    else
+                    // (the runs' positions follow one another: the run is the first whose first position is <= np)
+                    int q = 0, base = pb[0];
+#pragma unroll
+                    for (int t = 1; t < 6; t++)
                     {
-                        const int run = li + slab2_slot_level(e);
-                        val = ring[((size_t)(run & 7) * ns + s) * stride + (np - tab[run])];
-                        if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe: the last LDS value, where from
-                        {
-                            sa.sw_nbr[5 * NP + pos] = val;
-                            sa.sw_nbr[4 * NP + pos] = 1000.0 * e + 100.0 * run + (np - tab[run]) + 0.001 * tab[run];
-                        }
+                        const bool further = np < pb[t - 1];
+                        q = further ? t : q;
+                        base = further ? pb[t] : base;
                     }
+                    v = ring[((size_t)((li - 1 - q) & 7) * ns + s) * stride + (np - base)];
                 }
-                else
-                    val = 0; // (a neighbour's neighbour that is the voxel itself: never listed)
                 if (e < 6)
-                    contrib += val;
+                    contrib += v;
                 else
-                    contrib2 += -val;
+                    contrib2 += -v;
             }
             double pm;
             if (second)
@@ -1778,11 +1763,13 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 pm = r.q[s] * spatial_mean;
             }
             pm_out[s] = pm;
-            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe (tools/measure/slab2_debug.py)
+            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe (tools/measure/slab2_probe.py)
             {
                 sa.sw_nbr[0 * NP + pos] = contrib;
                 sa.sw_nbr[1 * NP + pos] = contrib2;
                 sa.sw_nbr[2 * NP + pos] = pm;
+                sa.sw_nbr[4 * NP + pos] = r.q[s];
+                sa.sw_nbr[5 * NP + pos] = r.pprec[s];
             }
 #pragma unroll
             for (int j = 0; j < P; j++)
@@ -1839,24 +1826,23 @@ __global__ __launch_bounds__(512) void vb_spatial_slab2_sweep_kernel(const Spati
     {
         const int begin = tab[li], count = tab[n_runs + li];
         // second stage of this run's record (its positions were requested G runs ago), then the neighbours below
-        rec.gather(sa, ns, slab_begin);
-        if (lane < count)
-            slab2_wait_below<P, NS>(sa, rec, ns, slab_begin);
+        rec.gather(sa, ns, slab_begin, begin);
+        rec.wait_below(sa, ns);
         // runs 0 .. li - 1 complete? (the ring slot this run overwrites held run li - 8: read by runs up to li - 1)
         const int need = li * waves_per_group;
         while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
             __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (lane < count && rec.r.alive)
-            slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, slab_begin, s_mem, stride);
+            slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, n_runs, slab_begin, s_mem, stride);
         for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide)
         {
             Slab2Record<P, NS> one;
             one.load(sa, begin + i, ns);
-            one.gather(sa, ns, slab_begin);
-            slab2_wait_below<P, NS>(sa, one, ns, slab_begin);
+            one.gather(sa, ns, slab_begin, begin);
+            one.wait_below(sa, ns);
             if (one.r.alive)
-                slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, slab_begin, s_mem, stride);
+                slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, n_runs, slab_begin, s_mem, stride);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((threadIdx.x & 63) == 0)

@@ -716,10 +716,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     // (second-neighbour priors: the slab form with the last levels' means in LDS - vb_spatial_slab2_sweep_kernel -, whole
     // volumes on one device; its runs are numbered on the host and include the EMPTY levels of a slab, so that a
     // neighbour's run follows from its level)
-    // NOT what runs yet: FVB_SPATIAL_SLAB2=1 only. The kernel is 2.6 x faster than the data-flow form (4.9 against
-    // 12.8 ms per iteration at 128^3) but its results differ from the per-level sweep's for voxels whose +x neighbour is
-    // missing and for every voxel of a 2-D / 3-D volume: until that is found, types P / p keep the
-    // data-flow sweep.
+    // Not what runs by default (FVB_SPATIAL_SLAB2=1): correct - the bit-for-bit test covers it - but at 128^3 it takes
+    // 25 ms per iteration against the data-flow form's 12.8: its 42 slots per voxel have to be told apart
+    // by position at run time (the neighbour table lists the neighbours that exist, not directions), which costs the
+    // 512-lane workgroups their registers.
     const bool eligible_slab2 = allow_fast && has_spatial && second_neighbours && whole && !multi_fast && n_owned > 0
         && !getenv("FVB_SPATIAL_PER_LEVEL") && getenv("FVB_SPATIAL_SLAB2") != nullptr;
     if ((eligible || eligible_slab2) && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll"))

@@ -511,10 +511,13 @@ def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, m
         _, y = smooth_exp_data(coords, 20, 0.04, seed=36)
         h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 20, num_exps=1, dt=0.04, max_iterations=3, param_overrides={"amp1": dict(type="P")})
     sp = vbabi.SpatialHolder(coords, **sp_kw)
-    # (the slab form of this sweep - FVB_SPATIAL_SLAB2=1, vb_spatial_slab2_sweep_kernel - is not correct yet and not
-    # what runs: DESIGN 3.4)
+    # the forms of the ordered part: the data-flow form (what runs) and the slab form with the last levels' means in LDS
+    # (FVB_SPATIAL_SLAB2=1: correct, slower at volume size) with slabs of 1 / 2 / 3 planes
     forms = {}
-    for name, env in (("default", {}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"})):
+    for name, env in (("default", {}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"}),
+                      ("slab form", {"FVB_SPATIAL_SLAB2": "1"}), ("slab form, 2 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "2"}),
+                      ("slab form, 3 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "3"}),
+                      ("slab form, one slab", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "100"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         forms[name] = hiplib.run_spatial_host(h, sp, y)
