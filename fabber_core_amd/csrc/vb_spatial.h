@@ -81,6 +81,7 @@ struct SpatialArgs
     double *sw_sig;          // [n_spatial][P][n_pos] the spatial parameters' rows of Sigma
     int32_t *sw_npos;        // [6][n_pos] positions of the live first neighbours, -1 = none
     int32_t *sw_alive;       // [n_pos] 1 = the voxel takes part in the sweep
+    const int32_t *xyz;      // types P, p in a split form: [3][V] the voxels' co-ordinates (the tables below are written by direction)
     int32_t *sw_npos2;       // types P, p: [36][n_pos] positions of the live second neighbours in list order - slot
                              // a * 6 + b = neighbour b of neighbour a (priors.cc:377-385) -, -1 = none; else NULL
     const int32_t *sw_level_pos;   // [n_levels] first position of a level
@@ -785,10 +786,27 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     // list was fixed when it was built and reaches across a failed voxel), except v itself and the ones that have
     // failed (Vb::IgnoreVoxel, inference_vb.cc:266-297) - in list order, as positions
     int nn2_live = 0;
+    int dir1[6] = { 0, 1, 2, 3, 4, 5 }; // the direction (+x -x +y -y +z -z) of each listed first neighbour
     if (sa.sw_npos2) // (uniform)
     {
+        // The neighbour table lists the neighbours that exist one after the other. The sweeps' tables are written
+        // by DIRECTION instead (slot a = direction a, slot a * 6 + b = direction b from the neighbour in direction a;
+        // -1 where there is none): the order of the entries that exist is the same, so every sum is, and the slab
+        // form can tell from a slot alone how many levels away the neighbour is.
+        const size_t V3 = V;
+        const int x0 = sa.xyz[v], y0 = sa.xyz[V3 + v], z0 = sa.xyz[2 * V3 + v];
+        auto direction = [&](int xa, int ya, int za, int u) -> int {
+            const int dx = sa.xyz[u] - xa, dy = sa.xyz[V3 + u] - ya, dz = sa.xyz[2 * V3 + u] - za;
+            return dx > 0 ? 0 : (dx < 0 ? 1 : (dy > 0 ? 2 : (dy < 0 ? 3 : (dz > 0 ? 4 : 5))));
+        };
+        if (!ignored)
+            for (int e = 0; e < 36; e++)
+                sa.sw_npos2[(size_t)e * NP + pos] = -1;
         for (int a = 0; a < 6; a++)
         {
+            const int da = ok1[a] ? direction(x0, y0, z0, n1[a]) : a;
+            dir1[a] = da;
+            const int xa = sa.xyz[n1[a]], ya = sa.xyz[V3 + n1[a]], za = sa.xyz[2 * V3 + n1[a]];
             int n2[6];
 #pragma unroll
             for (int b = 0; b < 6; b++)
@@ -799,8 +817,8 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
                 const int w = (n2[b] < 0) ? v : n2[b];
                 const bool live2 = ok1[a] && (n2[b] >= 0) && (n2[b] != v) && (sa.status[w] == 0);
                 nn2_live += live2 ? 1 : 0;
-                if (!ignored)
-                    sa.sw_npos2[(size_t)(a * 6 + b) * NP + pos] = live2 ? sa.pos_of[w] : -1;
+                if (!ignored && live2)
+                    sa.sw_npos2[(size_t)(da * 6 + direction(xa, ya, za, w)) * NP + pos] = sa.pos_of[w];
             }
         }
     }
@@ -927,9 +945,21 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         else
             sa.sw_rhs0[k * NP + pos] = theta_rhs(base, st.pprec[k], st.pm[k]);
     }
+    if (sa.sw_npos2) // (by direction, see above)
+    {
 #pragma unroll
-    for (int a = 0; a < 6; a++)
-        sa.sw_npos[a * NP + pos] = live1[a] ? sa.pos_of[n1[a]] : -1;
+        for (int a = 0; a < 6; a++)
+            sa.sw_npos[a * NP + pos] = -1;
+        for (int a = 0; a < 6; a++)
+            if (live1[a])
+                sa.sw_npos[dir1[a] * NP + pos] = sa.pos_of[n1[a]];
+    }
+    else
+    {
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+            sa.sw_npos[a * NP + pos] = live1[a] ? sa.pos_of[n1[a]] : -1;
+    }
     sa.sw_alive[pos] = 1;
     // the posterior's new covariance and the priors are final here (the state's means stay the OLD ones
     // until the noise kernel has seen them: F "before" is evaluated with them)
@@ -1596,25 +1626,36 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
 }
 
 // ---- the ordered part, slab form, second neighbours (types P and p) -------------------------------------------
-// As the slab sweep above, for the stencil of priors.cc:377-385: with level = x + 2y + 3z the listed neighbours of
-// EARLIER levels are up to 6 levels back. A workgroup (512 lanes) owns a slab of z-planes and keeps the means of its
-// last 8 runs in LDS; the slab's runs are its levels one by one, empty ones included, so an earlier neighbour inside
-// the slab sits in one of the six runs before the voxel's. Where a listed neighbour's mean comes from follows from
-// its POSITION alone (the neighbour table lists the neighbours that exist one after the other, not by direction):
-//   position >= the first position of the voxel's run: a later neighbour (same slab or a slab above) - its mean of
-//       the previous sweep, read from sw_x (nobody overwrites it before this voxel is done: it waits for this voxel);
-//   position < the slab's first position: a neighbour below the slab (always an earlier one: a step in z outweighs
-//       the steps in x and y) - its own granule in device-scope memory, polled until it carries this sweep's serial
-//       number (every voxel writes its granule when it is done, as in the data-flow form);
-//   else: LDS, the run among the last six that holds the position.
+// As the slab sweep above, for the stencil of priors.cc:377-385: with level = x + 2y + 3z the 3 + 15 listed neighbours
+// of EARLIER levels are up to 6 levels back. A workgroup (512 lanes) owns a slab of z-planes and keeps the means of
+// its last 8 runs in LDS; the slab's runs are its levels one by one, empty ones included, so the run of a neighbour
+// follows from the slot it has in the list: for the second-neighbour forms the prep kernel writes the tables
+// DIRECTION-indexed (slot a = direction +x -x +y -y +z -z, -1 where there is none - the neighbour table itself lists
+// the neighbours that exist one after the other; the order of the sums is the same), and a direction changes the
+// level by +1 -1 +2 -2 +3 -3: known at compile time. Per slot:
+//   level change > 0 (3 + 15 slots): a later neighbour - its mean of the previous sweep, read from sw_x (nobody
+//       overwrites it before this voxel is done: it waits for this voxel);
+//   level change < 0, position inside the slab: LDS, run li + change, offset position - first position of that run;
+//   level change < 0, position below the slab: the neighbour's own granule in device-scope memory, polled until it
+//       carries this sweep's serial number (every voxel writes its granule when it is done, as in the data-flow form).
 // Sums in list order, the expressions of the other forms (second_order_mean / second_order_pm): the same bits.
+__device__ __forceinline__ constexpr int slab2_dir_level(int a)
+{
+    return a == 0 ? 1 : a == 1 ? -1 : a == 2 ? 2 : a == 3 ? -2 : a == 4 ? 3 : -3;
+}
+// slot e: 0..5 the first neighbours, 6 + a * 6 + b neighbour b of neighbour a
+__device__ __forceinline__ constexpr int slab2_slot_level(int e)
+{
+    return e < 6 ? slab2_dir_level(e) : slab2_dir_level((e - 6) / 6) + slab2_dir_level((e - 6) % 6);
+}
+
 template <int P, int NS>
 struct Slab2Record
 {
     SweepRecord<P, NS> r;
     int np2[36];
-    double val[NS][42];             // the means known before the voxel's turn: later neighbours, neighbours below
-    unsigned long long pending[NS]; // slots below the slab whose granule did not carry this sweep's number yet
+    double later[NS][42]; // (only the slots of later levels are loaded and used)
+    unsigned long long lo[NS][42], hi[NS][42]; // (only the slots of earlier levels below the slab)
     __device__ __forceinline__ int slot_pos(int e) const
     {
         return e < 6 ? r.np[e] : np2[e - 6];
@@ -1628,92 +1669,92 @@ struct Slab2Record
         for (int e = 0; e < 36; e++)
             np2[e] = sa.sw_npos2[(size_t)e * NP + pos];
     }
-    // the second stage, once the positions have arrived (run_begin = first position of the voxel's run)
-    __device__ __forceinline__ void gather(const SpatialArgs &sa, int ns, int slab_begin, int run_begin)
+    // the second stage, once the positions have arrived: the later neighbours' means and a first look at the granules
+    // of the neighbours below the slab
+    __device__ __forceinline__ void gather(const SpatialArgs &sa, int ns, int slab_begin)
     {
         const size_t NP = (size_t)sa.n_pos;
-        const unsigned long long serial = sa.sw_serial;
 #pragma unroll
         for (int s = 0; s < NS; s++)
             if (s < ns)
             {
                 const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
                 const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
-                pending[s] = 0;
 #pragma unroll
                 for (int e = 0; e < 42; e++)
                 {
                     const int np = slot_pos(e);
                     const bool want = r.alive && np >= 0 && (e < 6 || second);
-                    const bool later = want && np >= run_begin, below = want && np < slab_begin;
-                    double x = 0;
-                    if (later)
-                        x = sa.sw_x[(size_t)s * NP + np];
-                    else if (below)
+                    if (slab2_slot_level(e) > 0)
+                        later[s][e] = sa.sw_x[(size_t)s * NP + (want ? np : 0)];
+                    else if (slab2_slot_level(e) < 0)
                     {
-                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + np) * 2;
-                        const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        x = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-                        if (((lo >> 32) != serial) || ((hi >> 32) != serial))
-                            pending[s] |= 1ull << e;
+                        const bool below = want && np < slab_begin;
+                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + (below ? np : 0)) * 2;
+                        lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    val[s][e] = x;
-                }
-            }
-    }
-    // wait until every neighbour below the slab carries this sweep's serial number
-    __device__ __forceinline__ void wait_below(const SpatialArgs &sa, int ns)
-    {
-        const size_t NP = (size_t)sa.n_pos;
-        const unsigned long long serial = sa.sw_serial;
-#pragma unroll
-        for (int s = 0; s < NS; s++)
-            if (s < ns)
-            {
-                int spins = 0;
-                while (__any(pending[s] != 0))
-                {
-                    if (++spins > (1 << 22)) // never (a slab waits for the slabs below only); the run is repeated
-                    {
-                        sa.sw_flags[0] = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                    for (int e = 0; e < 42; e++)
-                        if ((pending[s] >> e) & 1)
-                        {
-                            const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + slot_pos(e)) * 2;
-                            const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (((lo >> 32) == serial) && ((hi >> 32) == serial))
-                            {
-                                val[s][e] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-                                pending[s] &= ~(1ull << e);
-                            }
-                        }
                 }
             }
     }
 };
 
-// one voxel's step: li = its run, tab = the slab's run table ([n_runs] first positions, [n_runs] counts), ring = the LDS
-// means [8][ns][stride]
+// wait until every neighbour below the slab carries this sweep's serial number
+template <int P, int NS>
+__device__ __forceinline__ void slab2_wait_below(const SpatialArgs &sa, Slab2Record<P, NS> &rec, int ns, int slab_begin)
+{
+    const size_t NP = (size_t)sa.n_pos;
+    const unsigned long long serial = sa.sw_serial;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (s < ns)
+        {
+            const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
+            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
+            unsigned long long pending = 0;
+#pragma unroll
+            for (int e = 0; e < 42; e++)
+                if (slab2_slot_level(e) < 0)
+                {
+                    const int np = rec.slot_pos(e);
+                    if (rec.r.alive && np >= 0 && np < slab_begin && (e < 6 || second)
+                        && (((rec.lo[s][e] >> 32) != serial) || ((rec.hi[s][e] >> 32) != serial)))
+                        pending |= 1ull << e;
+                }
+            int spins = 0;
+            while (__any(pending != 0))
+            {
+                if (++spins > (1 << 22)) // never (a slab waits for the slabs below only); the run is repeated
+                {
+                    sa.sw_flags[0] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1))
+                    {
+                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + rec.slot_pos(e)) * 2;
+                        rec.lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rec.hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int e = 0; e < 42; e++)
+                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1) && ((rec.lo[s][e] >> 32) == serial)
+                        && ((rec.hi[s][e] >> 32) == serial))
+                        pending &= ~(1ull << e);
+            }
+        }
+}
+
+// one voxel's step: li = its run, tab = the slab's run table (first positions), ring = the LDS means [8][ns][stride]
 template <int P, int NS>
 __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Record<P, NS> &rec, int pos, int slot, int ns, int li,
-    const int *tab, int n_runs, int slab_begin, double *ring, int stride)
+    const int *tab, int slab_begin, double *ring, int stride)
 {
     const SweepRecord<P, NS> &r = rec.r;
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
-    const int run_begin = tab[li];
-    // the first positions of the six runs before this one (descending; nothing before the slab's first run)
-    int pb[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        pb[k] = li - 1 - k >= 0 ? tab[li - 1 - k] : slab_begin;
-    (void)n_runs;
     double rhs[P], pm_out[NS];
 #pragma unroll
     for (int j = 0; j < P; j++)
@@ -1732,24 +1773,40 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 const int np = rec.slot_pos(e);
                 if (np < 0 || (e >= 6 && !second))
                     continue;
-                double v = rec.val[s][e];
-                if (np >= slab_begin && np < run_begin) // an earlier neighbour inside the slab: one of the last six runs
+                double val;
+                if (slab2_slot_level(e) > 0)
+                    val = rec.later[s][e];
+                else if (slab2_slot_level(e) < 0)
                 {
-                    // (the runs' positions follow one another: the run is the first whose first position is <= np)
-                    int q = 0, base = pb[0];
-#pragma unroll
-                    for (int t = 1; t < 6; t++)
+                    if (np < slab_begin)
+                        val = __longlong_as_double((long long)((rec.hi[s][e] << 32) | (rec.lo[s][e] & 0xffffffffull)));
+                    else
                     {
-                        const bool further = np < pb[t - 1];
-                        q = further ? t : q;
-                        base = further ? pb[t] : base;
+                        const int run = li + slab2_slot_level(e);
+                        val = ring[((size_t)(run & 7) * ns + s) * stride + (np - tab[run])];
                     }
-                    v = ring[((size_t)((li - 1 - q) & 7) * ns + s) * stride + (np - base)];
                 }
-                if (e < 6)
-                    contrib += v;
                 else
-                    contrib2 += -v;
+                    val = 0; // (a neighbour's neighbour that is the voxel itself: never listed)
+#ifdef FVB_SLAB2_DEBUG
+                {
+                    const unsigned long long *gq = sa.sw_gran + ((size_t)s * NP + np) * 2;
+                    const unsigned long long l0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long h0 = __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double vg = __longlong_as_double((long long)((h0 << 32) | (l0 & 0xffffffffull)));
+                    if ((sa.sl_debug & 16) && slab2_slot_level(e) > 0)
+                        val = vg;
+                    if ((sa.sl_debug & 32) && slab2_slot_level(e) < 0 && np >= slab_begin)
+                        val = vg;
+                    if ((sa.sl_debug & 64) && vg != val && ((h0 >> 32) == serial || slab2_slot_level(e) > 0))
+                        printf("slab2 pos %d slot %d level %d np %d: %.17g, granule %.17g (li %d tab %d)\n", pos, e, slab2_slot_level(e), np, val, vg, li,
+                            slab2_slot_level(e) < 0 ? tab[li + slab2_slot_level(e)] : -1);
+                }
+#endif
+                if (e < 6)
+                    contrib += val;
+                else
+                    contrib2 += -val;
             }
             double pm;
             if (second)
@@ -1763,14 +1820,11 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 pm = r.q[s] * spatial_mean;
             }
             pm_out[s] = pm;
-            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe (tools/measure/slab2_probe.py)
-            {
-                sa.sw_nbr[0 * NP + pos] = contrib;
-                sa.sw_nbr[1 * NP + pos] = contrib2;
-                sa.sw_nbr[2 * NP + pos] = pm;
-                sa.sw_nbr[4 * NP + pos] = r.q[s];
-                sa.sw_nbr[5 * NP + pos] = r.pprec[s];
-            }
+#ifdef FVB_SLAB2_DEBUG
+            if (sa.sw_serial == 1 && pos < 3)
+                printf("slab2 pos %d: contrib %.17g contrib2 %.17g rec %.17g q %.17g pprec %.17g pm %.17g rhs0 %.17g np %d %d %d %d %d %d\n", pos, contrib, contrib2,
+                    r.rec[s], r.q[s], r.pprec[s], pm, r.rhs0[k], r.np[0], r.np[1], r.np[2], r.np[3], r.np[4], r.np[5]);
+#endif
 #pragma unroll
             for (int j = 0; j < P; j++)
                 if (j == k)
@@ -1785,8 +1839,6 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
             for (int j = 0; j < P; j++)
                 m = __builtin_fma(r.sig[s][j], rhs[j], m);
             ring[((size_t)(li & 7) * ns + s) * stride + slot] = m;
-            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1)
-                sa.sw_nbr[3 * NP + pos] = m;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
             unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
             __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1826,23 +1878,24 @@ __global__ __launch_bounds__(512) void vb_spatial_slab2_sweep_kernel(const Spati
     {
         const int begin = tab[li], count = tab[n_runs + li];
         // second stage of this run's record (its positions were requested G runs ago), then the neighbours below
-        rec.gather(sa, ns, slab_begin, begin);
-        rec.wait_below(sa, ns);
+        rec.gather(sa, ns, slab_begin);
+        if (lane < count)
+            slab2_wait_below<P, NS>(sa, rec, ns, slab_begin);
         // runs 0 .. li - 1 complete? (the ring slot this run overwrites held run li - 8: read by runs up to li - 1)
         const int need = li * waves_per_group;
         while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
             __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (lane < count && rec.r.alive)
-            slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, n_runs, slab_begin, s_mem, stride);
+            slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, slab_begin, s_mem, stride);
         for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide)
         {
             Slab2Record<P, NS> one;
             one.load(sa, begin + i, ns);
-            one.gather(sa, ns, slab_begin, begin);
-            one.wait_below(sa, ns);
+            one.gather(sa, ns, slab_begin);
+            slab2_wait_below<P, NS>(sa, one, ns, slab_begin);
             if (one.r.alive)
-                slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, n_runs, slab_begin, s_mem, stride);
+                slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, slab_begin, s_mem, stride);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((threadIdx.x & 63) == 0)

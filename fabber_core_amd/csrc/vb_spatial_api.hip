@@ -445,6 +445,7 @@ struct fvb_spatial_run
     int device_share = 1;    // how many such slabs run on THIS device at once (a device listed several times)
     bool fast_second = false; // the split sweep with second neighbours (types P, p): vb_spatial_sweep2_kernel
     bool slab2 = false;       // ... in its slab form: vb_spatial_slab2_sweep_kernel
+    DevMem d_xyz;             // (the co-ordinates on the device for the prep kernel of those forms)
     DevMem d_up_pos;
     std::vector<int32_t> h_pos_of; // (multi_fast: the numbering, for the slab below to address this slab's inboxes)
     int fast_prep(int it);
@@ -717,9 +718,8 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     // volumes on one device; its runs are numbered on the host and include the EMPTY levels of a slab, so that a
     // neighbour's run follows from its level)
     // Not what runs by default (FVB_SPATIAL_SLAB2=1): correct - the bit-for-bit test covers it - but at 128^3 it takes
-    // 25 ms per iteration against the data-flow form's 12.8: its 42 slots per voxel have to be told apart
-    // by position at run time (the neighbour table lists the neighbours that exist, not directions), which costs the
-    // 512-lane workgroups their registers.
+    // 34 ms per iteration against the data-flow form's 13: with one plane per slab every level of a slab
+    // waits for the slab below through device-scope memory, and the step itself carries 42 slots per voxel.
     const bool eligible_slab2 = allow_fast && has_spatial && second_neighbours && whole && !multi_fast && n_owned > 0
         && !getenv("FVB_SPATIAL_PER_LEVEL") && getenv("FVB_SPATIAL_SLAB2") != nullptr;
     if ((eligible || eligible_slab2) && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll"))
@@ -1035,6 +1035,20 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sw_npos = (int32_t *)d_sw_i32.p;
         sa.sw_alive = (int32_t *)d_sw_i32.p + 6 * NP;
         sa.sw_npos2 = fast_second ? (int32_t *)d_sw_i32.p + 7 * NP : nullptr;
+        if (fast_second)
+        {
+            if (d_coords.p) // (left by the neighbour table's kernels)
+            {
+                std::swap(d_xyz.p, d_coords.p);
+                std::swap(d_xyz.stream, d_coords.stream);
+            }
+            else
+            {
+                FVB_HIP_CHECK(d_xyz.alloc(sizeof(int32_t) * 3 * (size_t)V, stream));
+                FVB_HIP_CHECK(hipMemcpyAsync(d_xyz.p, sp.coords, sizeof(int32_t) * 3 * (size_t)V, hipMemcpyHostToDevice, stream));
+            }
+            sa.xyz = (const int32_t *)d_xyz.p;
+        }
         sa.sw_counter = (uint32_t *)d_sw_sync.p;
         sa.sw_flags = (int32_t *)d_sw_sync.p + 4;
         sa.pos_of = (const int32_t *)d_pos_of.p;

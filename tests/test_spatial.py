@@ -512,10 +512,11 @@ def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, m
         h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 20, num_exps=1, dt=0.04, max_iterations=3, param_overrides={"amp1": dict(type="P")})
     sp = vbabi.SpatialHolder(coords, **sp_kw)
     # the forms of the ordered part: the data-flow form (what runs) and the slab form with the last levels' means in LDS
-    # (FVB_SPATIAL_SLAB2=1: correct, slower at volume size) with slabs of 1 / 2 / 3 planes
+    # (FVB_SPATIAL_SLAB2=1: correct, slower at volume size) with slabs of 1 / 2 / 3 planes and one slab
     forms = {}
-    for name, env in (("default", {}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"}),
-                      ("slab form", {"FVB_SPATIAL_SLAB2": "1"}), ("slab form, 2 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "2"}),
+    for name, env in (("default", {}), ("data-flow (poll)", {"FVB_SPATIAL_SWEEP": "poll"}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"}),
+                      ("slab form", {"FVB_SPATIAL_SLAB2": "1"}), ("slab form, geometry on the host", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_HOST_GEOMETRY": "1"}),
+                      ("slab form, 2 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "2"}),
                       ("slab form, 3 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "3"}),
                       ("slab form, one slab", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "100"})):
         for k, v in env.items():

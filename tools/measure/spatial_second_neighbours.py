@@ -1,5 +1,5 @@
-"""Types P / p (second-neighbour priors) at C5's size: the split first sweep (one data-flow launch,
-vb_spatial_sweep2_kernel) against the per-level launches it replaces - the same problem, results compared.
+"""Types P / p (second-neighbour priors) at C5's size: the split first sweep (one launch: the data-flow form
+vb_spatial_sweep2_kernel, or with FVB_SPATIAL_SLAB2=1 its slab form vb_spatial_slab2_sweep_kernel) against the per-level launches it replaces - the same problem, results compared.
 
     python tools/measure/spatial_second_neighbours.py [n=128] [iterations=10] [type=P]
 """
@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 its = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 typ = sys.argv[3] if len(sys.argv) > 3 else "P"
 res = {}
-for label, env in (("one data-flow launch per iteration", {}), ("one launch per level", {"FVB_SPATIAL_PER_LEVEL": "1"})):
+for label, env in (("one data-flow launch per iteration", {}), ("one slab-sweep launch per iteration", {"FVB_SPATIAL_SLAB2": "1"}), ("one launch per level", {"FVB_SPATIAL_PER_LEVEL": "1"})):
     os.environ.update(env)
     t = {}
     for k in (2, its):  # (two runs of different length: the difference is the iterations alone)
@@ -28,5 +28,7 @@ for label, env in (("one data-flow launch per iteration", {}), ("one launch per 
     print("%s: %.1f ms per run of %d iterations, %.2f ms per iteration" % (label, t[its], its, (t[its] - t[2]) / (its - 2)), flush=True)
     for k in env:
         del os.environ[k]
-a, b = res.values()
-print("identical" if all(np.array_equal(a[k], b[k], equal_nan=True) for k in ("mvn", "status")) else "DIFFERENT")
+ref = res["one launch per level"]
+for label, r in res.items():
+    if r is not ref:
+        print(label + ":", "identical to the per-level sweep" if all(np.array_equal(r[k], ref[k], equal_nan=True) for k in ("mvn", "status")) else "DIFFERENT")
