@@ -1788,21 +1788,6 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 }
                 else
                     val = 0; // (a neighbour's neighbour that is the voxel itself: never listed)
-#ifdef FVB_SLAB2_DEBUG
-                {
-                    const unsigned long long *gq = sa.sw_gran + ((size_t)s * NP + np) * 2;
-                    const unsigned long long l0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long h0 = __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double vg = __longlong_as_double((long long)((h0 << 32) | (l0 & 0xffffffffull)));
-                    if ((sa.sl_debug & 16) && slab2_slot_level(e) > 0)
-                        val = vg;
-                    if ((sa.sl_debug & 32) && slab2_slot_level(e) < 0 && np >= slab_begin)
-                        val = vg;
-                    if ((sa.sl_debug & 64) && vg != val && ((h0 >> 32) == serial || slab2_slot_level(e) > 0))
-                        printf("slab2 pos %d slot %d level %d np %d: %.17g, granule %.17g (li %d tab %d)\n", pos, e, slab2_slot_level(e), np, val, vg, li,
-                            slab2_slot_level(e) < 0 ? tab[li + slab2_slot_level(e)] : -1);
-                }
-#endif
                 if (e < 6)
                     contrib += val;
                 else
@@ -1820,11 +1805,6 @@ __device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Rec
                 pm = r.q[s] * spatial_mean;
             }
             pm_out[s] = pm;
-#ifdef FVB_SLAB2_DEBUG
-            if (sa.sw_serial == 1 && pos < 3)
-                printf("slab2 pos %d: contrib %.17g contrib2 %.17g rec %.17g q %.17g pprec %.17g pm %.17g rhs0 %.17g np %d %d %d %d %d %d\n", pos, contrib, contrib2,
-                    r.rec[s], r.q[s], r.pprec[s], pm, r.rhs0[k], r.np[0], r.np[1], r.np[2], r.np[3], r.np[4], r.np[5]);
-#endif
 #pragma unroll
             for (int j = 0; j < P; j++)
                 if (j == k)
