@@ -1661,6 +1661,50 @@ int32_t oracle_calc_neighbours(const int32_t *coords, int32_t n_voxels, int32_t 
     return 0;
 }
 
+int32_t oracle_spatial_prior_apply(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t type, double mean0,
+    double prec0, double aK, const double *means, double *prior_mean, double *prior_prec)
+{
+#ifdef ORACLE_QUAD
+    return -1;
+#else
+    SpatialCtx ctx;
+    try
+    {
+        calc_neighbours(coords, n_voxels, spatial_dims, ctx);
+        ctx.nvoxels = n_voxels;
+        ctx.it = 0;
+        ctx.fwd_post.assign(n_voxels, Mvn(1));
+        ctx.fwd_prior.assign(n_voxels, Mvn(1));
+        for (int v = 0; v < n_voxels; v++)
+            ctx.fwd_post[v].means[0] = means[v];
+        SpatialPriorK s;
+        s.idx = 0;
+        s.type = type;
+        s.mean0 = mean0;
+        s.prec0 = prec0;
+        s.aK = aK;
+        s.dims = spatial_dims;
+        s.speed = -1;
+        s.q1 = 10;
+        s.q2 = 1;
+        s.update_first_iter = false; // (aK stays what the caller gave)
+        for (int v = 1; v <= n_voxels; v++)
+        {
+            ctx.v = v;
+            s.ApplyToMVN(&ctx.fwd_prior[v - 1], ctx);
+            prior_mean[v - 1] = (double)ctx.fwd_prior[v - 1].means[0];
+            prior_prec[v - 1] = (double)ctx.fwd_prior[v - 1].GetPrecisions()(0, 0);
+        }
+    }
+    catch (std::exception &e)
+    {
+        g_oracle_error = e.what();
+        return -10;
+    }
+    return 0;
+#endif
+}
+
 double oracle_gammaln(double x)
 {
     return gammaln(x);

@@ -60,6 +60,12 @@ int32_t oracle_nlls_run(const fvb_config *cfg, const fvb_nlls *nl, const void *d
 int32_t oracle_calc_neighbours(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t *nn,
     int32_t *nn2, int32_t *n2count);
 
+/* SpatialPrior::ApplyToMVN (priors.cc:346-488) for ONE parameter on a grid, for unit tests: with the posterior means
+ * `means` [n_voxels] of that parameter and the smoothing precision aK, the prior mean and prior precision every voxel
+ * gets (in voxel order; nothing is updated in between). type = FVB_PRIOR_SPATIAL_*. */
+int32_t oracle_spatial_prior_apply(const int32_t *coords, int32_t n_voxels, int32_t spatial_dims, int32_t type, double mean0,
+    double prec0, double aK, const double *means, double *prior_mean, double *prior_prec);
+
 /* Scalar helpers exposed for unit tests. */
 double oracle_gammaln(double x);   /* tools.cc:87-98 */
 double oracle_digamma(double x);   /* MISCMATHS::digamma restated in fp64 */

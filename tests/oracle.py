@@ -264,3 +264,23 @@ def calc_neighbours(coords, spatial_dims=3):
     if rc != 0:
         raise RuntimeError(L.oracle_last_error().decode())
     return nn, nn2, n2c
+
+
+def spatial_prior_apply(coords, typ, means, mean0, prec0, aK, spatial_dims=3):
+    """SpatialPrior::ApplyToMVN (priors.cc:346-488) for one parameter on a grid: (prior mean [V], prior precision [V])
+    every voxel gets from the posterior means `means` and the smoothing precision aK. typ: "M", "m", "P", "p"."""
+    coords = np.ascontiguousarray(coords, dtype=np.int32)
+    V = coords.shape[1]
+    means = np.ascontiguousarray(means, dtype=np.float64)
+    assert means.shape == (V,)
+    pm, pp = np.zeros(V), np.zeros(V)
+    L = lib()
+    L.oracle_spatial_prior_apply.restype = C.c_int32
+    L.oracle_spatial_prior_apply.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_last_error.restype = C.c_char_p
+    rc = L.oracle_spatial_prior_apply(coords.ctypes.data, V, spatial_dims, vbabi.PRIOR_CODES[typ], mean0, prec0, aK,
+                                      means.ctypes.data, pm.ctypes.data, pp.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(L.oracle_last_error().decode())
+    return pm, pp

@@ -189,7 +189,66 @@ def test_oracle_spatial_loop_reproduces_reference_spatialvb_output():
     assert np.max(np.abs(gc - cov) / (sd[:, :, None] * sd[:, None, :])) < 1e-5
 
 
-@pytest.mark.parametrize("typ", ["M", "m", "P", "p"])
+@pytest.mark.parametrize("dims", [3, 2, 1])
+@pytest.mark.parametrize("typ", ["P", "p"])
+def test_second_neighbour_prior_types_as_the_reference_codes_them(typ, dims):
+    """priors.cc:455 `double rec = 1 / (8*nn - nn2);` divides two ints: 0 for every reachable neighbourhood (nn2 <= 5 nn).
+    As coded spatial_mean is 0, so the prior mean of types P and p never reads a neighbour's value:
+      P: mu0 = prec0 mean0 / (prec0 + aK (nn^2 + nn)),  p: mu0 = prec0 mean0 / (aK (4 d^2 + 2 d))  (42 aK for d = 3)
+    while types M and m do smooth (mean of the neighbours). The precisions are what the formula says either way."""
+    mask, coords = masked_volume((6, 5, 4), seed=2)
+    V = coords.shape[1]
+    rng = np.random.default_rng(3)
+    means = rng.normal(2.0, 1.0, V)
+    mean0, prec0, aK = 0.7, 1e-3, 0.37
+    nn_ids, nn2_ids, n2c = oracle.calc_neighbours(coords, dims)
+    nn = (nn_ids > 0).sum(axis=1)
+    assert np.all(8 * nn[nn > 0] - n2c[nn > 0] >= 3)  # the divisor of :455: its integer reciprocal is 0
+    pm, pp = oracle.spatial_prior_apply(coords, typ, means, mean0, prec0, aK, spatial_dims=dims)
+    if typ == "P":
+        want_prec = prec0 + aK * (nn * nn + nn)
+        want_mean = prec0 * mean0 / want_prec
+    else:
+        want_prec = np.full(V, aK * (4 * dims * dims + 2 * dims))
+        want_mean = prec0 * mean0 / want_prec
+    assert np.allclose(pp, want_prec, rtol=1e-14, atol=0)
+    assert np.allclose(pm, want_mean, rtol=1e-13, atol=0)
+    # not a function of the neighbours' values ...
+    pm2, _ = oracle.spatial_prior_apply(coords, typ, rng.normal(-5.0, 3.0, V), mean0, prec0, aK, spatial_dims=dims)
+    assert np.array_equal(pm, pm2)
+    # ... only of whether they are finite: 0 x inf = NaN reaches the first and second neighbours of a bad voxel
+    bad = V // 2
+    poisoned = means.copy()
+    poisoned[bad] = np.inf
+    pm3, _ = oracle.spatial_prior_apply(coords, typ, poisoned, mean0, prec0, aK, spatial_dims=dims)
+    reach = set((nn_ids[bad][nn_ids[bad] > 0] - 1).tolist()) | set((nn2_ids[bad][:n2c[bad]] - 1).tolist())
+    assert set(np.flatnonzero(np.isnan(pm3)).tolist()) == reach
+    # types M / m next to them: the mean of the neighbours
+    pmM, ppM = oracle.spatial_prior_apply(coords, "M", means, mean0, prec0, aK, spatial_dims=dims)
+    for v in range(V):
+        ids = nn_ids[v][nn_ids[v] > 0] - 1
+        if len(ids):
+            sp = aK * (len(ids) + 1e-8)
+            assert np.isclose(pmM[v], sp / (prec0 + sp) * means[ids].mean(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("typ", ["P", "p"])
+def test_oracle_second_neighbour_types_do_not_smooth(typ):
+    """The run-level consequence of the integer division: a P / p prior pulls towards prec0 mean0 / precision, i.e. it
+    only shrinks. With types M / m the fitted map is closer to the smooth truth than the voxelwise fit; with P / p it is
+    the voxelwise fit shrunk (never closer to the truth than M)."""
+    mask, coords = masked_volume((8, 7, 6), seed=0)
+    V = coords.shape[1]
+    amp, y = smooth_exp_data(coords, 50, 0.04, seed=1)
+    run = lambda t: oracle.run_spatial(vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=10,
+                                                         param_overrides={"amp1": dict(type=t)}), vbabi.SpatialHolder(coords), y)
+    r, rM = run(typ), run("M")
+    rmse = lambda res: np.sqrt(np.mean((np.exp(res["mvn"][6]) - amp) ** 2))
+    assert np.isfinite(r["mvn"]).all()
+    assert rmse(rM) < rmse(r)
+
+
+@pytest.mark.parametrize("typ", ["M", "m"])
 def test_oracle_spatial_prior_smooths(typ):
     mask, coords = masked_volume((8, 7, 6), seed=0)
     V = coords.shape[1]
