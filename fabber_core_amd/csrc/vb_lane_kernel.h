@@ -972,12 +972,6 @@ __device__ __forceinline__ void residual_and_trace(const KernelArgs &ka, const M
         }
         return;
     }
-#ifdef FVB_DEBUG_LOST
-    if (want)
-        atomicAdd((unsigned int *)ka.out.iterations + v, 1u << 8);
-    if (__any(want))
-        atomicAdd((unsigned int *)ka.out.iterations + v, 1u << 20);
-#endif
     if (__any(want)) // wave-uniform: the pass is taken by the whole wavefront or not at all
     {
         park_state<P, NEEDF>(park, st);
@@ -1657,12 +1651,8 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
         ka.out.free_energy[v] = F;
     if (ka.out.status)
         ka.out.status[v] = status | (setup_failed ? 0x100 : 0);
-#ifdef FVB_DEBUG_LOST
-    atomicAdd((unsigned int *)ka.out.iterations + v, (unsigned int)it);
-#else
     if (ka.out.iterations)
         ka.out.iterations[v] = it;
-#endif
 }
 
 #endif // __HIPCC__

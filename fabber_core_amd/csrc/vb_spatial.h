@@ -5,11 +5,11 @@
  * v's spatial prior (SpatialPrior::ApplyToMVN, priors.cc:346-488) reads its neighbours' CURRENT
  * posterior means - already updated for u < v, previous iteration for u > v (Gauss-Seidel) -
  * and then UpdateTheta changes v's own mean. That order is kept EXACTLY: with
- * level(v) = x + 2y + 4z every first or second neighbour of v with a smaller index has a
- * strictly smaller level and every one with a larger index a strictly larger level (all twelve
- * stencil offsets have non-zero level difference of the right sign), so voxels of one level are
- * independent and the levels are processed in ascending order, one launch each
- * (vb_spatial_theta_kernel). The second sweep (UpdateNoise, ReCentre, F) has no coupling and is
+ * level(v) = x + y + z (first neighbours) or x + 2y + 3z (second neighbours too) every listed
+ * neighbour of v with a smaller index has a strictly smaller level and every one with a larger
+ * index a strictly larger level, so voxels of one level are independent and the levels are
+ * processed in ascending order - one launch each (vb_spatial_theta_kernel, the exact form that
+ * takes everything), or the split form further down. The second sweep (UpdateNoise, ReCentre, F) has no coupling and is
  * one lane-per-voxel launch over all voxels (vb_spatial_noise_kernel) sharing its device
  * functions with the voxelwise kernel. The global smoothing precisions aK (CalculateaK,
  * priors.cc:221-344) are two deterministic tree reductions per spatial parameter per iteration.
@@ -67,44 +67,39 @@ struct SpatialArgs
     // host-evaluated models (HostLinModel): [V][n_times * (P + 1)] linearisations, g then J per voxel - about the
     // centre the moments in the state belong to (lin_cur) and about the means the second sweep re-centres on (lin_next)
     const double *lin_cur, *lin_next;
-    // ---- the split first sweep (SweepPlan below); NULL / 0 when the per-level launches are used ----
-    const int32_t *pos_of;   // [V] position of a voxel in the level-major numbering
-    int32_t n_pos;           // positions, every level padded to a multiple of 16
-    int32_t n_spatial;       // spatial parameters ...
+    // ---- the split first sweep (below); NULL / 0 when the per-level launches are used. Only the parameters with a
+    // first-neighbour prior (types M, m) take part in it: types P and p read no neighbour's value as the reference
+    // codes them (priors.cc:455), their prior mean is complete in the prep kernel ----
+    const int32_t *pos_of;   // [V] position of a voxel in the slab-major numbering
+    int32_t n_pos;           // positions (padded to a multiple of 16)
+    int32_t n_spatial;       // parameters of types M, m ...
     int32_t spatial_param[FVB_MAX_PARAMS]; // ... and which they are
-    double *sw_x;            // [n_spatial][n_pos] means of the spatial parameters, swept in place
+    double *sw_x;            // [n_spatial][n_pos] means of those parameters, swept in place
     double *sw_pm;           // [n_spatial][n_pos] their prior means as the sweep left them
     double *sw_rhs0;         // [P][n_pos] eq (20) right-hand side: complete where it needs no neighbour, else its base
     double *sw_pprec;        // [n_spatial][n_pos] prior precision of the spatial parameter
     double *sw_q;            // [n_spatial][n_pos] (1 / prior precision) x spatial precision
-    double *sw_rec;          // [n_spatial][n_pos] 1 / number of live neighbours (types M, m)
+    double *sw_rec;          // [n_spatial][n_pos] 1 / number of live neighbours
     double *sw_sig;          // [n_spatial][P][n_pos] the spatial parameters' rows of Sigma
     int32_t *sw_npos;        // [6][n_pos] positions of the live first neighbours, -1 = none
     int32_t *sw_alive;       // [n_pos] 1 = the voxel takes part in the sweep
-    const int32_t *xyz;      // types P, p in a split form: [3][V] the voxels' co-ordinates (the tables below are written by direction)
-    int32_t *sw_npos2;       // types P, p: [36][n_pos] positions of the live second neighbours in list order - slot
-                             // a * 6 + b = neighbour b of neighbour a (priors.cc:377-385) -, -1 = none; else NULL
-    const int32_t *sw_level_pos;   // [n_levels] first position of a level
-    const int32_t *sw_level_count; // [n_levels] voxels in it
-    int32_t n_levels;
-    unsigned long long *sw_gran; // [n_spatial][n_pos][2] the means again as two self-validating 8-byte granules
-                                 // {low / high half of the double, serial number of the sweep that wrote it}
+    // positions are slab-major, a slab = sl_dz z-planes, inside a slab level-major (level = x + y + z): the voxels of
+    // one (slab, level) are a contiguous RUN; sl_first_run[s] .. sl_first_run[s + 1] are slab s's runs
+    const int32_t *sw_level_pos;   // [n_runs] first position of a run
+    const int32_t *sw_level_count; // [n_runs] voxels in it
+    int32_t n_levels;              // n_runs
+    unsigned long long *sw_gran; // [n_spatial][n_pos][2] the INBOX of a voxel: the mean of its z-1 neighbour when that lives
+                                 // in the slab below, as two self-validating 8-byte granules {low / high half of the
+                                 // double, serial number of the sweep that wrote it}
     uint32_t sw_serial;      // this sweep's serial number (1, 2, ...; the buffer starts zeroed)
-    // ---- slab form of the split sweep (vb_spatial_slab_sweep_kernel): positions are slab-major, a slab = sl_dz
-    // z-planes, inside a slab level-major; sw_level_pos / sw_level_count then describe the RUNS (one slab's
-    // voxels of one level), sl_first_run[s] .. sl_first_run[s + 1] are slab s's, and a granule is the INBOX of its
-    // voxel: the mean of the z-1 neighbour when that lives in the slab below ----
-    int32_t sl_mode;         // 1 = slab form; 2 = slab form with second neighbours (granules are the voxels' own, as in the data-flow sweep)
     int32_t n_slabs;
     const int32_t *sl_first_run; // [n_slabs + 1]
     int32_t sl_width;        // lanes that work on one run (a multiple of 64 that divides 1024)
     int32_t sl_max_run;      // longest run (the LDS buffers hold two of them per spatial parameter)
-    int32_t sl_debug;        // timing experiments (wrong results): 1 = never wait for an inbox, 2 = never fetch another record,
-                             // 4 = no step, 8 = no stores
     double *sw_nbr;          // [n_spatial][6][n_pos] the neighbours' means BEFORE the sweep (what a later neighbour contributes)
-    uint32_t *sw_counter;    // (unused by the data-flow sweep; kept for the barrier variant)
-    int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the
-                             // sweep, a barrier timed out): the run is repeated with the per-level launches
+    int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the sweep, a
+                             // non-finite mean next to a type P / p prior, an inbox that never arrived): the run is
+                             // repeated with the per-level launches
     // ---- the slab sweep across DEVICES (fabber_vb_run_spatial_host_multi): a device owns a range of z-planes of the
     // volume and holds ghost copies of the planes next to it; in sw_npos a neighbour that is a ghost BELOW the owned
     // range reads FVB_NP_BELOW (its mean of this sweep arrives in the voxel's inbox, written by the device below), one
@@ -201,10 +196,19 @@ __device__ __forceinline__ void sp_store_noise(const SpatialArgs &sa, int v, con
     p[(size_t)L::S * V] = mo.s;
 }
 
-// SpatialPrior::ApplyToMVN with second neighbours (types P, p; priors.cc:441-482), the two expressions every form
-// of the first sweep shares (written with explicit fused operations so that they round the same everywhere):
-//   mean of the MRF = (8 sum(first neighbours) - sum(second neighbours)) / (8 nn - nn2)
-//   prior mean      = (1 / prior precision) (spatial precision x that mean + prec0 mean0)
+// SpatialPrior::ApplyToMVN with second neighbours (types P, p; priors.cc:441-482) AS CODED:
+//   spatial_mean = (8 sum(first neighbours) - sum(second neighbours)) * rec,   rec = 1 / (8 nn - nn2) in `int`
+//   prior mean   = (1 / prior precision) (spatial precision x spatial_mean + prec0 mean0)
+// :455 divides two ints; nn2 <= 5 nn, so the divisor is >= 3 and rec is 0 for every reachable neighbourhood:
+// spatial_mean is +-0 - or NaN where a listed neighbour's mean is not finite - and the prior mean reads no
+// neighbour's VALUE. The per-level kernel evaluates the expression as it stands (second_order_rec), NaN included;
+// the split form takes the prior mean as pcov x (prec0 mean0) and leaves every run in which a mean next to such a
+// prior is not finite to the per-level kernel (sw_flags).
+__device__ __forceinline__ double second_order_rec(int nn, int nn2)
+{
+    const int d = 8 * nn - nn2;
+    return (d == 0) ? 0.0 : (double)(1 / d); // (d == 0 cannot happen: the reference would divide by zero there)
+}
 __device__ __forceinline__ double second_order_mean(double contrib_nn, double contrib_nn2, double rec)
 {
     return __builtin_fma(8.0, contrib_nn, contrib_nn2) * rec;
@@ -217,6 +221,11 @@ __device__ __forceinline__ double second_order_pm(double pcov, double spatial_pr
 __device__ __forceinline__ bool is_spatial_type(int t)
 {
     return t >= FVB_PRIOR_SPATIAL_M;
+}
+// ... and the ones whose prior mean waits for the neighbours' current means (the ordered sweep of the split form)
+__device__ __forceinline__ bool is_swept_type(int t)
+{
+    return t == FVB_PRIOR_SPATIAL_M || t == FVB_PRIOR_SPATIAL_m;
 }
 
 // The re-centre that ends iteration sa.it is the run's linearisation number sa.it + 1 (the set-up's is number 0). Like
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             }
             else if (nn != 0)
             {
-                const double rec = 1 / double(8 * nn - nn2);
+                const double rec = second_order_rec(nn, nn2); // (integer division, priors.cc:455)
                 spatial_mean = second_order_mean(contrib_nn, contrib_nn2, rec);
             }
             else
@@ -671,72 +680,57 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
 }
 
 // =====================================================================================================
-// The first sweep, split (spatial prior types M and m). Per level the per-level launches above pay one
-// kernel boundary and one voxel's whole dependent chain - state, neighbour ids, neighbour means, the
-// P x P inversion, the stores - 382 times per iteration at 128^3 (5.2 of 6.2 ms). But of all that only
-// ONE number per spatial parameter really waits for the neighbours: the prior mean
+// The first sweep, split. Per level the per-level launches above pay one kernel boundary and one voxel's whole
+// dependent chain - state, neighbour ids, neighbour means, the P x P inversion, the stores - 382 times per
+// iteration at 128^3 (5.2 of 6.2 ms). But of all that only ONE number per parameter with a first-neighbour
+// prior (types M, m) really waits for the neighbours: the prior mean
 //        mu0_k = (1 / prec0_k) s_k mean(neighbours' current means of parameter k)       (priors.cc:441-482)
 // The prior PRECISION s_k = a_K (nn + 1e-8) depends on the neighbour COUNT only, so Lambda (eq 19), its
 // inverse Sigma and every entry of eq (20)'s right-hand side except mu0_k's are known for all voxels at
 // once. The sweep that has to respect the reference's voxel order shrinks to
 //        m_k(v) = sum_j Sigma_kj rhs_j,   rhs_k = fma(prec0_k, mu0_k, base_k)
-// a dozen multiply-adds per voxel on records laid out in the order of the sweep. Three steps per iteration:
-//   vb_spatial_prep_kernel   all voxels in parallel: priors, Lambda, Sigma, right-hand sides -> sweep records
-//   the ordered part         ONE launch that updates the spatial parameters' means in place:
-//     vb_spatial_slab_sweep_kernel  (what runs) a workgroup per z-slab, the previous level's means in LDS, an
-//                            inbox hand-over between slabs - further down
-//     vb_spatial_sweep_kernel       (FVB_SPATIAL_SWEEP=poll) every lane walks the levels and polls exactly the
-//                            neighbours it needs through device-scope granules, no barrier
-//   vb_spatial_noise_kernel  (FAST) first completes the other means from the sweep's result - the same
-//                            theta_rhs / theta_mean sequence update_theta runs, so the posterior is the
-//                            per-level kernels' bit for bit - then carries on with the second sweep
-// A voxel that FAILS during the first sweep (singular Lambda, non-finite F) changes its later neighbours'
-// lists in the reference (Vb::IgnoreVoxel); the split sweep does not model that: it raises sw_flags[0] and
-// the driver repeats the whole run with the per-level launches (tests/test_spatial.py forces both).
+// a dozen multiply-adds per voxel on records laid out in the order of the sweep. Types P and p, as the reference
+// codes them (second_order_rec above), wait for nothing: their prior mean is pcov x prec0 mean0, complete in the
+// prep kernel like an ordinary prior's. Three steps per iteration:
+//   vb_spatial_prep_kernel        all voxels in parallel: priors, Lambda, Sigma, right-hand sides -> sweep records
+//   vb_spatial_slab_sweep_kernel  the ordered part, ONE launch (none without a type M / m prior): a workgroup per
+//                                 z-slab, the previous level's means in LDS, an inbox hand-over between slabs
+//   vb_spatial_noise_kernel       (FAST) first completes the other means from the sweep's result - the same
+//                                 theta_rhs / theta_mean sequence update_theta runs, so the posterior is the
+//                                 per-level kernels' bit for bit - then carries on with the second sweep
+// What the split form does not model raises sw_flags[0], and the driver repeats the whole run with the per-level
+// launches (tests/test_spatial.py forces each): a voxel that FAILS during the first sweep (singular Lambda,
+// non-finite F) changes its later neighbours' lists in the reference (Vb::IgnoreVoxel); a mean that is not
+// finite next to a type P / p prior turns the prior means of its first and second neighbours into NaN
+// (0 x inf) in the reference's voxel order.
 // =====================================================================================================
-__device__ __forceinline__ double load_sc1(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void store_sc1(double *p, double x)
-{
-    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
-// A voxel that drops out in prep (the run is going to be repeated): hand its old means to the sweep with THIS
-// sweep's serial number, so that no neighbour waits for it.
-__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, uint32_t serial, int v = -1)
+// A voxel that drops out in prep (the run is going to be repeated): give every later neighbour's inbox this
+// voxel's old mean with THIS sweep's serial number, so that no neighbour waits for it.
+__device__ __forceinline__ void sweep_release(const SpatialArgs &sa, int pos, uint32_t serial, int v)
 {
     const size_t NP = (size_t)sa.n_pos;
-    if (sa.sl_mode == 1)
+    const size_t V = (size_t)sa.ka.cfg.n_voxels;
+    for (int a = 0; a < 6; a++)
     {
-        // slab form: the granules are inboxes - give every later neighbour's inbox this voxel's old mean
-        if (v < 0)
-            return;
-        const size_t V = (size_t)sa.ka.cfg.n_voxels;
-        for (int a = 0; a < 6; a++)
+        const int u = sa.nn[(size_t)v * 6 + a];
+        if (u < 0 || sa.pos_of[u] < pos)
+            continue;
+        for (int s = 0; s < sa.n_spatial; s++)
         {
-            const int u = sa.nn[(size_t)v * 6 + a];
-            if (u < 0 || sa.pos_of[u] < pos)
-                continue;
-            for (int s = 0; s < sa.n_spatial; s++)
-            {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(sa.state[(size_t)sa.spatial_param[s] * V + v]);
-                unsigned long long *g = sa.sw_gran + ((size_t)s * NP + sa.pos_of[u]) * 2;
-                const unsigned long long now = (unsigned long long)serial << 32;
-                __hip_atomic_store(g, now | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 1, now | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sa.state[(size_t)sa.spatial_param[s] * V + v]);
+            unsigned long long *g = sa.sw_gran + ((size_t)s * NP + sa.pos_of[u]) * 2;
+            const unsigned long long now = (unsigned long long)serial << 32;
+            __hip_atomic_store(g, now | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, now | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        return;
     }
-    for (int s = 0; s < sa.n_spatial; s++)
-    {
-        unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
-        const unsigned long long now = (unsigned long long)serial << 32;
-        g[0] = now | (g[0] & 0xffffffffull);
-        g[1] = now | (g[1] & 0xffffffffull);
-    }
+}
+
+// a type P / p prior's parameter must stay finite (and far from overflow: the reference sums up to 36 of them)
+__device__ __forceinline__ bool second_order_safe(double m)
+{
+    return fabs(m) < 1e300; // (false for NaN)
 }
 
 template <int P, bool NEEDF, class NZ = SpWhite<P> >
@@ -767,99 +761,54 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     sp_load<P>(sa, v, st, mo);
     const int dims = sa.spatial_dims;
     int n1[6];
-    bool ok1[6], live1[6];
+    bool live1[6];
 #pragma unroll
     for (int a = 0; a < 6; a++)
     {
         const int u = sa.nn[(size_t)v * 6 + a];
         n1[a] = (u < 0) ? v : u;
-        ok1[a] = (u >= 0);
+        live1[a] = (u >= 0);
     }
 #pragma unroll
     for (int a = 0; a < 6; a++)
-        live1[a] = ok1[a] && (sa.status[n1[a]] == 0);
+        live1[a] = live1[a] && (sa.status[n1[a]] == 0);
     int nn_live = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++)
         nn_live += live1[a] ? 1 : 0;
-    // types P, p: the second-neighbour list - the neighbours of every first neighbour that exists (alive or not: the
-    // list was fixed when it was built and reaches across a failed voxel), except v itself and the ones that have
-    // failed (Vb::IgnoreVoxel, inference_vb.cc:266-297) - in list order, as positions
-    int nn2_live = 0;
-    int dir1[6] = { 0, 1, 2, 3, 4, 5 }; // the direction (+x -x +y -y +z -z) of each listed first neighbour
-    if (sa.sw_npos2) // (uniform)
-    {
-        // The neighbour table lists the neighbours that exist one after the other. The sweeps' tables are written
-        // by DIRECTION instead (slot a = direction a, slot a * 6 + b = direction b from the neighbour in direction a;
-        // -1 where there is none): the order of the entries that exist is the same, so every sum is, and the slab
-        // form can tell from a slot alone how many levels away the neighbour is.
-        const size_t V3 = V;
-        const int x0 = sa.xyz[v], y0 = sa.xyz[V3 + v], z0 = sa.xyz[2 * V3 + v];
-        auto direction = [&](int xa, int ya, int za, int u) -> int {
-            const int dx = sa.xyz[u] - xa, dy = sa.xyz[V3 + u] - ya, dz = sa.xyz[2 * V3 + u] - za;
-            return dx > 0 ? 0 : (dx < 0 ? 1 : (dy > 0 ? 2 : (dy < 0 ? 3 : (dz > 0 ? 4 : 5))));
-        };
-        if (!ignored)
-            for (int e = 0; e < 36; e++)
-                sa.sw_npos2[(size_t)e * NP + pos] = -1;
-        for (int a = 0; a < 6; a++)
-        {
-            const int da = ok1[a] ? direction(x0, y0, z0, n1[a]) : a;
-            dir1[a] = da;
-            const int xa = sa.xyz[n1[a]], ya = sa.xyz[V3 + n1[a]], za = sa.xyz[2 * V3 + n1[a]];
-            int n2[6];
-#pragma unroll
-            for (int b = 0; b < 6; b++)
-                n2[b] = sa.nn[(size_t)n1[a] * 6 + b];
-#pragma unroll
-            for (int b = 0; b < 6; b++)
-            {
-                const int w = (n2[b] < 0) ? v : n2[b];
-                const bool live2 = ok1[a] && (n2[b] >= 0) && (n2[b] != v) && (sa.status[w] == 0);
-                nn2_live += live2 ? 1 : 0;
-                if (!ignored && live2)
-                    sa.sw_npos2[(size_t)(da * 6 + direction(xa, ya, za, w)) * NP + pos] = sa.pos_of[w];
-            }
-        }
-    }
     double Fprior = 0;
-    int si = 0; // index among the spatial parameters
+    int si = 0; // index among the parameters the sweep updates
 #pragma unroll
     for (int k = 0; k < P; k++)
     {
         const int type = ka.cfg.prior_type[k];
-        if (is_spatial_type(type)) // SpatialPrior::ApplyToMVN (priors.cc:362-482), types M and m
+        if (is_spatial_type(type)) // SpatialPrior::ApplyToMVN (priors.cc:362-482)
         {
             const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
             const bool dirichlet = (type == FVB_PRIOR_SPATIAL_m || type == FVB_PRIOR_SPATIAL_p);
             const int nn = dirichlet ? 2 * dims : nn_live;
-            const int nn2 = dirichlet ? 4 * dims * dims - nn : nn2_live;
             const double aK = sa.aK[k];
             const double spatial_prec = second ? aK * (nn * nn + nn) : ((type == FVB_PRIOR_SPATIAL_M) ? aK * (nn + 1e-8) : aK * nn);
             st.pprec[k] = dirichlet ? spatial_prec : ka.cfg.prior_prec[k] + spatial_prec;
             const double pcov = 1.0 / st.pprec[k];
+            if (second)
+            {
+                // as coded the MRF mean is 0 x (a finite sum) (second_order_rec): what is left is the parameter's own prior
+                st.pm[k] = pcov * (ka.cfg.prior_prec[k] * ka.cfg.prior_mean[k]);
+                if (!ignored && !second_order_safe(st.m[k]))
+                    sa.sw_flags[0] = 1;
+                continue;
+            }
             if (!ignored)
             {
-                // (types P, p: the sweep forms the prior mean with second_order_pm from the spatial precision itself)
                 sa.sw_pprec[si * NP + pos] = st.pprec[k];
-                sa.sw_q[si * NP + pos] = second ? spatial_prec : pcov * spatial_prec;
-                sa.sw_rec[si * NP + pos] = second ? ((nn != 0) ? 1 / double(8 * nn - nn2) : 0.0) : 1 / double(nn);
+                sa.sw_q[si * NP + pos] = pcov * spatial_prec;
+                sa.sw_rec[si * NP + pos] = 1 / double(nn);
                 sa.sw_x[si * NP + pos] = st.m[k];
-                if (sa.sl_mode == 1)
-                {
-                    // what each neighbour contributes if the sweep reaches it AFTER this voxel: its mean now
+                // what each neighbour contributes if the sweep reaches it AFTER this voxel: its mean now
 #pragma unroll
-                    for (int a = 0; a < 6; a++)
-                        sa.sw_nbr[((size_t)si * 6 + a) * NP + pos] = live1[a] ? sa.state[(size_t)(L::M + k) * V + n1[a]] : 0.0;
-                }
-                else
-                {
-                    // the mean as the sweep's neighbours read it: a value of the PREVIOUS sweep
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(st.m[k]);
-                    const unsigned long long old = (unsigned long long)(serial - 1) << 32;
-                    sa.sw_gran[((size_t)si * NP + pos) * 2] = old | (bits & 0xffffffffull);
-                    sa.sw_gran[((size_t)si * NP + pos) * 2 + 1] = old | (bits >> 32);
-                }
+                for (int a = 0; a < 6; a++)
+                    sa.sw_nbr[((size_t)si * 6 + a) * NP + pos] = live1[a] ? sa.state[(size_t)(L::M + k) * V + n1[a]] : 0.0;
             }
             si++;
         }
@@ -894,13 +843,12 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     if (NEEDF)
     {
         // CalculateF "before" (:643) with the old posterior and the new priors. Only its FAILURE is observable
-        // (a non-finite F stops the voxel before its means are updated); the one term that needs the spatial
-        // prior means, (m - mu0)' Lambda0 (m - mu0), is checked where they are known (noise kernel).
+        // (a non-finite F stops the voxel before its means are updated); the one term that needs the swept
+        // parameters' prior means, (m - mu0)' Lambda0 (m - mu0), is checked where they are known (noise kernel).
         VoxelState<P> tmp = st;
-        int sk = 0;
 #pragma unroll
         for (int k = 0; k < P; k++)
-            if (is_spatial_type(ka.cfg.prior_type[k]))
+            if (is_swept_type(ka.cfg.prior_type[k]))
                 tmp.pm[k] = tmp.m[k];
         double F0;
         bool finite0 = true;
@@ -911,7 +859,6 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
             sweep_release(sa, pos, serial, v);
             return;
         }
-        (void)sk;
     }
     // eq (19) and its inverse, exactly update_theta's; the means follow in the sweep and in the noise kernel
     const double phibar = st.b * st.c;
@@ -929,33 +876,25 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         sweep_release(sa, pos, serial, v);
         return;
     }
-    si = 0;
-#pragma unroll
-    for (int k = 0; k < P; k++)
+    if (sa.n_spatial > 0) // (uniform) the records of the ordered sweep
     {
-        const double base = theta_rhs_base<P>(phibar, mo, k);
-        if (is_spatial_type(ka.cfg.prior_type[k]))
+        si = 0;
+#pragma unroll
+        for (int k = 0; k < P; k++)
         {
-            sa.sw_rhs0[k * NP + pos] = base;
+            const double base = theta_rhs_base<P>(phibar, mo, k);
+            const int type = ka.cfg.prior_type[k];
+            if (is_swept_type(type))
+            {
+                sa.sw_rhs0[k * NP + pos] = base;
 #pragma unroll
-            for (int j = 0; j < P; j++)
-                sa.sw_sig[((size_t)si * P + j) * NP + pos] = st.Sig[tri(k, j)];
-            si++;
+                for (int j = 0; j < P; j++)
+                    sa.sw_sig[((size_t)si * P + j) * NP + pos] = st.Sig[tri(k, j)];
+                si++;
+            }
+            else
+                sa.sw_rhs0[k * NP + pos] = theta_rhs(base, st.pprec[k], st.pm[k]);
         }
-        else
-            sa.sw_rhs0[k * NP + pos] = theta_rhs(base, st.pprec[k], st.pm[k]);
-    }
-    if (sa.sw_npos2) // (by direction, see above)
-    {
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-            sa.sw_npos[a * NP + pos] = -1;
-        for (int a = 0; a < 6; a++)
-            if (live1[a])
-                sa.sw_npos[dir1[a] * NP + pos] = sa.pos_of[n1[a]];
-    }
-    else
-    {
 #pragma unroll
         for (int a = 0; a < 6; a++)
             sa.sw_npos[a * NP + pos] = live1[a] ? sa.pos_of[n1[a]] : -1;
@@ -975,377 +914,6 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         for (int i = 0; i < L::PT; i++)
             p[(size_t)(L::SIG + i) * V] = st.Sig[i];
         p[(size_t)L::LOGDET * V] = st.logdetLam;
-    }
-}
-
-// What a sweep step needs of one voxel besides its neighbours' means: read ahead of the level barrier.
-template <int P, int NS>
-struct SweepRecord
-{
-    int alive;
-    int np[6];
-    double rhs0[P];
-    double pprec[NS], q[NS], rec[NS]; // per spatial parameter (NS = the most the kernel is built for)
-    double sig[NS][P];                // [spatial parameter][j]
-    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
-    {
-        // every load unconditional (a lane without a voxel reads position 0 and ignores it): a load that had to
-        // wait for the `alive` word first would cost the step a second memory round trip
-        const size_t NP = (size_t)sa.n_pos;
-        const bool have = pos >= 0;
-        pos = have ? pos : 0;
-        const int alive_word = sa.sw_alive[pos];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-            np[a] = sa.sw_npos[a * NP + pos];
-#pragma unroll
-        for (int j = 0; j < P; j++)
-            rhs0[j] = sa.sw_rhs0[j * NP + pos];
-#pragma unroll
-        for (int s = 0; s < NS; s++)
-            if (s < ns)
-            {
-                pprec[s] = sa.sw_pprec[s * NP + pos];
-                q[s] = sa.sw_q[s * NP + pos];
-                rec[s] = sa.sw_rec[s * NP + pos];
-#pragma unroll
-                for (int j = 0; j < P; j++)
-                    sig[s][j] = sa.sw_sig[((size_t)s * P + j) * NP + pos];
-            }
-        alive = have ? alive_word : 0;
-    }
-};
-
-// The step of (up to) NV voxels of one level together: prior means of the spatial parameters from the
-// neighbours' CURRENT means, then eq (20). level_begin = first position of the level: neighbours before it
-// were (or are being) updated in THIS sweep and are waited for - their granules must carry this sweep's
-// serial number -, neighbours after it still hold the previous sweep's means. All voxels of the call poll
-// in the same loop: one memory round trip per attempt, not one per voxel.
-// next / next_pos: the records to fetch for the following level (or NULL). They are requested right after the
-// first poll's loads have been issued and before their results are used: younger than the poll's loads, they
-// are not waited for with them (s_waitcnt vmcnt(N) leaves the N youngest outstanding), and by the next level's
-// poll they are old enough to be back.
-template <int P, int NS, int NV>
-__device__ __forceinline__ void sweep_step(const SpatialArgs &sa, const SweepRecord<P, NS> (&r)[NV], const int (&pos)[NV], int ns,
-    int level_begin, SweepRecord<P, NS> *next = nullptr, const int *next_pos = nullptr)
-{
-    const size_t NP = (size_t)sa.n_pos;
-    const unsigned long long serial = sa.sw_serial;
-    double rhs[NV][P];
-#pragma unroll
-    for (int i = 0; i < NV; i++)
-#pragma unroll
-        for (int j = 0; j < P; j++)
-            rhs[i][j] = r[i].rhs0[j];
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            const unsigned long long *g = sa.sw_gran + (size_t)s * NP * 2;
-            unsigned long long lo[NV][6], hi[NV][6];
-            int spins = 0;
-            for (;;)
-            {
-#pragma unroll
-                for (int i = 0; i < NV; i++)
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-                    {
-                        const size_t at = (size_t)((!r[i].alive || r[i].np[a] < 0) ? 0 : r[i].np[a]) * 2;
-                        lo[i][a] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hi[i][a] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                if (next && s == 0 && spins == 0)
-                {
-#pragma unroll
-                    for (int i = 0; i < NV; i++)
-                        next[i].load(sa, next_pos[i], ns);
-                }
-                bool ready = true;
-#pragma unroll
-                for (int i = 0; i < NV; i++)
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-                        if (r[i].alive && r[i].np[a] >= 0 && r[i].np[a] < level_begin)
-                            ready = ready && ((lo[i][a] >> 32) == serial) && ((hi[i][a] >> 32) == serial);
-#ifdef FVB_SWEEP_STATS
-                atomicAdd((unsigned long long *)(sa.sw_flags + 4), 1ull); // poll attempts
-#endif
-                if (ready)
-                    break;
-                if (++spins > (1 << 22)) // never (every wave of the grid is resident); the run is repeated
-                {
-                    sa.sw_flags[0] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int i = 0; i < NV; i++)
-            {
-                if (!r[i].alive)
-                    continue;
-                double contrib = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-                    if (r[i].np[a] >= 0)
-                        contrib += __longlong_as_double((long long)((hi[i][a] << 32) | (lo[i][a] & 0xffffffffull)));
-                const double spatial_mean = contrib * r[i].rec[s];
-                const double pm = r[i].q[s] * spatial_mean;
-                sa.sw_pm[s * NP + pos[i]] = pm;
-                const int k = sa.spatial_param[s];
-#pragma unroll
-                for (int j = 0; j < P; j++)
-                    if (j == k)
-                        rhs[i][j] = theta_rhs(rhs[i][j], r[i].pprec[s], pm);
-            }
-        }
-#pragma unroll
-    for (int i = 0; i < NV; i++)
-    {
-        if (!r[i].alive)
-            continue;
-#pragma unroll
-        for (int s = 0; s < NS; s++)
-            if (s < ns)
-            {
-                double m = 0;
-#pragma unroll
-                for (int j = 0; j < P; j++)
-                    m = __builtin_fma(r[i].sig[s][j], rhs[i][j], m);
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-                unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos[i]) * 2;
-                __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sa.sw_x[s * NP + pos[i]] = m; // for the kernels after this one
-            }
-    }
-}
-
-// The ordered part: ONE launch, gridDim.x workgroups of 256 lanes, every wave resident. Each lane walks the
-// levels in order with (up to) two voxels per level; nothing synchronises the grid: a voxel waits for exactly
-// the neighbours it needs - those of the previous level - by polling their means, which travel as 8-byte
-// granules {half of the double, serial number of the sweep} written and read with device-scope (sc1)
-// accesses: a granule is valid or not by itself, no flag, no fence, no barrier (MI355X_MICROARCH.md
-// "handoff-1to1": ~1 us per hop). Every wave advances through the levels in the same order and level 0 waits
-// for nobody, so the grid cannot lock up as long as it is resident (64 workgroups at most on 256 CUs); a poll
-// that does not end raises sw_flags[0] and the run is repeated with the per-level launches. The records of the
-// NEXT level's voxels (everything that does not wait for a neighbour) are requested as soon as the current
-// level's results have left; a level with more than 512 x gridDim.x voxels takes the rest one by one.
-template <int P, int NS>
-__global__ __launch_bounds__(256) void vb_spatial_sweep_kernel(const SpatialArgs sa)
-{
-    const int ns = sa.n_spatial;
-    const int nl = sa.n_levels;
-    const int stride = gridDim.x * 256;
-    const int lane0 = blockIdx.x * 256 + threadIdx.x;
-    extern __shared__ int s_tab[]; // [2][n_levels]: first position, voxel count (no dependent global load per level)
-    for (int i = threadIdx.x; i < nl; i += 256)
-    {
-        s_tab[i] = sa.sw_level_pos[i];
-        s_tab[nl + i] = sa.sw_level_count[i];
-    }
-    __syncthreads();
-    SweepRecord<P, NS> r[2], nx[2];
-    int begin = s_tab[0], count = s_tab[nl];
-    r[0].load(sa, lane0 < count ? begin + lane0 : -1, ns);
-    r[1].load(sa, lane0 + stride < count ? begin + lane0 + stride : -1, ns);
-    for (int l = 0; l < nl; l++)
-    {
-        const int pos[2] = { begin + lane0, begin + lane0 + stride };
-        const int nbegin = (l + 1 < nl) ? s_tab[l + 1] : 0, ncount = (l + 1 < nl) ? s_tab[nl + l + 1] : 0;
-        const int npos[2] = { lane0 < ncount ? nbegin + lane0 : -1, lane0 + stride < ncount ? nbegin + lane0 + stride : -1 };
-        sweep_step<P, NS, 2>(sa, r, pos, ns, begin, nx, npos);
-        for (int i = lane0 + 2 * stride; i < count; i += stride) // (huge levels only)
-        {
-            SweepRecord<P, NS> one[1];
-            one[0].load(sa, begin + i, ns);
-            const int p1[1] = { begin + i };
-            sweep_step<P, NS, 1>(sa, one, p1, ns, begin);
-        }
-        r[0] = nx[0];
-        r[1] = nx[1];
-        begin = nbegin;
-        count = ncount;
-    }
-}
-
-// ---- the data-flow sweep with second neighbours (types P and p, next to any M / m) ------------------------
-// The same single launch for priors that also read the neighbours' neighbours (priors.cc:377-385): with
-// level = x + 2y + 3z every one of the 6 + 18 stencil offsets to a smaller voxel index lowers the level, so a voxel
-// polls the granules of its first neighbours and of the (up to 30, with repeats) entries of its second-neighbour
-// list and waits for those of earlier levels to carry this sweep's serial number. One voxel per lane and level
-// (the polls are 84 loads per spatial parameter); everything else as above.
-template <int P, int NS>
-struct SweepRecord2
-{
-    SweepRecord<P, NS> r;
-    int np2[36];
-    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
-    {
-        r.load(sa, pos, ns);
-        const size_t NP = (size_t)sa.n_pos;
-        pos = pos >= 0 ? pos : 0;
-#pragma unroll
-        for (int e = 0; e < 36; e++)
-            np2[e] = sa.sw_npos2[(size_t)e * NP + pos];
-    }
-};
-
-template <int P, int NS>
-__device__ __forceinline__ void sweep2_step(const SpatialArgs &sa, const SweepRecord2<P, NS> &rec, int pos, int ns, int level_begin,
-    SweepRecord2<P, NS> *next, int next_pos)
-{
-    const SweepRecord<P, NS> &r = rec.r;
-    const size_t NP = (size_t)sa.n_pos;
-    const unsigned long long serial = sa.sw_serial;
-    double rhs[P];
-#pragma unroll
-    for (int j = 0; j < P; j++)
-        rhs[j] = r.rhs0[j];
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            const int k = sa.spatial_param[s];
-            const int type = sa.ka.cfg.prior_type[k];
-            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p); // (uniform)
-            const unsigned long long *g = sa.sw_gran + (size_t)s * NP * 2;
-            unsigned long long lo[42], hi[42];
-            // every listed granule once (the later neighbours hold the previous sweep's means and cannot change before
-            // this voxel is done: they wait for it) ...
-#pragma unroll
-            for (int e = 0; e < 42; e++)
-            {
-                const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
-                const bool want = r.alive && np >= 0 && (e < 6 || second);
-                const size_t at = (size_t)(want ? np : 0) * 2;
-                lo[e] = __hip_atomic_load(g + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hi[e] = __hip_atomic_load(g + at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (next && s == 0)
-                next->load(sa, next_pos, ns);
-            // ... then only the neighbours of earlier levels that do not carry this sweep's serial number yet, again
-            unsigned long long pending = 0;
-#pragma unroll
-            for (int e = 0; e < 42; e++)
-            {
-                const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
-                if (r.alive && np >= 0 && np < level_begin && (e < 6 || second)
-                    && (((lo[e] >> 32) != serial) || ((hi[e] >> 32) != serial)))
-                    pending |= 1ull << e;
-            }
-            int spins = 0;
-            while (__any(pending != 0))
-            {
-                if (++spins > (1 << 22)) // never (every wave of the grid is resident); the run is repeated
-                {
-                    sa.sw_flags[0] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                    if ((pending >> e) & 1)
-                    {
-                        const int np = (e < 6) ? r.np[e] : rec.np2[e - 6];
-                        lo[e] = __hip_atomic_load(g + (size_t)np * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hi[e] = __hip_atomic_load(g + (size_t)np * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                    if (((pending >> e) & 1) && ((lo[e] >> 32) == serial) && ((hi[e] >> 32) == serial))
-                        pending &= ~(1ull << e);
-            }
-            if (!r.alive)
-                continue;
-            double contrib = 0, contrib2 = 0;
-#pragma unroll
-            for (int e = 0; e < 6; e++)
-                if (r.np[e] >= 0)
-                    contrib += __longlong_as_double((long long)((hi[e] << 32) | (lo[e] & 0xffffffffull)));
-            double pm;
-            if (second)
-            {
-#pragma unroll
-                for (int e = 6; e < 42; e++)
-                    if (rec.np2[e - 6] >= 0)
-                        contrib2 += -__longlong_as_double((long long)((hi[e] << 32) | (lo[e] & 0xffffffffull)));
-                const double spatial_mean = (r.rec[s] != 0) ? second_order_mean(contrib, contrib2, r.rec[s]) : 0.0;
-                pm = second_order_pm(1.0 / r.pprec[s], r.q[s], spatial_mean, sa.ka.cfg.prior_prec[k], sa.ka.cfg.prior_mean[k]);
-            }
-            else
-            {
-                const double spatial_mean = contrib * r.rec[s];
-                pm = r.q[s] * spatial_mean;
-            }
-            sa.sw_pm[s * NP + pos] = pm;
-            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1) // probe (tools/measure/slab2_debug.py)
-            {
-                sa.sw_nbr[0 * NP + pos] = contrib;
-                sa.sw_nbr[1 * NP + pos] = contrib2;
-                sa.sw_nbr[2 * NP + pos] = pm;
-                sa.sw_nbr[4 * NP + pos] = r.q[s];
-                sa.sw_nbr[5 * NP + pos] = r.pprec[s];
-            }
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                if (j == k)
-                    rhs[j] = theta_rhs(rhs[j], r.pprec[s], pm);
-        }
-    if (!r.alive)
-        return;
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            double m = 0;
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                m = __builtin_fma(r.sig[s][j], rhs[j], m);
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-            unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
-            __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sa.sw_x[s * NP + pos] = m;
-            if ((sa.sl_debug & 256) && sa.sw_nbr && s == 0 && sa.sw_serial == 1)
-                sa.sw_nbr[3 * NP + pos] = m;
-        }
-}
-
-template <int P, int NS>
-__global__ __launch_bounds__(256) void vb_spatial_sweep2_kernel(const SpatialArgs sa)
-{
-    const int ns = sa.n_spatial;
-    const int nl = sa.n_levels;
-    // (launched with ONE wave per workgroup: the 150 gathered loads per voxel and level go through the texture
-    // addresser of the compute unit, which four waves of one workgroup would share)
-    const int W = blockDim.x;
-    const int stride = gridDim.x * W;
-    const int lane0 = blockIdx.x * W + threadIdx.x;
-    extern __shared__ int s_tab[]; // [2][n_levels]: first position, voxel count
-    for (int i = threadIdx.x; i < nl; i += W)
-    {
-        s_tab[i] = sa.sw_level_pos[i];
-        s_tab[nl + i] = sa.sw_level_count[i];
-    }
-    __syncthreads();
-    SweepRecord2<P, NS> r, nx;
-    int begin = s_tab[0], count = s_tab[nl];
-    r.load(sa, lane0 < count ? begin + lane0 : -1, ns);
-    for (int l = 0; l < nl; l++)
-    {
-        const int nbegin = (l + 1 < nl) ? s_tab[l + 1] : 0, ncount = (l + 1 < nl) ? s_tab[nl + l + 1] : 0;
-        sweep2_step<P, NS>(sa, r, begin + lane0, ns, begin, &nx, lane0 < ncount ? nbegin + lane0 : -1);
-        for (int i = lane0 + stride; i < count; i += stride) // (huge levels only)
-        {
-            SweepRecord2<P, NS> one;
-            one.load(sa, begin + i, ns);
-            sweep2_step<P, NS>(sa, one, begin + i, ns, begin, nullptr, -1);
-        }
-        r = nx;
-        begin = nbegin;
-        count = ncount;
     }
 }
 
@@ -1423,7 +991,7 @@ __device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecor
 #pragma unroll
     for (int a = 0; a < 6; a++)
         from_below |= ((r.np[a] >= 0) && (r.np[a] < slab_begin)) || (r.np[a] == FVB_NP_BELOW);
-    if (!from_below || (sa.sl_debug & 1))
+    if (!from_below)
         return;
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
@@ -1436,9 +1004,12 @@ __device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecor
 #pragma nounroll
             while ((r.in_lo[s] >> 32) != serial || (r.in_hi[s] >> 32) != serial)
             {
-                if (++spins > (1 << 22)) // never (slabs start in order and every slab only waits for the one below)
+                // never (slabs start in order and every slab only waits for the one below) - but if a hand-over is missed
+                // all the same, ONE wait runs to its limit: it raises the flag every other wait looks at, so the
+                // kernel drains at once and the host repeats the run with the per-level launches
+                if (++spins > (1 << 22) || ((spins & 63) == 0 && __hip_atomic_load(sa.sw_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
                 {
-                    sa.sw_flags[0] = 1;
+                    __hip_atomic_store(sa.sw_flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -1600,7 +1171,7 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         double m[NS], pm[NS];
         const bool work = lane < count && r.alive;
-        if (work && !(sa.sl_debug & 4))
+        if (work)
             slab_step<P, NS>(sa, r, begin + lane, lane, ns, prev_begin, prev_count, slab_begin, lds_prev, lds_cur, stride, m, pm);
         for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide: 1024 lanes, one group)
         {
@@ -1617,272 +1188,11 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
         if ((threadIdx.x & 63) == 0)
             __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // while the next group works: results to memory, then this group's next record
-        if (work && !(sa.sl_debug & 8))
+        if (work)
             slab_store<P, NS>(sa, r, begin + lane, ns, slab_end, m, pm);
         const int nx = li + G;
-        if (nx < n_runs && !(sa.sl_debug & 2))
-            r.load(sa, lane < tab[n_runs + nx] ? tab[nx] + lane : -1, ns);
-    }
-}
-
-// ---- the ordered part, slab form, second neighbours (types P and p) -------------------------------------------
-// As the slab sweep above, for the stencil of priors.cc:377-385: with level = x + 2y + 3z the 3 + 15 listed neighbours
-// of EARLIER levels are up to 6 levels back. A workgroup (512 lanes) owns a slab of z-planes and keeps the means of
-// its last 8 runs in LDS; the slab's runs are its levels one by one, empty ones included, so the run of a neighbour
-// follows from the slot it has in the list: for the second-neighbour forms the prep kernel writes the tables
-// DIRECTION-indexed (slot a = direction +x -x +y -y +z -z, -1 where there is none - the neighbour table itself lists
-// the neighbours that exist one after the other; the order of the sums is the same), and a direction changes the
-// level by +1 -1 +2 -2 +3 -3: known at compile time. Per slot:
-//   level change > 0 (3 + 15 slots): a later neighbour - its mean of the previous sweep, read from sw_x (nobody
-//       overwrites it before this voxel is done: it waits for this voxel);
-//   level change < 0, position inside the slab: LDS, run li + change, offset position - first position of that run;
-//   level change < 0, position below the slab: the neighbour's own granule in device-scope memory, polled until it
-//       carries this sweep's serial number (every voxel writes its granule when it is done, as in the data-flow form).
-// Sums in list order, the expressions of the other forms (second_order_mean / second_order_pm): the same bits.
-__device__ __forceinline__ constexpr int slab2_dir_level(int a)
-{
-    return a == 0 ? 1 : a == 1 ? -1 : a == 2 ? 2 : a == 3 ? -2 : a == 4 ? 3 : -3;
-}
-// slot e: 0..5 the first neighbours, 6 + a * 6 + b neighbour b of neighbour a
-__device__ __forceinline__ constexpr int slab2_slot_level(int e)
-{
-    return e < 6 ? slab2_dir_level(e) : slab2_dir_level((e - 6) / 6) + slab2_dir_level((e - 6) % 6);
-}
-
-template <int P, int NS>
-struct Slab2Record
-{
-    SweepRecord<P, NS> r;
-    int np2[36];
-    double later[NS][42]; // (only the slots of later levels are loaded and used)
-    unsigned long long lo[NS][42], hi[NS][42]; // (only the slots of earlier levels below the slab)
-    __device__ __forceinline__ int slot_pos(int e) const
-    {
-        return e < 6 ? r.np[e] : np2[e - 6];
-    }
-    __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
-    {
-        r.load(sa, pos, ns);
-        const size_t NP = (size_t)sa.n_pos;
-        pos = pos >= 0 ? pos : 0;
-#pragma unroll
-        for (int e = 0; e < 36; e++)
-            np2[e] = sa.sw_npos2[(size_t)e * NP + pos];
-    }
-    // the second stage, once the positions have arrived: the later neighbours' means and a first look at the granules
-    // of the neighbours below the slab
-    __device__ __forceinline__ void gather(const SpatialArgs &sa, int ns, int slab_begin)
-    {
-        const size_t NP = (size_t)sa.n_pos;
-#pragma unroll
-        for (int s = 0; s < NS; s++)
-            if (s < ns)
-            {
-                const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
-                const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                {
-                    const int np = slot_pos(e);
-                    const bool want = r.alive && np >= 0 && (e < 6 || second);
-                    if (slab2_slot_level(e) > 0)
-                        later[s][e] = sa.sw_x[(size_t)s * NP + (want ? np : 0)];
-                    else if (slab2_slot_level(e) < 0)
-                    {
-                        const bool below = want && np < slab_begin;
-                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + (below ? np : 0)) * 2;
-                        lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-    }
-};
-
-// wait until every neighbour below the slab carries this sweep's serial number
-template <int P, int NS>
-__device__ __forceinline__ void slab2_wait_below(const SpatialArgs &sa, Slab2Record<P, NS> &rec, int ns, int slab_begin)
-{
-    const size_t NP = (size_t)sa.n_pos;
-    const unsigned long long serial = sa.sw_serial;
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            const int type = sa.ka.cfg.prior_type[sa.spatial_param[s]];
-            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
-            unsigned long long pending = 0;
-#pragma unroll
-            for (int e = 0; e < 42; e++)
-                if (slab2_slot_level(e) < 0)
-                {
-                    const int np = rec.slot_pos(e);
-                    if (rec.r.alive && np >= 0 && np < slab_begin && (e < 6 || second)
-                        && (((rec.lo[s][e] >> 32) != serial) || ((rec.hi[s][e] >> 32) != serial)))
-                        pending |= 1ull << e;
-                }
-            int spins = 0;
-            while (__any(pending != 0))
-            {
-                if (++spins > (1 << 22)) // never (a slab waits for the slabs below only); the run is repeated
-                {
-                    sa.sw_flags[0] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1))
-                    {
-                        const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + rec.slot_pos(e)) * 2;
-                        rec.lo[s][e] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        rec.hi[s][e] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                for (int e = 0; e < 42; e++)
-                    if (slab2_slot_level(e) < 0 && ((pending >> e) & 1) && ((rec.lo[s][e] >> 32) == serial)
-                        && ((rec.hi[s][e] >> 32) == serial))
-                        pending &= ~(1ull << e);
-            }
-        }
-}
-
-// one voxel's step: li = its run, tab = the slab's run table (first positions), ring = the LDS means [8][ns][stride]
-template <int P, int NS>
-__device__ __forceinline__ void slab2_step(const SpatialArgs &sa, const Slab2Record<P, NS> &rec, int pos, int slot, int ns, int li,
-    const int *tab, int slab_begin, double *ring, int stride)
-{
-    const SweepRecord<P, NS> &r = rec.r;
-    const size_t NP = (size_t)sa.n_pos;
-    const unsigned long long serial = sa.sw_serial;
-    double rhs[P], pm_out[NS];
-#pragma unroll
-    for (int j = 0; j < P; j++)
-        rhs[j] = r.rhs0[j];
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            const int k = sa.spatial_param[s];
-            const int type = sa.ka.cfg.prior_type[k];
-            const bool second = (type == FVB_PRIOR_SPATIAL_P || type == FVB_PRIOR_SPATIAL_p);
-            double contrib = 0, contrib2 = 0;
-#pragma unroll
-            for (int e = 0; e < 42; e++)
-            {
-                const int np = rec.slot_pos(e);
-                if (np < 0 || (e >= 6 && !second))
-                    continue;
-                double val;
-                if (slab2_slot_level(e) > 0)
-                    val = rec.later[s][e];
-                else if (slab2_slot_level(e) < 0)
-                {
-                    if (np < slab_begin)
-                        val = __longlong_as_double((long long)((rec.hi[s][e] << 32) | (rec.lo[s][e] & 0xffffffffull)));
-                    else
-                    {
-                        const int run = li + slab2_slot_level(e);
-                        val = ring[((size_t)(run & 7) * ns + s) * stride + (np - tab[run])];
-                    }
-                }
-                else
-                    val = 0; // (a neighbour's neighbour that is the voxel itself: never listed)
-                if (e < 6)
-                    contrib += val;
-                else
-                    contrib2 += -val;
-            }
-            double pm;
-            if (second)
-            {
-                const double spatial_mean = (r.rec[s] != 0) ? second_order_mean(contrib, contrib2, r.rec[s]) : 0.0;
-                pm = second_order_pm(1.0 / r.pprec[s], r.q[s], spatial_mean, sa.ka.cfg.prior_prec[k], sa.ka.cfg.prior_mean[k]);
-            }
-            else
-            {
-                const double spatial_mean = contrib * r.rec[s];
-                pm = r.q[s] * spatial_mean;
-            }
-            pm_out[s] = pm;
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                if (j == k)
-                    rhs[j] = theta_rhs(rhs[j], r.pprec[s], pm);
-        }
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (s < ns)
-        {
-            double m = 0;
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                m = __builtin_fma(r.sig[s][j], rhs[j], m);
-            ring[((size_t)(li & 7) * ns + s) * stride + slot] = m;
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-            unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
-            __hip_atomic_store(g, (serial << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 1, (serial << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sa.sw_x[s * NP + pos] = m;
-            sa.sw_pm[s * NP + pos] = pm_out[s];
-        }
-}
-
-template <int P, int NS>
-__global__ __launch_bounds__(512) void vb_spatial_slab2_sweep_kernel(const SpatialArgs sa)
-{
-    extern __shared__ double s_mem[]; // [8][ns][sl_max_run] means of the last eight runs, then the slab's run table
-    const int ns = sa.n_spatial;
-    const int W = sa.sl_width, G = 512 / W;
-    const int g = threadIdx.x / W, lane = threadIdx.x % W; // (W is a multiple of 64: g is wave-uniform)
-    const int stride = sa.sl_max_run;
-    const int run0 = sa.sl_first_run[blockIdx.x], n_runs = sa.sl_first_run[blockIdx.x + 1] - run0;
-    int *tab = (int *)(s_mem + (size_t)8 * ns * stride); // [2][n_runs]: first position, count; then the counter
-    for (int i = threadIdx.x; i < n_runs; i += 512)
-    {
-        tab[i] = sa.sw_level_pos[run0 + i];
-        tab[n_runs + i] = sa.sw_level_count[run0 + i];
-    }
-    if (threadIdx.x == 0)
-        tab[2 * n_runs] = 0;
-    __syncthreads();
-    if (n_runs == 0)
-        return;
-    const int slab_begin = tab[0];
-    int *progress = tab + 2 * n_runs; // waves that have finished a run (every run gets W / 64 of them, in run order)
-    const int waves_per_group = W / 64;
-    Slab2Record<P, NS> rec;
-    if (g < n_runs)
-        rec.load(sa, lane < tab[n_runs + g] ? tab[g] + lane : -1, ns);
-    for (int li = g; li < n_runs; li += G)
-    {
-        const int begin = tab[li], count = tab[n_runs + li];
-        // second stage of this run's record (its positions were requested G runs ago), then the neighbours below
-        rec.gather(sa, ns, slab_begin);
-        if (lane < count)
-            slab2_wait_below<P, NS>(sa, rec, ns, slab_begin);
-        // runs 0 .. li - 1 complete? (the ring slot this run overwrites held run li - 8: read by runs up to li - 1)
-        const int need = li * waves_per_group;
-        while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-            __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane < count && rec.r.alive)
-            slab2_step<P, NS>(sa, rec, begin + lane, lane, ns, li, tab, slab_begin, s_mem, stride);
-        for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide)
-        {
-            Slab2Record<P, NS> one;
-            one.load(sa, begin + i, ns);
-            one.gather(sa, ns, slab_begin);
-            slab2_wait_below<P, NS>(sa, one, ns, slab_begin);
-            if (one.r.alive)
-                slab2_step<P, NS>(sa, one, begin + i, i, ns, li, tab, slab_begin, s_mem, stride);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((threadIdx.x & 63) == 0)
-            __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int nx = li + G;
         if (nx < n_runs)
-            rec.load(sa, lane < tab[n_runs + nx] ? tab[nx] + lane : -1, ns);
+            r.load(sa, lane < tab[n_runs + nx] ? tab[nx] + lane : -1, ns);
     }
 }
 
@@ -1903,7 +1213,7 @@ __device__ __forceinline__ bool sp_complete_theta(const SpatialArgs &sa, int v, 
     int si = 0;
 #pragma unroll
     for (int k = 0; k < P; k++)
-        if (is_spatial_type(ka.cfg.prior_type[k]))
+        if (is_swept_type(ka.cfg.prior_type[k]))
         {
             st.pm[k] = sa.sw_pm[si * NP + pos];
             m_new[k] = sa.sw_x[si * NP + pos];
@@ -1920,11 +1230,16 @@ __device__ __forceinline__ bool sp_complete_theta(const SpatialArgs &sa, int v, 
         rhs[k] = theta_rhs(theta_rhs_base<P>(phibar, mo, k), st.pprec[k], st.pm[k]);
 #pragma unroll
     for (int k = 0; k < P; k++)
-        if (!is_spatial_type(ka.cfg.prior_type[k]))
+        if (!is_swept_type(ka.cfg.prior_type[k]))
             m_new[k] = theta_mean<P>(st.Sig, rhs, k);
 #pragma unroll
     for (int k = 0; k < P; k++)
+    {
         st.m[k] = m_new[k];
+        // (types P, p: a mean that is not finite would reach the prior means of the voxels after this one)
+        if ((ka.cfg.prior_type[k] == FVB_PRIOR_SPATIAL_P || ka.cfg.prior_type[k] == FVB_PRIOR_SPATIAL_p) && !second_order_safe(m_new[k]))
+            sa.sw_flags[0] = 1;
+    }
     if (NEEDF) // F "theta" (:651): its value is overwritten, its failure would have stopped the voxel
     {
         double F0;
@@ -2064,13 +1379,10 @@ struct SpatialKernels
     const char *name;
     // the split first sweep
     SpatialPrepFn prep;
-    SpatialSweepFn sweep[3]; // built for 1, 2 and up to P spatial parameters (what a lane keeps in registers grows with it)
     SpatialKernelFn noise_fast;
-    SpatialSweepFn slab_sweep[3]; // the slab form of the sweep, same three builds
+    SpatialSweepFn slab_sweep[3]; // the ordered part, built for 1, 2 and up to P swept parameters (what a lane keeps in registers grows with it)
     int lds_classes;              // 1: setup / noise / noise_fast keep cfg.phi_index in LDS (n_times bytes of dynamic LDS)
     SpatialKernelFn noise_acc, noise_fast_acc; // the second sweep of the iterations that end in a pointwise re-centre, or NULL
-    SpatialSweepFn sweep2[3];                  // the data-flow sweep with second neighbours (types P, p)
-    SpatialSweepFn slab_sweep2[3];             // ... and its slab form
 };
 SpatialKernels get_spatial_kernels_poly(int P, bool need_f);
 SpatialKernels get_spatial_kernels_linear(int P, bool need_f);
@@ -2099,16 +1411,10 @@ SpatialKernelFn spatial_noise_acc(bool need_f)
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false>,                         \
             vb_spatial_pack_kernel<PP>, SpLayout<PP>::ROWS, "spatial<" TAG "," #PP ">",                      \
             need_f ? (SpatialPrepFn)vb_spatial_prep_kernel<PP, true> : (SpatialPrepFn)vb_spatial_prep_kernel<PP, false>, \
-            { vb_spatial_sweep_kernel<PP, 1>, vb_spatial_sweep_kernel<PP, (PP < 2 ? PP : 2)>,                  \
-                vb_spatial_sweep_kernel<PP, PP> },                                                           \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true, true>                     \
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true>,                   \
             { vb_spatial_slab_sweep_kernel<PP, 1>, vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>,        \
                 vb_spatial_slab_sweep_kernel<PP, PP> }, 0,                                                   \
-            spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f),    \
-            { vb_spatial_sweep2_kernel<PP, 1>, vb_spatial_sweep2_kernel<PP, (PP < 2 ? PP : 2)>,                \
-                vb_spatial_sweep2_kernel<PP, PP> },                                                          \
-            { vb_spatial_slab2_sweep_kernel<PP, 1>, vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)>,      \
-                vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)> } };
+            spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f) };
 
 } // namespace fvb

@@ -176,6 +176,7 @@ struct DevMem
     void *p = nullptr;
     hipStream_t stream = nullptr;
     bool plain = false; // hipMalloc'ed (fine-grained memory another device writes into), not from the pool
+    bool fine = false;  // ... and really fine-grained (alloc_fine falls back to ordinary device memory)
     ~DevMem()
     {
         reset();
@@ -188,6 +189,7 @@ struct DevMem
             (void)hipFreeAsync(p, stream);
         p = nullptr;
         plain = false;
+        fine = false;
     }
     // memory that a kernel on ANOTHER device writes while a kernel on this one polls it (the inboxes of the slab sweep
     // across devices): fine-grained, i.e. not held in this device's L2 between the polls
@@ -195,8 +197,11 @@ struct DevMem
     {
         plain = true;
         hipError_t e = hipExtMallocWithFlags(&p, bytes ? bytes : 8, hipDeviceMallocFinegrained);
+        fine = (e == hipSuccess);
         if (e != hipSuccess)
         {
+            // ordinary device memory: good for slabs that share a device; across devices a remote store might stay
+            // invisible to the polling device's L2, so the caller takes the level-chunk pipeline then (gran_fine)
             (void)hipGetLastError();
             e = hipMalloc(&p, bytes ? bytes : 8);
         }
@@ -439,13 +444,11 @@ struct fvb_spatial_run
     DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums, d_seg_start;
     int n_segments = 0;
     double t_geometry_ms = 0, t_neighbours_ms = 0;
-    // the split first sweep (vb_spatial.h): whole-volume runs with first-neighbour priors (types M, m)
+    // the split first sweep (vb_spatial.h): whole-volume runs, or one of several slabs that sweep together
     bool allow_fast = false, fast = false;
     bool multi_fast = false; // one of several slabs on several devices that sweep together (fabber_vb_run_spatial_host_multi)
     int device_share = 1;    // how many such slabs run on THIS device at once (a device listed several times)
-    bool fast_second = false; // the split sweep with second neighbours (types P, p): vb_spatial_sweep2_kernel
-    bool slab2 = false;       // ... in its slab form: vb_spatial_slab2_sweep_kernel
-    DevMem d_xyz;             // (the co-ordinates on the device for the prep kernel of those forms)
+    bool gran_fine = false;  // multi_fast: the inboxes are fine-grained memory (another DEVICE may write them)
     DevMem d_up_pos;
     std::vector<int32_t> h_pos_of; // (multi_fast: the numbering, for the slab below to address this slab's inboxes)
     int fast_prep(int it);
@@ -455,7 +458,7 @@ struct fvb_spatial_run
     std::vector<int32_t> level_begin_counts; // voxels per level
     DevMem d_pos_of, d_level_pos, d_level_count, d_sw_f64, d_sw_i32, d_sw_sync, d_sw_gran, d_slab_first;
     int max_runs_per_slab = 0;
-    bool slab_form = false; // the sweep's workgroups own z-slabs (vb_spatial_slab_sweep_kernel), else the data-flow sweep
+    bool slab_form = false; // (= fast) the voxels are numbered slab-major for vb_spatial_slab_sweep_kernel
     int sweep_fast(int it);
     int fast_failed(bool &failed);
     // the second-sweep kernel of iteration `it`: the instance with the half-ulp exp where the iteration ends in one
@@ -589,16 +592,21 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     t_neighbours_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     const int32_t *X = sp.coords, *Y = sp.coords + V, *Z = sp.coords + 2 * (size_t)V;
     // Level function a x + b y + c z: a stencil offset that leads to a smaller voxel index must
-    // lower the level, one that leads to a larger index must raise it. First neighbours only
-    // (types M, m): (1,1,1). Second neighbours too (types P, p read neighbours of neighbours, e.g.
-    // (x+1, y-1) which has a smaller index): b > a and c > b, so (1,2,3).
-    bool second_neighbours = false;
+    // lower the level, one that leads to a larger index must raise it. First neighbours only: (1,1,1). Second
+    // neighbours too (the per-level kernel sums the neighbours of neighbours for types P, p, e.g. (x+1, y-1) which
+    // has a smaller index - the sum is multiplied by the 0 of priors.cc:455, but a NaN in it is not lost): b > a and
+    // c > b, so (1,2,3). The split form treats types P, p as local (vb_spatial.h) and numbers with (1,1,1).
+    bool second_neighbours = false, minus_zero = false;
     for (int kk = 0; kk < P; kk++)
     {
-        second_neighbours |= (cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_P || cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_p);
+        const bool second = (cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_P || cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_p);
+        second_neighbours |= second;
         has_spatial |= cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M;
+        // (prec0 mean0 = -0: the sign of the reference's 0 x sum would decide the sign of a zero prior mean)
+        const double pm0 = cfg.prior_prec[kk] * cfg.prior_mean[kk];
+        minus_zero |= second && pm0 == 0 && std::signbit(pm0);
     }
-    const long long cy = second_neighbours ? 2 : 1, cz = second_neighbours ? 3 : 1;
+    long long cy = 1, cz = 1;
     const int n_owned = owned_end - owned_begin;
     auto level_of = [&](int i) -> long long {
         const int v = owned_begin + i;
@@ -621,27 +629,31 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         for (auto &th : pool)
             th.join();
     };
-    std::vector<long long> tmin(nt, 0), tmax(nt, 0);
-    parallel([&](int t) {
-        long long lo = 0, hi = 0;
-        for (int i = chunk(t); i < chunk(t + 1); i++)
-        {
-            const long long l = level_of(i);
-            lo = (i == chunk(t) || l < lo) ? l : lo;
-            hi = (i == chunk(t) || l > hi) ? l : hi;
-        }
-        tmin[t] = lo;
-        tmax[t] = hi;
-    });
     long long lmin = 0, lmax = 0;
-    bool first = true;
-    for (int t = 0; t < nt; t++)
-        if (chunk(t + 1) > chunk(t))
-        {
-            lmin = (first || tmin[t] < lmin) ? tmin[t] : lmin;
-            lmax = (first || tmax[t] > lmax) ? tmax[t] : lmax;
-            first = false;
-        }
+    auto scan_levels = [&]() {
+        std::vector<long long> tmin(nt, 0), tmax(nt, 0);
+        parallel([&](int t) {
+            long long lo = 0, hi = 0;
+            for (int i = chunk(t); i < chunk(t + 1); i++)
+            {
+                const long long l = level_of(i);
+                lo = (i == chunk(t) || l < lo) ? l : lo;
+                hi = (i == chunk(t) || l > hi) ? l : hi;
+            }
+            tmin[t] = lo;
+            tmax[t] = hi;
+        });
+        bool first = true;
+        lmin = lmax = 0;
+        for (int t = 0; t < nt; t++)
+            if (chunk(t + 1) > chunk(t))
+            {
+                lmin = (first || tmin[t] < lmin) ? tmin[t] : lmin;
+                lmax = (first || tmax[t] > lmax) ? tmax[t] : lmax;
+                first = false;
+            }
+    };
+    scan_levels();
     // The level order (voxel ids sorted by level) is what the per-level launches walk; the slab form of the split
     // sweep numbers the voxels itself (below) and does without it - 2.5 ms of a 128^3 run's set-up.
     std::vector<int32_t> order(1);
@@ -703,27 +715,17 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             level_begin.push_back(n_owned);
         }
     };
-    // ---- numbering for the split first sweep ----
+    // ---- numbering for the split first sweep: the parameters the ordered part updates are those of types M, m ----
     int n_spatial = 0, spatial_param[FVB_MAX_PARAMS] = { 0 };
     for (int kk = 0; kk < P; kk++)
-        if (cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M)
+        if (cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_M || cfg.prior_type[kk] == FVB_PRIOR_SPATIAL_m)
             spatial_param[n_spatial++] = kk;
     const bool whole = owned_begin == 0 && owned_end == V;
-    const bool eligible = allow_fast && has_spatial && !second_neighbours && (whole || multi_fast) && n_owned > 0
-        && !getenv("FVB_SPATIAL_PER_LEVEL");
+    const bool eligible = allow_fast && has_spatial && !minus_zero && (whole || multi_fast) && n_owned > 0 && !getenv("FVB_SPATIAL_PER_LEVEL");
     std::vector<int32_t> pos_of, level_pos, level_count, slab_first;
-    int n_pos = 0, sl_width = 64, sl_max_run = 0, sl_dz = 0;
+    int n_pos = 0, sl_width = 64, sl_max_run = 0;
     slab_form = false;
-    // (second-neighbour priors: the slab form with the last levels' means in LDS - vb_spatial_slab2_sweep_kernel -, whole
-    // volumes on one device; its runs are numbered on the host and include the EMPTY levels of a slab, so that a
-    // neighbour's run follows from its level)
-    // Not what runs by default (FVB_SPATIAL_SLAB2=1): correct - the bit-for-bit test covers it - but at 128^3 it takes
-    // 34 ms per iteration against the data-flow form's 13: with one plane per slab every level of a slab
-    // waits for the slab below through device-scope memory, and the step itself carries 42 slots per voxel.
-    const bool eligible_slab2 = allow_fast && has_spatial && second_neighbours && whole && !multi_fast && n_owned > 0
-        && !getenv("FVB_SPATIAL_PER_LEVEL") && getenv("FVB_SPATIAL_SLAB2") != nullptr;
-    if ((eligible || eligible_slab2) && !(getenv("FVB_SPATIAL_SWEEP") && !strcmp(getenv("FVB_SPATIAL_SWEEP"), "poll"))
-        && lmax - lmin < (1LL << 22))
+    if (eligible && lmax - lmin < (1LL << 22))
     {
         // Slab-major numbering: a slab = dz z-planes, inside a slab the voxels level by level (index order in a
         // level). dz: as few planes as keep the slabs within the chip's workgroups (every slab is one resident
@@ -733,7 +735,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         // (with the co-ordinates on the device - the usual case - the numbering is three small kernels there; the
         // host does it with its threads otherwise: 3 ms at 128^3 against 0.2)
         // (a slab with ghost planes is numbered on the host: the device kernels number every local voxel)
-        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING") && whole && !second_neighbours;
+        const bool on_dev = d_coords.p != nullptr && !getenv("FVB_SPATIAL_HOST_NUMBERING") && whole;
         int zmin = Z[owned_begin], zmax = Z[owned_begin];
         if (on_dev)
         {
@@ -788,29 +790,10 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 });
             slab_first.assign((size_t)n_slabs + 1, 0);
             int32_t running = 0;
-            // (second neighbours: the last level of each slab that has voxels, so that the empty ones before it get runs)
-            std::vector<size_t> last_key((size_t)n_slabs, 0);
-            std::vector<char> any_key((size_t)n_slabs, 0);
-            if (second_neighbours)
-                for (size_t key = 0; key < nk; key++)
-                {
-                    int32_t n = 0;
-                    for (int t = 0; t < nth; t++)
-                        n += count[t][key];
-                    if (n > 0)
-                    {
-                        last_key[key / nl] = key;
-                        any_key[key / nl] = 1;
-                    }
-                }
-            bool started = false;
             for (size_t key = 0; key < nk; key++)
             {
                 if (key % nl == 0)
-                {
                     slab_first[key / nl] = (int32_t)level_pos.size();
-                    started = false;
-                }
                 const int32_t begin = running;
                 for (int t = 0; t < nth; t++) // thread order = index order
                 {
@@ -818,8 +801,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                     count[t][key] = running;
                     running += n;
                 }
-                started = started || running > begin;
-                if (running > begin || (second_neighbours && started && any_key[key / nl] && key <= last_key[key / nl]))
+                if (running > begin)
                 {
                     level_pos.push_back(begin);
                     level_count.push_back(running - begin);
@@ -827,16 +809,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 }
             }
             slab_first[(size_t)n_slabs] = (int32_t)level_pos.size();
-            int most_runs = 0;
-            for (size_t b = 0; b + 1 < slab_first.size(); b++)
-                most_runs = std::max(most_runs, (int)(slab_first[b + 1] - slab_first[b]));
-            int n_sp = 0;
-            for (int kk = 0; kk < P; kk++)
-                n_sp += cfg.prior_type[kk] >= FVB_PRIOR_SPATIAL_M;
-            // (second neighbours: 8 runs of means and the run table in at most 144 KB of LDS, runs within the 512 lanes)
-            const bool slab2_fits = !second_neighbours
-                || (n_sp <= 2 && sizeof(double) * 8 * (size_t)n_sp * sl_max_run + sizeof(int32_t) * (2 * (size_t)most_runs + 2) <= 144 * 1024 && sl_max_run <= 512);
-            if (sl_max_run <= 8192 && n_slabs <= slab_cap && slab2_fits)
+            if (sl_max_run <= 8192 && n_slabs <= slab_cap)
             {
                 if (on_dev)
                 {
@@ -859,13 +832,12 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
                 }
                 n_pos = (n_owned + 15) / 16 * 16;
                 // lanes per run: the next power of two from 64 that holds the longest run, 1024 at most
-                while (sl_width < sl_max_run && sl_width < (second_neighbours ? 512 : 1024))
+                while (sl_width < sl_max_run && sl_width < 1024)
                     sl_width *= 2;
                 if (const char *forced = getenv("FVB_SPATIAL_SLAB_WIDTH")) // tests: lanes that take several voxels of a run
-                    sl_width = std::max(64, std::min(second_neighbours ? 512 : 1024, atoi(forced) / 64 * 64));
-                if (second_neighbours && 512 % sl_width != 0) // (the 512 lanes are whole groups)
+                    sl_width = std::max(64, std::min(1024, atoi(forced) / 64 * 64));
+                if (1024 % sl_width != 0) // (the 1024 lanes are whole groups)
                     sl_width = 64;
-                sl_dz = (int)dz;
                 slab_form = true;
                 level_begin_counts = level_count;
             }
@@ -878,12 +850,17 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         }
     }
     if (!slab_form)
+    {
+        // the per-level launches: the exact form, with the second-neighbour levels where types P, p are about
+        if (second_neighbours)
+        {
+            cy = 2;
+            cz = 3;
+            scan_levels();
+        }
         build_level_order();
-    // (the data-flow sweep keeps the level table in LDS; it is also what takes the second-neighbour priors, types P and p)
-    const bool eligible2 = allow_fast && has_spatial && second_neighbours && whole && n_owned > 0 && !getenv("FVB_SPATIAL_PER_LEVEL");
-    fast = slab_form || ((eligible || eligible2) && whole && level_begin.size() <= 6000);
-    fast_second = fast && second_neighbours;
-    slab2 = slab_form && second_neighbours;
+    }
+    fast = slab_form;
     if (slab_form && !whole)
     {
         // ghosts have no position: what stands in sw_npos for them says where their mean comes from (vb_spatial.h)
@@ -894,27 +871,6 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     }
     if (multi_fast)
         h_pos_of = pos_of;
-    if (fast && !slab_form)
-    {
-        // level-major numbering for the data-flow sweep
-        // every level starts on a multiple of 16 positions: a wave's 64 consecutive doubles are whole 128-byte lines
-        const size_t nl = level_begin.size() - 1;
-        level_pos.resize(nl);
-        level_count.resize(nl);
-        pos_of.assign((size_t)V, 0);
-        for (size_t l = 0; l < nl; l++)
-        {
-            n_pos = (n_pos + 15) / 16 * 16;
-            level_pos[l] = n_pos;
-            level_count[l] = level_begin[l + 1] - level_begin[l];
-            for (int i = level_begin[l]; i < level_begin[l + 1]; i++)
-                pos_of[(size_t)order[i]] = n_pos + (i - level_begin[l]);
-            n_pos += level_count[l];
-        }
-        n_pos = (n_pos + 15) / 16 * 16;
-        level_begin_counts = level_count;
-    }
-
     t_geometry_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 
     // ---- device memory ----
@@ -986,18 +942,21 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         FVB_HIP_CHECK(d_level_count.alloc(sizeof(int32_t) * level_count.size(), stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_pos.p, level_pos.data(), sizeof(int32_t) * level_pos.size(), hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_count.p, level_count.data(), sizeof(int32_t) * level_count.size(), hipMemcpyHostToDevice, stream));
-        // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; slab form: nbr [ns][6][NP]
-        const bool probe = getenv("FVB_SLAB_DEBUG") && (atoi(getenv("FVB_SLAB_DEBUG")) & 256);
-        const size_t n_f64 = (5 * ns + (size_t)P + ns * (size_t)P + ((slab_form || probe) ? 6 * ns : 0)) * NP;
+        // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; nbr [ns][6][NP]
+        const size_t n_f64 = std::max<size_t>(1, (5 * ns + (ns ? (size_t)P : 0) + ns * (size_t)P + 6 * ns) * NP);
         FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64, stream));
-        const size_t n_i32 = (fast_second ? 43 : 7) * NP;
-        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * n_i32, stream)); // npos [6][NP], alive [NP], types P / p: npos2 [36][NP]
-        FVB_HIP_CHECK(d_sw_sync.alloc(64, stream));                      // counter, flags[2]
+        const size_t n_i32 = 7 * NP;
+        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * n_i32, stream)); // npos [6][NP], alive [NP]
+        FVB_HIP_CHECK(d_sw_sync.alloc(64, stream));                      // flags
+        const size_t gran_bytes = std::max<size_t>(16, sizeof(unsigned long long) * 2 * ns * NP);
         if (multi_fast)
-            FVB_HIP_CHECK(d_sw_gran.alloc_fine(sizeof(unsigned long long) * 2 * ns * NP));
+        {
+            FVB_HIP_CHECK(d_sw_gran.alloc_fine(gran_bytes));
+            gran_fine = d_sw_gran.fine;
+        }
         else
-            FVB_HIP_CHECK(d_sw_gran.alloc(sizeof(unsigned long long) * 2 * ns * NP, stream));
-        FVB_HIP_CHECK(hipMemsetAsync(d_sw_gran.p, 0, sizeof(unsigned long long) * 2 * ns * NP, stream));
+            FVB_HIP_CHECK(d_sw_gran.alloc(gran_bytes, stream));
+        FVB_HIP_CHECK(hipMemsetAsync(d_sw_gran.p, 0, gran_bytes, stream));
         sa.sl_remote = multi_fast ? 1 : 0;
         sa.sw_gran = (unsigned long long *)d_sw_gran.p;
         sa.sw_serial = 0;
@@ -1011,45 +970,19 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sw_q = f + 3 * ns * NP;
         sa.sw_rec = f + 4 * ns * NP;
         sa.sw_rhs0 = f + 5 * ns * NP;
-        sa.sw_sig = f + (5 * ns + (size_t)P) * NP;
-        if (probe)
-        {
-            sa.sw_nbr = f + (5 * ns + (size_t)P + ns * (size_t)P) * NP;
-            sa.sl_debug = atoi(getenv("FVB_SLAB_DEBUG"));
-        }
-        if (slab_form)
-        {
-            sa.sw_nbr = f + (5 * ns + (size_t)P + ns * (size_t)P) * NP;
-            FVB_HIP_CHECK(d_slab_first.alloc(sizeof(int32_t) * slab_first.size(), stream));
-            FVB_HIP_CHECK(hipMemcpyAsync(d_slab_first.p, slab_first.data(), sizeof(int32_t) * slab_first.size(), hipMemcpyHostToDevice, stream));
-            sa.sl_mode = second_neighbours ? 2 : 1;
-            sa.n_slabs = (int32_t)slab_first.size() - 1;
-            sa.sl_first_run = (const int32_t *)d_slab_first.p;
-            sa.sl_width = sl_width;
-            sa.sl_max_run = sl_max_run;
-            sa.sl_debug = getenv("FVB_SLAB_DEBUG") ? atoi(getenv("FVB_SLAB_DEBUG")) : 0;
-            max_runs_per_slab = 0;
-            for (size_t b = 0; b + 1 < slab_first.size(); b++)
-                max_runs_per_slab = std::max(max_runs_per_slab, (int)(slab_first[b + 1] - slab_first[b]));
-        }
+        sa.sw_sig = f + (5 * ns + (ns ? (size_t)P : 0)) * NP;
+        sa.sw_nbr = f + (5 * ns + (ns ? (size_t)P : 0) + ns * (size_t)P) * NP;
+        FVB_HIP_CHECK(d_slab_first.alloc(sizeof(int32_t) * slab_first.size(), stream));
+        FVB_HIP_CHECK(hipMemcpyAsync(d_slab_first.p, slab_first.data(), sizeof(int32_t) * slab_first.size(), hipMemcpyHostToDevice, stream));
+        sa.n_slabs = (int32_t)slab_first.size() - 1;
+        sa.sl_first_run = (const int32_t *)d_slab_first.p;
+        sa.sl_width = sl_width;
+        sa.sl_max_run = sl_max_run;
+        max_runs_per_slab = 0;
+        for (size_t b = 0; b + 1 < slab_first.size(); b++)
+            max_runs_per_slab = std::max(max_runs_per_slab, (int)(slab_first[b + 1] - slab_first[b]));
         sa.sw_npos = (int32_t *)d_sw_i32.p;
         sa.sw_alive = (int32_t *)d_sw_i32.p + 6 * NP;
-        sa.sw_npos2 = fast_second ? (int32_t *)d_sw_i32.p + 7 * NP : nullptr;
-        if (fast_second)
-        {
-            if (d_coords.p) // (left by the neighbour table's kernels)
-            {
-                std::swap(d_xyz.p, d_coords.p);
-                std::swap(d_xyz.stream, d_coords.stream);
-            }
-            else
-            {
-                FVB_HIP_CHECK(d_xyz.alloc(sizeof(int32_t) * 3 * (size_t)V, stream));
-                FVB_HIP_CHECK(hipMemcpyAsync(d_xyz.p, sp.coords, sizeof(int32_t) * 3 * (size_t)V, hipMemcpyHostToDevice, stream));
-            }
-            sa.xyz = (const int32_t *)d_xyz.p;
-        }
-        sa.sw_counter = (uint32_t *)d_sw_sync.p;
         sa.sw_flags = (int32_t *)d_sw_sync.p + 4;
         sa.pos_of = (const int32_t *)d_pos_of.p;
         sa.n_pos = n_pos;
@@ -1153,17 +1086,10 @@ int fvb_spatial_run::fast_prep(int it)
 }
 int fvb_spatial_run::fast_sweep()
 {
+    if (sa.n_spatial == 0) // (types P, p only: nothing waits for a neighbour)
+        return 0;
     const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
     // one workgroup of 1024 lanes per slab (within the device's compute units, see the numbering)
-    if (slab2) // second neighbours: 512 lanes, the last 8 runs' means in LDS
-    {
-        const size_t lds2 = sizeof(double) * 8 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
-        if (lds2 > 48 * 1024)
-            FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep2[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k.slab_sweep2[which], dim3((unsigned)sa.n_slabs), dim3(512), lds2, stream, sa);
-        FVB_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
     const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
     if (lds > 48 * 1024)
         FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1210,68 +1136,12 @@ int fvb_spatial_run::link_up(fvb_spatial_run &upper, int global_first, int upper
     return 0;
 }
 
-// probe of the second-neighbour sweeps (FVB_SLAB_DEBUG & 256): what the first sweep summed for every voxel, by voxel
-static int dump_probe(fvb_spatial_run &run, hipStream_t stream);
-
 int fvb_spatial_run::sweep_fast(int it)
 {
-    struct AtExit
-    {
-        fvb_spatial_run &r;
-        int it;
-        ~AtExit()
-        {
-            if (it == 0 && (r.sa.sl_debug & 256))
-                (void)dump_probe(r, r.stream);
-        }
-    } at_exit{ *this, it };
-    if (slab_form)
-    {
-        int rc = fast_prep(it);
-        if (rc == 0)
-            rc = fast_sweep();
-        return rc ? rc : fast_noise(it);
-    }
-    sa.it = it;
-    sa.sw_serial++; // this sweep's number
-    const int n_owned = owned_end - owned_begin;
-    hipLaunchKernelGGL(k.prep, dim3((unsigned)(((n_owned + 63) / 64 + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
-    // few workgroups, all resident at once on any MI355X (256 CUs): the level barrier is a counter
-    const int max_level = *std::max_element(level_begin_counts.begin(), level_begin_counts.end());
-    const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
-    int wg_cap = 64;
-    if (const char *forced = getenv("FVB_SPATIAL_SWEEP_WGS")) // tests: levels with more voxels than the launch has lanes
-        wg_cap = std::max(1, std::min(64, atoi(forced)));
-    if (fast_second) // one voxel per lane, one wave per workgroup, as many workgroups as the longest level needs (all resident)
-    {
-        const int wgs = getenv("FVB_SPATIAL_SWEEP_WGS") ? wg_cap : 256;
-        hipLaunchKernelGGL(k.sweep2[which], dim3((unsigned)std::max(1, std::min(wgs, (max_level + 63) / 64))), dim3(64),
-            2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
-    }
-    else
-    {
-        const unsigned nwg = (unsigned)std::max(1, std::min(wg_cap, (max_level + 511) / 512)); // two voxels per lane
-        hipLaunchKernelGGL(k.sweep[which], dim3(nwg), dim3(256), 2 * sizeof(int32_t) * (size_t)sa.n_levels, stream, sa);
-    }
-    hipLaunchKernelGGL(second_sweep(true, it), dim3((unsigned)((n_owned + 63) / 64)), dim3(64), noise_lds, stream, sa);
-    FVB_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-static int dump_probe(fvb_spatial_run &run, hipStream_t stream)
-{
-    const size_t NP = (size_t)run.sa.n_pos;
-    const int V = run.V;
-    std::vector<double> h(6 * NP);
-    std::vector<int32_t> pos((size_t)V);
-    FVB_HIP_CHECK(hipStreamSynchronize(stream));
-    FVB_HIP_CHECK(hipMemcpy(h.data(), run.sa.sw_nbr, sizeof(double) * 6 * NP, hipMemcpyDeviceToHost));
-    FVB_HIP_CHECK(hipMemcpy(pos.data(), run.sa.pos_of, sizeof(int32_t) * (size_t)V, hipMemcpyDeviceToHost));
-    for (int v = 0; v < V && v < 64; v++)
-        fprintf(stderr, "[probe] v %d pos %d contrib %.17g contrib2 %.17g pm %.17g m %.17g q %.17g pprec %.17g\n", v, pos[(size_t)v],
-            h[0 * NP + pos[(size_t)v]], h[1 * NP + pos[(size_t)v]], h[2 * NP + pos[(size_t)v]], h[3 * NP + pos[(size_t)v]], h[4 * NP + pos[(size_t)v]],
-            h[5 * NP + pos[(size_t)v]]);
-    return 0;
+    int rc = fast_prep(it);
+    if (rc == 0)
+        rc = fast_sweep();
+    return rc ? rc : fast_noise(it);
 }
 
 int fvb_spatial_run::fast_failed(bool &failed)
@@ -1283,12 +1153,6 @@ int fvb_spatial_run::fast_failed(bool &failed)
     FVB_HIP_CHECK(hipMemcpyAsync(&flag, sa.sw_flags, sizeof(flag), hipMemcpyDeviceToHost, stream));
     FVB_HIP_CHECK(hipStreamSynchronize(stream));
     failed = flag != 0;
-    if (getenv("FVB_SWEEP_STATS"))
-    {
-        unsigned long long st[2] = { 0, 0 };
-        FVB_HIP_CHECK(hipMemcpy(st, sa.sw_flags + 4, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[fvb spatial] sweep statistics: %llu poll attempts by all lanes, %.3f ms inside the steps (lane 0, all sweeps)\n", st[0], st[1] / 1e5);
-    }
     return 0;
 }
 
@@ -1866,15 +1730,26 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
         second |= (cfg->prior_type[k] == FVB_PRIOR_SPATIAL_P || cfg->prior_type[k] == FVB_PRIOR_SPATIAL_p);
         has_spatial |= cfg->prior_type[k] >= FVB_PRIOR_SPATIAL_M;
     }
-    const int halo = second ? 2 : 1;
     const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
     };
-    // all slabs sweep together with the slab form of the split sweep (first-neighbour priors; vb_spatial.h) unless
-    // that was tried and abandoned (s_multi_no_fast) or FVB_SPATIAL_PER_LEVEL asks for the level-chunk pipeline
-    const bool try_fast = has_spatial && !second && !s_multi_no_fast && !getenv("FVB_SPATIAL_PER_LEVEL") && !getenv("FVB_SPATIAL_MULTI_PIPELINE");
+    // all slabs sweep together with the slab form of the split sweep (vb_spatial.h) unless that was tried and abandoned
+    // (s_multi_no_fast), the devices cannot reach each other's memory, or FVB_SPATIAL_PER_LEVEL asks for the
+    // level-chunk pipeline
+    bool peers = true;
+    for (size_t r = 0; r + 1 < devs.size() && peers; r++)
+        if (devs[r] != devs[r + 1])
+        {
+            int can = 0;
+            peers = hipDeviceCanAccessPeer(&can, devs[r], devs[r + 1]) == hipSuccess && can != 0;
+            (void)hipGetLastError();
+        }
+    const bool try_fast = has_spatial && peers && !s_multi_no_fast && !getenv("FVB_SPATIAL_PER_LEVEL") && !getenv("FVB_SPATIAL_MULTI_PIPELINE");
+    // ghost planes: the split form reads first neighbours only (types P, p are local there, and their a_K sums are
+    // over first neighbours, priors.cc:280-301); the level-chunk pipeline's per-level kernel sums second neighbours
+    const int halo = (second && !try_fast) ? 2 : 1;
     // ---- the slabs: cuts on z-plane boundaries, balanced by voxel count; fewer slabs if the planes do not go round ----
     std::vector<int> plane_start;
     for (int v = 0; v < V; v++)
@@ -2041,7 +1916,12 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
     // ---- all slabs sweep together: every slab's top plane writes into the inboxes of the slab above ----
     bool all_fast = try_fast;
     for (int r = 0; r < world; r++)
+    {
         all_fast = all_fast && slabs[r]->run->slab_form;
+        // (an inbox another DEVICE writes into must be fine-grained memory, or its stores may stay invisible to the polls)
+        if (r > 0 && slabs[r]->dev != slabs[r - 1]->dev)
+            all_fast = all_fast && slabs[r]->run->gran_fine;
+    }
     if (try_fast && !all_fast) // (a slab the slab form does not take: the level-chunk pipeline for the whole run)
     {
         slabs.clear();
@@ -2058,9 +1938,18 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
             if (slabs[r]->dev != slabs[r + 1]->dev)
             {
                 hipError_t e = hipDeviceEnablePeerAccess(slabs[r + 1]->dev, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                    return api_fail(-100 - (int)e, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
                 (void)hipGetLastError();
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                {
+                    // (hipDeviceCanAccessPeer said yes: all the same, the pipeline needs no peer mapping)
+                    if (getenv("FVB_SPATIAL_VERBOSE"))
+                        fprintf(stderr, "[fvb spatial] hipDeviceEnablePeerAccess(%d -> %d): %s - level-chunk pipeline\n", slabs[r]->dev, slabs[r + 1]->dev, hipGetErrorString(e));
+                    slabs.clear();
+                    s_multi_no_fast = true;
+                    rc = fabber_vb_run_spatial_host_multi(cfg, sp, data, out, devices, n_devices, progress_cb);
+                    s_multi_no_fast = false;
+                    return rc;
+                }
             }
             if ((rc = slabs[r]->run->link_up(*slabs[r + 1]->run, slabs[r]->g0, slabs[r + 1]->g0)) != 0)
                 return rc;

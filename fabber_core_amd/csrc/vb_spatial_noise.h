@@ -671,20 +671,11 @@ SpatialKernels spatial_nz_table(bool need_f, const char *name)
     k.state_rows = SpLayout<PP>::ROWS + NZ::EXTRA_ROWS;
     k.name = name;
     k.prep = need_f ? (SpatialPrepFn)vb_spatial_prep_kernel<PP, true, NZ> : (SpatialPrepFn)vb_spatial_prep_kernel<PP, false>;
-    k.sweep[0] = vb_spatial_sweep_kernel<PP, 1>;
-    k.sweep[1] = vb_spatial_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
-    k.sweep[2] = vb_spatial_sweep_kernel<PP, PP>;
     k.noise_fast = need_f ? (SpatialKernelFn)vb_spatial_noise_nz_kernel<MODEL<PP>, PP, true, true, NZ>
                           : (SpatialKernelFn)vb_spatial_noise_nz_kernel<MODEL<PP>, PP, false, true, NZ>;
     k.slab_sweep[0] = vb_spatial_slab_sweep_kernel<PP, 1>;
     k.slab_sweep[1] = vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
     k.slab_sweep[2] = vb_spatial_slab_sweep_kernel<PP, PP>;
-    k.sweep2[0] = vb_spatial_sweep2_kernel<PP, 1>;
-    k.sweep2[1] = vb_spatial_sweep2_kernel<PP, (PP < 2 ? PP : 2)>;
-    k.sweep2[2] = vb_spatial_sweep2_kernel<PP, PP>;
-    k.slab_sweep2[0] = vb_spatial_slab2_sweep_kernel<PP, 1>;
-    k.slab_sweep2[1] = vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
-    k.slab_sweep2[2] = vb_spatial_slab2_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
     k.lds_classes = NZ::LDS_CLASSES ? 1 : 0;
     return k;
 }

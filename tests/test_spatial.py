@@ -469,11 +469,11 @@ def test_level_order_built_by_several_host_threads_is_the_same(monkeypatch):
 @pytest.mark.parametrize("case", ["M exp", "m exp masked", "two spatial + ARD + F", "M + image prior, dims 2, speed", "failing voxel with F",
                                   "NaN cascade without F"])
 def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch):
-    """Whole-volume runs with first-neighbour priors (types M, m) take the split first sweep (vb_spatial.h:
-    one parallel launch for everything that does not wait for a neighbour, ONE persistent launch that walks
-    the levels for the spatial parameters' means, the rest inside the second sweep's kernel); the per-level
-    launches stay for types P / p, for slabs, and as the fallback when a voxel fails during a sweep.
-    Both evaluate eq (19)-(20) with the same operation sequence: every output must be identical."""
+    """Whole-volume runs take the split first sweep (vb_spatial.h: one parallel launch for everything that does not
+    wait for a neighbour, ONE persistent launch that walks the levels for the means of the parameters with a
+    first-neighbour prior, the rest inside the second sweep's kernel); the per-level launches stay for
+    host-evaluated models, for the level-chunk pipeline of several slabs, and as the fallback when a voxel fails
+    during a sweep. Both evaluate eq (19)-(20) with the same operation sequence: every output must be identical."""
     rng = np.random.default_rng(41)
     sp_kw = {}
     if case == "M exp":
@@ -506,11 +506,11 @@ def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch)
         h, sp0, y, bad = failing_voxel_problem("M", need_f=False)
         coords = sp0.coords
     sp = vbabi.SpatialHolder(coords, **sp_kw)
-    # the forms of the ordered part: workgroups that own z-slabs of 1 / 2 / 3 planes (previous level in LDS, inbox
-    # hand-over between slabs; the default picks the thickness from the volume) and the data-flow sweep of round 2
+    # the ordered part: workgroups that own z-slabs of 1 / 2 / 3 planes (previous level in LDS, inbox hand-over
+    # between slabs; the default picks the thickness from the volume)
     forms = {}
     for name, env in (("default", {}), ("slabs of 1", {"FVB_SPATIAL_SLAB_DZ": "1"}), ("slabs of 2", {"FVB_SPATIAL_SLAB_DZ": "2"}),
-                      ("slabs of 3", {"FVB_SPATIAL_SLAB_DZ": "3"}), ("data-flow", {"FVB_SPATIAL_SWEEP": "poll"}),
+                      ("slabs of 3", {"FVB_SPATIAL_SLAB_DZ": "3"}),
                       ("slab numbering on the host", {"FVB_SPATIAL_HOST_NUMBERING": "1"}),
                       ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"})):
         for k, v in env.items():
@@ -527,13 +527,14 @@ def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch)
 
 @gpu
 @pytest.mark.parametrize("case", ["P exp", "p exp masked", "P + M + ARD + F", "p, dims 2, speed", "failing voxel with F", "NaN cascade without F",
-                                  "more voxels in a level than lanes"])
-def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch):
-    """Types P and p (priors.cc:377-385, 441-482: the prior mean also reads the neighbours' neighbours) take the split
-    first sweep too: the data-flow form with level = x + 2y + 3z, every voxel polling its 6 first and up to 30 listed
-    second neighbours (vb_spatial_sweep2_kernel). Same operation sequence as the per-level launches: identical output,
-    including next to first-neighbour priors in the same run, masked volumes (lists that reach across a missing voxel)
-    and the fallback when a voxel fails during a sweep."""
+                                  "P and p, nothing to sweep", "minus zero"])
+def test_second_neighbour_types_in_the_split_form_are_the_per_level_sweep_bit_for_bit(case, monkeypatch):
+    """Types P and p as the reference codes them (priors.cc:455: the MRF mean is 0 x a sum) read no neighbour's VALUE:
+    the split form takes their prior mean as pcov x prec0 mean0 in the prep kernel and sweeps only the parameters of
+    types M / m (none: no ordered launch at all). The per-level kernel evaluates the reference's expression as it
+    stands - second-neighbour sums, levels x + 2y + 3z, NaN where a listed mean is not finite. Identical output,
+    including the runs the split form hands back (a voxel failing during a sweep; a non-finite mean next to such a
+    prior, which the reference spreads to first and second neighbours in voxel order)."""
     rng = np.random.default_rng(43)
     sp_kw = {}
     if case == "P exp":
@@ -544,7 +545,7 @@ def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, m
         mask, coords = masked_volume((12, 10, 8), seed=33, keep=0.8)
         _, y = smooth_exp_data(coords, 40, 0.04, seed=34)
         h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 40, num_exps=1, dt=0.04, max_iterations=6, param_overrides={"r1": dict(type="p")})
-    elif case in ("P + M + ARD + F", "p, dims 2, speed"):
+    elif case in ("P + M + ARD + F", "p, dims 2, speed", "P and p, nothing to sweep", "minus zero"):
         mask, coords = masked_volume((10, 8, 6), seed=5)
         V = coords.shape[1]
         t = np.arange(1, 21.0)
@@ -554,30 +555,25 @@ def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, m
             h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6, need_f=True,
                                    param_overrides={"c0": dict(type="P"), "c1": dict(type="A"), "c2": dict(type="M")})
             sp_kw = dict(update_first_iter=True)
+        elif case.startswith("P and p"):
+            h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6, need_f=True,
+                                   param_overrides={"c0": dict(type="P", mean=1.5, prec=0.01), "c2": dict(type="p", mean=0.02, prec=3.0)})
+        elif case == "minus zero":
+            # prec0 x mean0 = -0: the sign of the reference's zero decides the sign of a zero prior mean - per-level launches
+            h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=4, param_overrides={"c0": dict(type="P", mean=-0.0)})
         else:
             h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=2, max_iterations=6, param_overrides={"c0": dict(type="p")})
             sp_kw = dict(spatial_dims=2, spatial_speed=1.5, q1=5.0, q2=2.0)
     elif case == "failing voxel with F":
         h, sp0, y, bad = failing_voxel_problem("P")
         coords = sp0.coords
-    elif case == "NaN cascade without F":
+    else:
         h, sp0, y, bad = failing_voxel_problem("P", need_f=False)
         coords = sp0.coords
-    else:
-        # one workgroup (256 lanes) for levels of up to ~280 voxels: the rest of a level is taken in turns
-        monkeypatch.setenv("FVB_SPATIAL_SWEEP_WGS", "1")
-        mask, coords = masked_volume((560, 290, 1), seed=35, keep=0.97)
-        _, y = smooth_exp_data(coords, 20, 0.04, seed=36)
-        h = vbabi.build_config(vbabi.MODEL_EXP, coords.shape[1], 20, num_exps=1, dt=0.04, max_iterations=3, param_overrides={"amp1": dict(type="P")})
     sp = vbabi.SpatialHolder(coords, **sp_kw)
-    # the forms of the ordered part: the data-flow form (what runs) and the slab form with the last levels' means in LDS
-    # (FVB_SPATIAL_SLAB2=1: correct, slower at volume size) with slabs of 1 / 2 / 3 planes and one slab
     forms = {}
-    for name, env in (("default", {}), ("data-flow (poll)", {"FVB_SPATIAL_SWEEP": "poll"}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"}),
-                      ("slab form", {"FVB_SPATIAL_SLAB2": "1"}), ("slab form, geometry on the host", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_HOST_GEOMETRY": "1"}),
-                      ("slab form, 2 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "2"}),
-                      ("slab form, 3 planes", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "3"}),
-                      ("slab form, one slab", {"FVB_SPATIAL_SLAB2": "1", "FVB_SPATIAL_SLAB_DZ": "100"})):
+    for name, env in (("default", {}), ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"}), ("slabs of 2", {"FVB_SPATIAL_SLAB_DZ": "2"}),
+                      ("slab numbering on the host", {"FVB_SPATIAL_HOST_NUMBERING": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         forms[name] = hiplib.run_spatial_host(h, sp, y)
@@ -588,6 +584,13 @@ def test_second_neighbour_split_sweep_is_the_per_level_sweep_bit_for_bit(case, m
     for name, split in forms.items():
         for k in ("mvn", "status", "iterations", "free_energy"):
             assert np.array_equal(split[k], per_level[k], equal_nan=True), (case, name, k)
+    if case == "NaN cascade without F":
+        # (the reference's cascade: more voxels than the three with a bad sample end up ignored)
+        assert set(bad) < set(np.flatnonzero(per_level["status"]).tolist())
+    monkeypatch.delenv("FVB_SPATIAL_PER_LEVEL")
+    cpu = oracle.run_spatial(h, sp, y)
+    cpu.setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
+    parity.strict(h, cpu, forms["default"], what="P/p as coded: " + case, cpu2=oracle.run_spatial_fma(h, sp, y), check_f=bool(h.cfg.need_f), allow_floor=True)
 
 
 @gpu

@@ -1,11 +1,10 @@
 #!/bin/bash
-# per-kernel times of the C5 bench for several settings of the spatial sweep: "dz[:debug]" or "poll"
+# per-kernel times of the C5 bench for several slab thicknesses of the spatial sweep
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-for cfg in ${CFGS:-1 2 4 poll}; do
-  unset FVB_SPATIAL_SWEEP FVB_SLAB_DEBUG FVB_SPATIAL_SLAB_DZ
-  if [ "$cfg" = poll ]; then export FVB_SPATIAL_SWEEP=poll; else export FVB_SPATIAL_SLAB_DZ=${cfg%%:*}; case $cfg in *:*) export FVB_SLAB_DEBUG=${cfg##*:};; esac; fi
-  OUT=$ROOT/gpurun_out/c5prof_${cfg/:/_}
+for cfg in ${CFGS:-1 2 4}; do
+  export FVB_SPATIAL_SLAB_DZ=$cfg
+  OUT=$ROOT/gpurun_out/c5prof_$cfg
   rm -rf $OUT
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --workload c5 --cpu-sample 0 --steps 3 > $OUT.log 2>&1 < /dev/null
   f=$(find $OUT -name "*kernel_stats.csv" | head -1)

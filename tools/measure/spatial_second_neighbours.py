@@ -1,5 +1,6 @@
-"""Types P / p (second-neighbour priors) at C5's size: the split first sweep (one launch: the data-flow form
-vb_spatial_sweep2_kernel, or with FVB_SPATIAL_SLAB2=1 its slab form vb_spatial_slab2_sweep_kernel) against the per-level launches it replaces - the same problem, results compared.
+"""Types P / p at C5's size. As the reference codes them (priors.cc:455, integer division) their prior mean reads no
+neighbour's value: the split form has no ordered launch for them (prep + second sweep) - against the per-level launches,
+which evaluate the reference's expression as it stands. The same problem, results compared.
 
     python tools/measure/spatial_second_neighbours.py [n=128] [iterations=10] [type=P]
 """
@@ -14,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 its = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 typ = sys.argv[3] if len(sys.argv) > 3 else "P"
 res = {}
-for label, env in (("one data-flow launch per iteration", {}), ("one slab-sweep launch per iteration", {"FVB_SPATIAL_SLAB2": "1"}), ("one launch per level", {"FVB_SPATIAL_PER_LEVEL": "1"})):
+for label, env in (("split form (prep + second sweep)", {}), ("one launch per level", {"FVB_SPATIAL_PER_LEVEL": "1"})):
     os.environ.update(env)
     t = {}
     for k in (2, its):  # (two runs of different length: the difference is the iterations alone)
