@@ -131,7 +131,8 @@ def bench_spatial(args, world, rank, device):
     from fabber_core_amd.device import DeviceProblem
     w = WORKLOADS["c5"]
     n = args.grid or w["grid"]
-    holder, coords, y, _ = cases.c5_problem((n, n, n), max_iterations=w["its"], need_f=bool(args.need_f))
+    extra = {} if args.prior_type == "M" else {"param_overrides": {"amp1": dict(type=args.prior_type)}}
+    holder, coords, y, _ = cases.c5_problem((n, n, n), max_iterations=w["its"], need_f=bool(args.need_f), **extra)
     V, T, P = holder.cfg.n_voxels, w["T"], holder.cfg.n_params
     sp = vbabi.SpatialHolder(coords)
     prob = DeviceProblem(holder, y, device)
@@ -159,7 +160,7 @@ def bench_spatial(args, world, rank, device):
     # HBM bytes of one run from the committed counter passes of this very command (tools/r3_profiles.sh ->
     # tools/pmc_c5_merge.py): attached when the profile is of the same problem
     pmc = os.path.join(ROOT, "profiles", "r3_pmc_c5.json")
-    if os.path.exists(pmc) and n == w["grid"] and not args.need_f:
+    if os.path.exists(pmc) and n == w["grid"] and not args.need_f and args.prior_type == "M":
         prof = json.load(open(pmc))
         roofline["traffic"] = prof["per_run"]["traffic"]
         roofline["traffic_detail"] = {"source": "profiles/r3_pmc_c5.json", "fetch_bytes": prof["per_run"]["fetch_bytes"],
@@ -174,7 +175,7 @@ def bench_spatial(args, world, rank, device):
         import parity
         m = min(32, n)
         keep = np.flatnonzero((coords[0] < m) & (coords[1] < m) & (coords[2] < m))
-        hs, _, _, _ = cases.c5_problem((m, m, m), max_iterations=w["its"], need_f=bool(args.need_f))  # (config only)
+        hs, _, _, _ = cases.c5_problem((m, m, m), max_iterations=w["its"], need_f=bool(args.need_f), **extra)  # (config only)
         ys = np.ascontiguousarray(y[:, keep])
         sps = vbabi.SpatialHolder(np.ascontiguousarray(coords[:, keep]))
         c0 = time.perf_counter()
@@ -194,7 +195,7 @@ def bench_spatial(args, world, rank, device):
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
               "config": {"workload": w["desc"], "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
-                         "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32",
+                         "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32", "spatial_prior_type": args.prior_type,
                          "bad_voxels": int(np.count_nonzero(got["status"])), "ms_per_iteration": dev_ms / w["its"]},
               "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(result), flush=True)
@@ -366,6 +367,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--voxels", type=int, default=None, help="voxels per GPU (default: the workload's)")
     ap.add_argument("--grid", type=int, default=None, help="c5: side of the cubic volume (default 128)")
+    ap.add_argument("--prior-type", default="M", choices=["M", "m", "P", "p"], help="c5: the spatial prior on amp1 (BASELINE config 5: M)")
     ap.add_argument("--need-f", action="store_true", help="also evaluate the free energy 4x per iteration (CLI default of the reference)")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="voxels timed on the CPU oracle (0 = skip)")
     ap.add_argument("--variant", default="auto", choices=["auto", "lane", "wave"])
