@@ -536,13 +536,13 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
             {
                 FVB_HIP_CHECK(api_pool_alloc(&tiles, Tile<double>::bytes(V, T), stream));
                 hipLaunchKernelGGL(retile_series<double>, dim3(rgrid), dim3(256), 0, stream, (const double *)data, (double *)tiles, V, T);
-                fn = lk.fn_tiles_f64;
+                fn = (cfg->convergence == FVB_CONV_MAXITS && lk.fn_tiles_f64_counting) ? lk.fn_tiles_f64_counting : lk.fn_tiles_f64;
             }
             else
             {
                 FVB_HIP_CHECK(api_pool_alloc(&tiles, Tile<float>::bytes(V, T), stream));
                 hipLaunchKernelGGL(retile_series<float>, dim3(rgrid), dim3(256), 0, stream, (const float *)data, (float *)tiles, V, T);
-                fn = lk.fn_tiles_f32;
+                fn = (cfg->convergence == FVB_CONV_MAXITS && lk.fn_tiles_f32_counting) ? lk.fn_tiles_f32_counting : lk.fn_tiles_f32;
             }
             FVB_HIP_CHECK(hipGetLastError());
             ka.tiles = tiles;

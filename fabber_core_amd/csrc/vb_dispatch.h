@@ -17,6 +17,9 @@ struct LaneKernelInfo
     // the same loop fed from the tiled series (vb_lane_kernel.h), float / double elements - what runs unless
     // timepoints are masked
     LaneKernelFn fn_tiles_f32, fn_tiles_f64;
+    // the tile-fed kernels of a run whose detector only counts iterations (convergence = maxits: the reference's
+    // default) - F evaluated, nothing watching it; NULL: take the ones above
+    LaneKernelFn fn_tiles_f32_counting = nullptr, fn_tiles_f64_counting = nullptr;
 };
 
 // Each returns {NULL,0,NULL} when (P, need_f) has no instantiation; the caller then falls back to
@@ -52,7 +55,9 @@ LaneKernelInfo get_lane_pattern_kernel_exp_4(int P);
         if (need_f)                                                                                          \
             return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, true, FEED_STRIDED>, lane_save_rows<PP>(),  \
                 "lane<" TAG "," #PP ",F>", vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F32>,              \
-                vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F64> };                                       \
+                vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F64>,                                         \
+                vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F32, false>,                                  \
+                vb_lane_kernel<MODEL<PP>, PP, true, FEED_TILES_F64, false> };                                \
         return LaneKernelInfo{ vb_lane_kernel<MODEL<PP>, PP, false, FEED_STRIDED>, lane_save_rows<PP>(),     \
             "lane<" TAG "," #PP ">", vb_lane_kernel<MODEL<PP>, PP, false, FEED_TILES_F32>,                   \
             vb_lane_kernel<MODEL<PP>, PP, false, FEED_TILES_F64> };

@@ -559,20 +559,19 @@ __device__ __forceinline__ bool apply_priors(const KernelArgs &ka, int v, int it
     {
         const int type = ka.cfg.prior_type[k];
         double fk = 0;
+        // (the new prior goes through two locals and ONE pair of stores: stores in the branches are merged by the
+        // compiler into a store through a pointer phi, which keeps st.pm / st.pprec in scratch memory)
+        double pm_k, pprec_k;
         if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
             const double post_mean = st.m[k];
             const double post_cov = st.Sig[tri(k, k)];
             const double new_cov = post_mean * post_mean + post_cov;
-            if (it == 0)
-            {
-                st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
-                st.pm[k] = ka.cfg.prior_mean[k];
-            }
-            else
-            {
-                st.pprec[k] = 1.0 / new_cov;
-            }
+            pprec_k = 1.0 / ((it == 0) ? ka.cfg.prior_var[k] : new_cov);
+            // priors.cc:166 sets the mean in iteration 0 and leaves it alone afterwards: it IS the configured mean in
+            // every iteration (nothing else writes the prior's mean; written unconditionally because `it == 0 ? load :
+            // old` becomes a load through a selected POINTER, which keeps the array in scratch memory as well)
+            pm_k = ka.cfg.prior_mean[k];
             if (NEEDF)
             {
                 const double bb = 2 / new_cov;
@@ -581,14 +580,16 @@ __device__ __forceinline__ bool apply_priors(const KernelArgs &ka, int v, int it
         }
         else if (type == FVB_PRIOR_IMAGE) // priors.cc:133-142
         {
-            st.pm[k] = ka.cfg.image_prior[k][v];
-            st.pprec[k] = ka.cfg.prior_prec[k];
+            pm_k = ka.cfg.image_prior[k][v];
+            pprec_k = ka.cfg.prior_prec[k];
         }
         else // priors.cc:108-117
         {
-            st.pm[k] = ka.cfg.prior_mean[k];
-            st.pprec[k] = ka.cfg.prior_prec[k];
+            pm_k = ka.cfg.prior_mean[k];
+            pprec_k = ka.cfg.prior_prec[k];
         }
+        st.pm[k] = pm_k;
+        st.pprec[k] = pprec_k;
         Fprior = fk;
     }
     return ok;
@@ -1186,35 +1187,77 @@ __device__ __forceinline__ void restore_posterior(const KernelArgs &ka, int v, V
     st.precValid = false;
 }
 
-// calc_free_energy for a loop that evaluates F four times per iteration (inference_vb.cc:468-495): the
-// same sum with the pieces that do not change between two evaluations kept - the noise terms depend on
-// (b, c) only (b changes once per iteration, c after the first noise update never: its lgamma and digamma
-// are kept separately), the prior's log-determinant on the prior precisions only (re-applied once per
-// iteration), lgamma(c0) and log(b0) are constants of the run. fp64 lgamma (seven divisions), digamma
-// and the logarithms are ~1000 of the ~1200 instructions of one evaluation. The terms are added in a
-// different order than noisemodel_white.cc:365-454 does (differences of a few ulp of the largest term).
+// The free energy in the voxel loop. Vb::DoCalculationsVoxelwise calls CalculateF four times per iteration
+// ("before", "theta", "phi", "lin": inference_vb.cc:468,477,485,495), but only the "lin" value is ever READ - by the
+// convergence detector, the history and the result (:496-500,552). The other three are observable in two ways only:
+// a non-finite value throws and stops the voxel there (noisemodel_white.cc:445-451), and when a later step of the
+// same iteration throws, the local F - the last value that was computed - is what the voxel reports (:552,567).
+// So the kernel evaluates F IN FULL once per iteration, at "lin". At the other three sites it forms the part without
+// a logarithm in it,
+//     partial = -(1/2 log|Lambda| - P/2 (log 2 pi + 1)) - 1/2 (m - mu0)' Lambda0 (m - mu0) - 1/2 tr(Sigma Lambda0)
+//               - 1/2 b c k'Qk - 1/2 tr(Sigma J'QJ) - (n + P)/2 log 2 pi,
+// checks that it and the arguments of the remaining terms are finite (b, c > 0 and finite, prior precisions finite
+// and non-zero: exactly when lgamma(c), digamma(c), log b, log|Lambda0| are), and keeps it as `pending`; a voxel that
+// fails later in the iteration completes the pending site's F after the loop (free_energy_rest: the cold path).
+// The terms are added in a different order than noisemodel_white.cc:365-454 does (a few ulp of the largest term).
 template <int P>
-struct FreeEnergyCache
+struct FreeEnergyConsts
 {
-    double b, c;         // the noise posterior the noise terms were computed for (NaN: none yet)
-    double c_fn;         // the shape lgamma / digamma were computed for
-    double lgamma_c, digamma_c;
-    double noise_terms;
-    double prior_const;  // -lgamma(c0) - c0 log(b0)
-    double prior_logdet; // 1/2 sum_i log|prior precision_i|
-    bool prior_valid;
+    // wave-uniform, held in scalar registers: the shape of the noise posterior after ANY noise update,
+    // c = (n - 1)/2 + c0 (eq 21), with its lgamma and digamma (fp64 lgamma is seven divisions, digamma a recurrence:
+    // ~700 instructions), the constant -lgamma(c0) - c0 log b0, and - without ARD priors, whose precisions follow
+    // the posterior - the prior's log-determinant, which Prior::ApplyToMVN then sets to the same value every time
+    double c_post, lgamma_post, digamma_post, prior_const, prior_logdet;
+    bool prior_is_const;
+    static __device__ __forceinline__ double uniform(double x)
+    {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
     __device__ __forceinline__ void init(const KernelArgs &ka)
     {
-        b = c = c_fn = __builtin_nan("");
-        prior_valid = false;
         const double b0 = ka.cfg.noise_prior_b[0], c0 = ka.cfg.noise_prior_c[0];
-        prior_const = -gammaln(c0) - c0 * log(b0);
+        c_post = ((double)ka.n_unmasked - 1) * 0.5 + c0; // update_noise's expression
+        lgamma_post = uniform(gammaln(c_post));
+        digamma_post = uniform(digamma(c_post));
+        prior_const = uniform(-gammaln(c0) - c0 * log(b0));
+        prior_is_const = true;
+        double mant = 1.0;
+        int expo = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            prior_is_const = prior_is_const && (ka.cfg.prior_type[i] != FVB_PRIOR_ARD);
+            int e;
+            mant *= frexp(fabs(ka.cfg.prior_prec[i]), &e);
+            expo += e;
+        }
+        prior_logdet = uniform(0.5 * (log(mant) + expo * 0.6931471805599453));
     }
 };
 
+// 1/2 log|Lambda0| for a diagonal prior: one logarithm for the product of the precisions (mantissas multiplied,
+// exponents added - see ldl_inverse)
 template <int P>
-__device__ __forceinline__ bool calc_free_energy_cached(const KernelArgs &ka, VoxelState<P> &st, double kk, double trSA,
-    double Fprior, FreeEnergyCache<P> &fc, bool &logdet_valid, double &F, bool &finite)
+__device__ __forceinline__ double prior_log_determinant(const VoxelState<P> &st)
+{
+    double mant = 1.0;
+    int expo = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        int e;
+        mant *= frexp(fabs(st.pprec[i]), &e);
+        expo += e;
+    }
+    return 0.5 * (log(mant) + expo * 0.6931471805599453);
+}
+
+// the part of F without a logarithm (see above); false: the posterior precision could not be formed
+template <int P>
+__device__ __forceinline__ bool free_energy_partial(const KernelArgs &ka, VoxelState<P> &st, double kk, double trSA, bool &logdet_valid,
+    double &theta_terms, double &data_terms)
 {
     // log|det Lambda| comes with the covariance from UpdateTheta's inversion; only a posterior that arrived
     // as a covariance (the initial one) has to be inverted for it, as MVNDist::GetPrecisions would
@@ -1226,38 +1269,6 @@ __device__ __forceinline__ bool calc_free_energy_cached(const KernelArgs &ka, Vo
         logdet_valid = true;
     }
     const double nq = (double)ka.n_unmasked;
-    if (!(st.b == fc.b && st.c == fc.c))
-    {
-        const double si = st.b, ci = st.c;
-        if (!(ci == fc.c_fn))
-        {
-            fc.lgamma_c = gammaln(ci);
-            fc.digamma_c = digamma(ci);
-            fc.c_fn = ci;
-        }
-        const double log_b = log(si);
-        const double dg = fc.digamma_c + log_b;
-        const double expectedLogPhiDist = -fc.lgamma_c - ci * log_b - ci + (ci - 1) * dg;
-        fc.noise_terms = -expectedLogPhiDist + dg * (nq * 0.5 + ka.cfg.noise_prior_c[0] - 1) + fc.prior_const
-            - si * ci / ka.cfg.noise_prior_b[0];
-        fc.b = si;
-        fc.c = ci;
-    }
-    if (!fc.prior_valid)
-    {
-        // (one logarithm for the product of the precisions: mantissas multiplied, exponents added - see ldl_inverse)
-        double mant = 1.0;
-        int expo = 0;
-#pragma unroll
-        for (int i = 0; i < P; i++)
-        {
-            int e;
-            mant *= frexp(fabs(st.pprec[i]), &e);
-            expo += e;
-        }
-        fc.prior_logdet = 0.5 * (log(mant) + expo * 0.6931471805599453);
-        fc.prior_valid = true;
-    }
     double quad = 0, trSL0 = 0;
 #pragma unroll
     for (int i = 0; i < P; i++)
@@ -1266,11 +1277,55 @@ __device__ __forceinline__ bool calc_free_energy_cached(const KernelArgs &ka, Vo
         quad += dm * st.pprec[i] * dm;
         trSL0 += st.Sig[tri(i, i)] * st.pprec[i];
     }
-    const double theta_terms = -(0.5 * st.logdetLam - 0.5 * P * (LOG_2PI + 1)) - 0.5 * quad - 0.5 * trSL0;
-    const double data_terms = -0.5 * st.b * st.c * kk - 0.5 * trSA - 0.5 * nq * LOG_2PI - 0.5 * P * LOG_2PI; // (trace unscaled, :416-417)
-    F = theta_terms + fc.noise_terms + data_terms + fc.prior_logdet;
+    theta_terms = -(0.5 * st.logdetLam - 0.5 * P * (LOG_2PI + 1)) - 0.5 * quad - 0.5 * trSL0;
+    data_terms = -0.5 * st.b * st.c * kk - 0.5 * trSA - 0.5 * nq * LOG_2PI - 0.5 * P * LOG_2PI; // (trace unscaled, :416-417)
+    return ok;
+}
+
+// the terms of F that depend on the noise posterior (b, c) alone; lgamma_c / digamma_c = those of c
+__device__ __forceinline__ double free_energy_noise_terms(const KernelArgs &ka, double b, double c, double lgamma_c, double digamma_c,
+    double prior_const)
+{
+    const double nq = (double)ka.n_unmasked;
+    const double log_b = log(b);
+    const double dg = digamma_c + log_b;
+    const double expectedLogPhiDist = -lgamma_c - c * log_b - c + (c - 1) * dg;
+    return -expectedLogPhiDist + dg * (nq * 0.5 + ka.cfg.noise_prior_c[0] - 1) + prior_const - b * c / ka.cfg.noise_prior_b[0];
+}
+
+// F of a site in full: hot at "lin" (the noise shape is the uniform c_post after any noise update, the prior's
+// log-determinant a constant without ARD: ONE logarithm), general otherwise (a posterior restored by a revert, the
+// pending site of a voxel that failed)
+template <int P>
+__device__ __forceinline__ double free_energy_full(const KernelArgs &ka, const FreeEnergyConsts<P> &fk, const VoxelState<P> &st, double b, double c,
+    bool priors_applied, double theta_terms, double data_terms, double Fprior, bool &finite)
+{
+    double lg, dg;
+    if (c == fk.c_post)
+    {
+        lg = fk.lgamma_post;
+        dg = fk.digamma_post;
+    }
+    else
+    {
+        lg = gammaln(c);
+        dg = digamma(c);
+    }
+    const double noise_terms = free_energy_noise_terms(ka, b, c, lg, dg, fk.prior_const);
+    const double prior_logdet = (fk.prior_is_const && priors_applied) ? fk.prior_logdet : prior_log_determinant<P>(st);
+    double F = theta_terms + noise_terms + data_terms + prior_logdet;
     finite = is_finite(F);
-    F += Fprior; // Vb::CalculateF, inference_vb.cc:310
+    return F + Fprior; // Vb::CalculateF, inference_vb.cc:310
+}
+
+// a site whose F nobody reads: would the reference's CalculateF have thrown? (see above)
+template <int P>
+__device__ __forceinline__ bool free_energy_would_be_finite(const VoxelState<P> &st, double theta_terms, double data_terms)
+{
+    bool ok = is_finite(theta_terms + data_terms) && st.b > 0 && st.c > 0 && is_finite(st.b * st.c) && is_finite(st.c);
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        ok = ok && is_finite(st.pprec[i]) && st.pprec[i] != 0;
     return ok;
 }
 
@@ -1350,7 +1405,11 @@ __device__ __forceinline__ void restore_state(const KernelArgs &ka, int v, Voxel
 //     for (;;) { ReCentre; first time: skip | after a revert: F, done | else: F, ++it, Test(F) -> done or
 //                revert; priors, F, theta, F, noise, F }
 // which executes the same steps in the same order.
-template <class Model, int P, bool NEEDF, int FEED>
+// WATCH: a convergence detector that watches F may run (F-change, F-reduction, trial mode, LM: convergence.cc:73-378),
+// with the save / revert copy of the posterior they ask for (inference_vb.cc:432-434,451-458,506-525). Without it - the
+// reference's default `maxits` detector, with or without F - the detector is a counter and none of that code, nor the
+// registers it holds across the streaming pass, exists in the kernel.
+template <class Model, int P, bool NEEDF, int FEED, bool WATCH = NEEDF>
 __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const KernelArgs ka)
 {
     constexpr int PT = P * (P + 1) / 2;
@@ -1469,7 +1528,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
     conv_reset(conv);
     // Only the detectors that watch F save and revert, and they need F: the kernels built
     // without it carry no save / revert code at all.
-    const bool use_save = NEEDF && (ka.save != nullptr);
+    const bool use_save = WATCH && (ka.save != nullptr);
     enum
     {
         FIRST,     // inference_vb.cc:235 and :443 re-centre about the same means: one pass gives both
@@ -1478,7 +1537,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
     };
     int phase = FIRST;
     int n_lin = 0; // linearisations done so far
-    bool logdet_valid = false; // st.logdetLam belongs to st.Sig (see calc_free_energy_cached)
+    bool logdet_valid = false; // st.logdetLam belongs to st.Sig (see free_energy_partial)
 
     // The iteration as four stages that each end with (at most) ONE evaluation of the free energy, so that
     // CalculateF (inference_vb.cc:302-318) - lgamma, digamma, logarithms, a few hundred instructions - is in
@@ -1497,13 +1556,19 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
     };
     int stage = LINEARISE;
     double kk = 0, trSA = 0;    // of the THETA stage, used again by NOISE
-    FreeEnergyCache<P> fcache;
+    FreeEnergyConsts<P> fk;
     if (NEEDF)
-        fcache.init(ka);
+        fk.init(ka);
+    // the last site of this iteration whose F was checked but not formed (see FreeEnergyConsts): its logarithm-free
+    // part, and - set where a voxel fails - the noise posterior that site saw
+    bool pending = false, priors_applied = false;
+    double pending_part = 0, pending_b = 0, pending_c = 0;
     for (;;)
     {
         bool want_f = NEEDF;
         double f_kk, f_tr;
+        pending_b = st.b; // (what the pending site saw: a stage changes the noise posterior after its predecessor's F)
+        pending_c = st.c;
         if (stage == LINEARISE)
         {
             park_state<P, NEEDF>(park, st);
@@ -1534,11 +1599,11 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
                 status = FVB_BAD_RESULT;
                 break;
             }
-            fcache.prior_valid = false; // (the prior precisions were rewritten)
+            priors_applied = true;
         }
         else if (stage == THETA)
         {
-            if (!update_theta<P>(st, mo, conv_lm_alpha(conv)) || !ensure_cov<P>(st)) // :470
+            if (!update_theta<P>(st, mo, WATCH ? conv_lm_alpha(conv) : 0.0) || !ensure_cov<P>(st)) // :470
             {
                 status = FVB_BAD_RESULT;
                 break;
@@ -1571,19 +1636,34 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
                 f_kk = kk;
                 f_tr = trSA;
             }
-            double Fn;
-            bool fin = true;
-            if (!calc_free_energy_cached<P>(ka, st, f_kk, f_tr, Fprior, fcache, logdet_valid, Fn, fin))
+            double theta_terms, data_terms;
+            if (!free_energy_partial<P>(ka, st, f_kk, f_tr, logdet_valid, theta_terms, data_terms))
             {
                 status = FVB_BAD_RESULT;
                 break;
             }
-            if (!fin)
+            if (stage == LINEARISE) // "lin" / "revert": the F that is read
             {
-                status = FVB_BAD_FREE_ENERGY;
-                break;
+                bool fin = true;
+                const double Fn = free_energy_full<P>(ka, fk, st, st.b, st.c, priors_applied && phase != REVERTED, theta_terms, data_terms, Fprior, fin);
+                if (!fin)
+                {
+                    status = FVB_BAD_FREE_ENERGY;
+                    break;
+                }
+                F = Fn;
+                pending = false;
             }
-            F = Fn;
+            else
+            {
+                if (!free_energy_would_be_finite<P>(st, theta_terms, data_terms))
+                {
+                    status = FVB_BAD_FREE_ENERGY;
+                    break;
+                }
+                pending_part = theta_terms + data_terms;
+                pending = true;
+            }
         }
         if (stage == LINEARISE)
         {
@@ -1595,14 +1675,13 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
                     ka.out.f_history[(size_t)hist_len * V + v] = F;
                 hist_len++;
                 ++it;
-                if (conv_test(conv, F)) // :500
+                if (WATCH ? conv_test(conv, F) : conv_test_counting(conv)) // :500
                 {
                     if (use_save && conv_need_save(conv)) // :506-513
                         save_posterior<P>(ka, v, st, logdet_valid);
                     if (use_save && conv_need_revert(conv)) // :516-525
                     {
                         restore_posterior<P>(ka, v, st, logdet_valid);
-                        fcache.prior_valid = false;
                         phase = REVERTED;
                         continue; // LINEARISE again, about the restored means
                     }
@@ -1614,6 +1693,12 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
         stage = (stage + 1) & 3;
     }
 
+    if (NEEDF && pending && status != FVB_OK)
+    {
+        // the voxel stopped after a site whose F was only checked: that F is what it reports (inference_vb.cc:552,567)
+        bool fin;
+        F = free_energy_full<P>(ka, fk, st, pending_b, pending_c, true, pending_part, 0.0, Fprior, fin);
+    }
     // ---- result MVN: MVNDist(fwd_post, noise.OutputAsMVN()) packed as MVNDist::Save does
     // (inference_vb.cc:549-550; dist_mvn.cc:57-100,410-429; noisemodel_white.cc:55-68) ----
     if (!ensure_cov<P>(st))

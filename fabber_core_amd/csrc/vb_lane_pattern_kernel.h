@@ -325,7 +325,7 @@ __device__ __forceinline__ bool calc_free_energy_pattern(const KernelArgs &ka, V
     double &F, bool &finite)
 {
     bool ok = true;
-    if (!logdet_valid) // (see calc_free_energy_cached)
+    if (!logdet_valid) // (see free_energy_partial, vb_lane_kernel.h)
     {
         st.precValid = false;
         ok = ensure_prec<P>(st);

@@ -622,13 +622,10 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
         else if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
             const double new_cov = st.m[k] * st.m[k] + st.Sig[tri(k, k)];
-            if (it == 0)
-            {
-                st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
-                st.pm[k] = ka.cfg.prior_mean[k];
-            }
-            else
-                st.pprec[k] = 1.0 / new_cov;
+            // (selects, not two branches that store: merged into one store through a pointer phi, the two stores keep
+            // st.pm / st.pprec from being promoted to registers)
+            st.pprec[k] = 1.0 / ((it == 0) ? ka.cfg.prior_var[k] : new_cov);
+            st.pm[k] = (it == 0) ? ka.cfg.prior_mean[k] : st.pm[k];
             const double bb = 2 / new_cov;
             Fprior += -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
         }
@@ -815,13 +812,10 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         else if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
             const double new_cov = st.m[k] * st.m[k] + st.Sig[tri(k, k)];
-            if (it == 0)
-            {
-                st.pprec[k] = 1.0 / ka.cfg.prior_var[k];
-                st.pm[k] = ka.cfg.prior_mean[k];
-            }
-            else
-                st.pprec[k] = 1.0 / new_cov;
+            // (selects, not two branches that store: merged into one store through a pointer phi, the two stores keep
+            // st.pm / st.pprec from being promoted to registers)
+            st.pprec[k] = 1.0 / ((it == 0) ? ka.cfg.prior_var[k] : new_cov);
+            st.pm[k] = (it == 0) ? ka.cfg.prior_mean[k] : st.pm[k];
             const double bb = 2 / new_cov;
             Fprior += -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
         }

@@ -69,6 +69,25 @@ def lib_fma():
     return _LIB_FMA
 
 
+_LIB_EXP1ULP = None
+
+
+def lib_exp1ulp():
+    """CPU build whose exp has the device's accuracy class (1 ulp; oracle/Makefile, -DORACLE_EXP_1ULP)."""
+    global _LIB_EXP1ULP
+    if _LIB_EXP1ULP is None:
+        path = os.path.join(_ROOT, "oracle", "liboracle_exp1ulp.so")
+        src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_exp1ulp.so"])
+        L = C.CDLL(path)
+        L.oracle_vb_run.restype = C.c_int32
+        L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        _LIB_EXP1ULP = L
+    return _LIB_EXP1ULP
+
+
 def lib_quad():
     """The white-noise voxelwise loop evaluated in IEEE binary128 (oracle/Makefile, -DORACLE_QUAD):
     the ground truth for the rounding error of any fp64 build of the algorithm."""
@@ -242,6 +261,14 @@ def run_spatial(holder, spatial, data, _lib=None):
 
 def run_spatial_fma(holder, spatial, data):
     return run_spatial(holder, spatial, data, _lib=lib_fma())
+
+
+def run_spatial_exp1ulp(holder, spatial, data):
+    return run_spatial(holder, spatial, data, _lib=lib_exp1ulp())
+
+
+def run_exp1ulp(holder, data, **kw):
+    return run(holder, data, _lib=lib_exp1ulp(), **kw)
 
 
 def run_spatial_quad(holder, spatial, data):

@@ -176,7 +176,13 @@ def test_random_spatial_configuration(seed):
     for r in (cpu, cpu2):
         r.setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
     tol_f = 2e-5 if h.cfg.model == vbabi.MODEL_EXP else parity.TOL_F
-    parity.strict(h, cpu, got, what=desc, cpu2=cpu2, tol_f=tol_f, allow_floor=True)
+    others = [cpu2]
+    if h.cfg.model == vbabi.MODEL_EXP:
+        # (a few iterations from rates of exactly 0: the step of the first central differences is 1e-10, the last bit
+        # of exp shows 1e6-fold in J, and the device's exp is a 1-ulp exp where glibc's is 0.51: one more CPU build)
+        others.append(oracle.run_spatial_exp1ulp(h, sp, y))
+        others[-1].setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
+    parity.strict(h, cpu, got, what=desc, cpu2=others, tol_f=tol_f, allow_floor=True)
 
 
 def test_random_spatial_cases_are_valid_for_the_oracle():
