@@ -866,6 +866,14 @@ __device__ __forceinline__ double rescue_residual(const KernelArgs &ka, const Mo
     return result;
 }
 
+// a value that is the same in every lane of the wavefront, moved to scalar registers
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // The streaming passes over t need ~130 VGPRs of their own (sweep state, perturbed parameter
 // vectors, moments); the P x P posterior is not touched while they run. With three waves per
 // SIMD (170 VGPRs each) the register allocator would push it to scratch - which is HBM traffic
@@ -1017,15 +1025,18 @@ __device__ __forceinline__ double rescue_tiles(const KernelArgs &ka, const Model
     {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
+        // (the rescued voxel's vectors are the same in every lane: told so, they live in scalar registers - or in the
+        // lanes of a spill VGPR - instead of 40 VGPRs, which the kernels that also carry F do not have: there the
+        // rescue spilled 22 of them to scratch memory and read them back per timepoint, 15 GB of traffic per launch)
         double tp[P], tp2[P], tp3[P], rden[P], nd[P];
 #pragma unroll
         for (int i = 0; i < P; i++)
         {
-            tp[i] = sweep_park[(0 * P + i) * 64 + src];
-            tp2[i] = sweep_park[(1 * P + i) * 64 + src];
-            tp3[i] = sweep_park[(2 * P + i) * 64 + src];
-            rden[i] = sweep_park[(3 * P + i) * 64 + src];
-            nd[i] = __shfl(mo.ml[i], src) - __shfl(m[i], src);
+            tp[i] = wave_uniform(sweep_park[(0 * P + i) * 64 + src]);
+            tp2[i] = wave_uniform(sweep_park[(1 * P + i) * 64 + src]);
+            tp3[i] = wave_uniform(sweep_park[(2 * P + i) * 64 + src]);
+            rden[i] = wave_uniform(sweep_park[(3 * P + i) * 64 + src]);
+            nd[i] = wave_uniform(__shfl(mo.ml[i], src) - __shfl(m[i], src));
         }
         PointwiseSweep<Model, P> sweep;
         double part = 0;
@@ -1211,9 +1222,7 @@ struct FreeEnergyConsts
     bool prior_is_const;
     static __device__ __forceinline__ double uniform(double x)
     {
-        const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        return wave_uniform(x);
     }
     __device__ __forceinline__ void init(const KernelArgs &ka)
     {
@@ -1560,15 +1569,22 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
     if (NEEDF)
         fk.init(ka);
     // the last site of this iteration whose F was checked but not formed (see FreeEnergyConsts): its logarithm-free
-    // part, and - set where a voxel fails - the noise posterior that site saw
+    // part, and - set where a voxel fails, so that nothing more is carried through the loop - the noise posterior
+    // that site saw
     bool pending = false, priors_applied = false;
     double pending_part = 0, pending_b = 0, pending_c = 0;
+#define FVB_VOXEL_FAILS(CODE, B, C)                                                                          \
+    {                                                                                                        \
+        status = (CODE);                                                                                     \
+        pending_b = (B);                                                                                     \
+        pending_c = (C);                                                                                     \
+        break;                                                                                               \
+    }
     for (;;)
     {
         bool want_f = NEEDF;
         double f_kk, f_tr;
-        pending_b = st.b; // (what the pending site saw: a stage changes the noise posterior after its predecessor's F)
-        pending_c = st.c;
+        double b_before = 0, c_before = 0; // NOISE: the noise posterior the pending "theta" site saw
         if (stage == LINEARISE)
         {
             park_state<P, NEEDF>(park, st);
@@ -1581,7 +1597,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
             if (status != FVB_OK)
             {
                 setup_failed = (phase == FIRST);
-                break;
+                FVB_VOXEL_FAILS(status, st.b, st.c)
             }
             if (phase == FIRST)
             {
@@ -1595,19 +1611,13 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
             if (use_save && conv_need_save(conv)) // :451-458
                 save_posterior<P>(ka, v, st, logdet_valid);
             if (!apply_priors<P, NEEDF>(ka, v, it, st, Fprior))
-            {
-                status = FVB_BAD_RESULT;
-                break;
-            }
+                FVB_VOXEL_FAILS(FVB_BAD_RESULT, st.b, st.c)
             priors_applied = true;
         }
         else if (stage == THETA)
         {
             if (!update_theta<P>(st, mo, WATCH ? conv_lm_alpha(conv) : 0.0) || !ensure_cov<P>(st)) // :470
-            {
-                status = FVB_BAD_RESULT;
-                break;
-            }
+                FVB_VOXEL_FAILS(FVB_BAD_RESULT, st.b, st.c)
             st.precValid = false; // Lambda is not kept: the covariance and log|det Lambda| are
             logdet_valid = true;
             if (FEED == FEED_STRIDED)
@@ -1617,6 +1627,8 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
         }
         else
         {
+            b_before = st.b;
+            c_before = st.c;
             update_noise<P>(ka, st, kk, trSA); // :479
         }
         if (want_f)
@@ -1624,10 +1636,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
             if (stage == LINEARISE || stage == PRIORS) // the centre is the current mean, so k = y - g
             {
                 if (!ensure_cov<P>(st))
-                {
-                    status = FVB_BAD_RESULT;
-                    break;
-                }
+                    FVB_VOXEL_FAILS(FVB_BAD_RESULT, st.b, st.c)
                 f_kk = mo.s;
                 f_tr = trace_SA<P>(st, mo);
             }
@@ -1638,19 +1647,13 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
             }
             double theta_terms, data_terms;
             if (!free_energy_partial<P>(ka, st, f_kk, f_tr, logdet_valid, theta_terms, data_terms))
-            {
-                status = FVB_BAD_RESULT;
-                break;
-            }
+                FVB_VOXEL_FAILS(FVB_BAD_RESULT, st.b, st.c)
             if (stage == LINEARISE) // "lin" / "revert": the F that is read
             {
                 bool fin = true;
                 const double Fn = free_energy_full<P>(ka, fk, st, st.b, st.c, priors_applied && phase != REVERTED, theta_terms, data_terms, Fprior, fin);
                 if (!fin)
-                {
-                    status = FVB_BAD_FREE_ENERGY;
-                    break;
-                }
+                    FVB_VOXEL_FAILS(FVB_BAD_FREE_ENERGY, st.b, st.c)
                 F = Fn;
                 pending = false;
             }
@@ -1658,8 +1661,9 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
             {
                 if (!free_energy_would_be_finite<P>(st, theta_terms, data_terms))
                 {
-                    status = FVB_BAD_FREE_ENERGY;
-                    break;
+                    // (the pending site of a failing "phi" is "theta", before this stage's noise update)
+                    const bool noise_stage = (stage == NOISE);
+                    FVB_VOXEL_FAILS(FVB_BAD_FREE_ENERGY, noise_stage ? b_before : st.b, noise_stage ? c_before : st.c)
                 }
                 pending_part = theta_terms + data_terms;
                 pending = true;
@@ -1692,6 +1696,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_kernel(const Kern
         }
         stage = (stage + 1) & 3;
     }
+#undef FVB_VOXEL_FAILS
 
     if (NEEDF && pending && status != FVB_OK)
     {
