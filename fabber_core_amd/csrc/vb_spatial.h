@@ -97,6 +97,12 @@ struct SpatialArgs
     int32_t sl_width;        // lanes that work on one run (a multiple of 64 that divides 1024)
     int32_t sl_max_run;      // longest run (the LDS buffers hold two of them per spatial parameter)
     double *sw_nbr;          // [n_spatial][6][n_pos] the neighbours' means BEFORE the sweep (what a later neighbour contributes)
+    // the prep kernel walks the volume in tiles of 8 x 8 voxels of a plane (tile_nx x tile_ny tiles per plane, planes
+    // tile_z0 ...): the voxel at (x, y, z) is dense[z xsize ysize + y xsize + x - dense_base], -1 = none. 0 tiles: in
+    // index order, 64 consecutive voxels per wavefront
+    const int32_t *dense;
+    long long dense_base, dense_span;
+    int32_t xsize, ysize, tile_nx, tile_ny, tile_z0, n_tiles;
     int32_t *sw_flags;       // [0] != 0: the split sweep met a case it does not handle (a voxel failed during the sweep, a
                              // non-finite mean next to a type P / p prior, an inbox that never arrived): the run is
                              // repeated with the per-level launches
@@ -152,6 +158,50 @@ __device__ __forceinline__ void sp_load(const SpatialArgs &sa, int v, VoxelState
     // how the linearisation these moments belong to evaluated the model: the set-up re-centre is linearisation 0, the
     // one that ends iteration it - 1 is linearisation it; the first ka.precise_passes of a run are pointwise (see
     // sp_precise below)
+    mo.precise = sa.it < sa.ka.precise_passes;
+    st.covValid = true;
+    st.precValid = false;
+}
+
+// What the prep kernel of the split first sweep reads of a voxel's state: the means, the effective moments and the
+// noise posterior - 2 P + PT + 2 of the image's rows (the covariance's diagonal too where an ARD prior follows the
+// posterior). The prior, the covariance and log|det Lambda| are what it WRITES. With F evaluated it checks the free
+// energy "before" (sweep_F) and needs all of it.
+template <int P, bool NEEDF>
+__device__ __forceinline__ void sp_load_prep(const SpatialArgs &sa, int v, VoxelState<P> &st, Moments<P> &mo)
+{
+    if (NEEDF)
+        return sp_load<P>(sa, v, st, mo);
+    typedef SpLayout<P> L;
+    const size_t V = (size_t)sa.ka.cfg.n_voxels;
+    const double *p = sa.state + v;
+    bool any_ard = false;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+    {
+        st.m[i] = p[(size_t)(L::M + i) * V];
+        mo.u[i] = p[(size_t)(L::U + i) * V];
+        mo.ml[i] = p[(size_t)(L::ML + i) * V];
+        st.pm[i] = 0;
+        st.pprec[i] = 0;
+        any_ard |= (sa.ka.cfg.prior_type[i] == FVB_PRIOR_ARD);
+    }
+#pragma unroll
+    for (int i = 0; i < L::PT; i++)
+    {
+        mo.A[i] = p[(size_t)(L::A + i) * V];
+        st.Sig[i] = 0;
+    }
+    if (any_ard) // (uniform)
+    {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            st.Sig[tri(i, i)] = p[(size_t)(L::SIG + tri(i, i)) * V];
+    }
+    st.logdetLam = 0;
+    st.b = p[(size_t)L::B * V];
+    st.c = p[(size_t)L::C * V];
+    mo.s = 0;
     mo.precise = sa.it < sa.ka.precise_passes;
     st.covValid = true;
     st.precValid = false;
@@ -320,12 +370,11 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_spatial_setup_kernel(c
         }
         if (Model::needs_data_max)
         {
-            double data_max = load_data(ka, v);
-            for (int t = 1; t < T; t++)
-            {
-                const double y = load_data(ka, (size_t)t * V + v);
-                data_max = (y > data_max) ? y : data_max;
-            }
+            // (through the prefetching loop of the streaming passes: one load per trip and a wait for it made this
+            // scan - 100 dependent memory round trips per wave - 0.9 of the kernel's 2.9 ms at 128^3)
+            double data_max = 0;
+            auto step = [&](int t, double y) { data_max = (t == 0 || y > data_max) ? y : data_max; };
+            FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
             Model::init_posterior(ma, data_max, st.m);
         }
 #pragma unroll
@@ -625,7 +674,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
             // (selects, not two branches that store: merged into one store through a pointer phi, the two stores keep
             // st.pm / st.pprec from being promoted to registers)
             st.pprec[k] = 1.0 / ((it == 0) ? ka.cfg.prior_var[k] : new_cov);
-            st.pm[k] = (it == 0) ? ka.cfg.prior_mean[k] : st.pm[k];
+            st.pm[k] = ka.cfg.prior_mean[k]; // (set in iteration 0 and never changed: apply_priors, vb_lane_kernel.h)
             const double bb = 2 / new_cov;
             Fprior += -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
         }
@@ -742,9 +791,31 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     // pieces of a 128-byte line merge there, through eight they leave as eight partial lines.
     const int per_xcd = (gridDim.x + 7) / 8;
     const int block = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int v = sa.owned_begin + block * 64 + threadIdx.x;
-    if (v >= sa.owned_end)
-        return;
+    // A wavefront takes a TILE of 8 x 8 voxels of one plane where the volume's dense map is at hand: the voxels of a
+    // tile's diagonals x + y = const are neighbours in a run, so the 8-byte record stores of up to eight lanes fall
+    // into one or two 32-byte sectors (64 consecutive voxels of a row are 64 different runs, one sector each:
+    // 1.74 GB written for 0.9 GB of records at 128^3).
+    int v;
+    if (sa.n_tiles > 0)
+    {
+        if (block >= sa.n_tiles)
+            return;
+        const int per_plane = sa.tile_nx * sa.tile_ny;
+        const int z = sa.tile_z0 + block / per_plane, ty = (block % per_plane) / sa.tile_nx, tx = block % sa.tile_nx;
+        const int x = tx * 8 + (threadIdx.x & 7), y = ty * 8 + (threadIdx.x >> 3);
+        const long long off = (long long)z * sa.xsize * sa.ysize + (long long)y * sa.xsize + x - sa.dense_base;
+        if (x >= sa.xsize || y >= sa.ysize || off < 0 || off >= sa.dense_span)
+            return;
+        v = sa.dense[off];
+        if (v < sa.owned_begin || v >= sa.owned_end)
+            return;
+    }
+    else
+    {
+        v = sa.owned_begin + block * 64 + threadIdx.x;
+        if (v >= sa.owned_end)
+            return;
+    }
     const size_t V = (size_t)ka.cfg.n_voxels;
     const size_t NP = (size_t)sa.n_pos;
     const int pos = sa.pos_of[v];
@@ -755,7 +826,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
         return;
     VoxelState<P> st;
     Moments<P> mo;
-    sp_load<P>(sa, v, st, mo);
+    sp_load_prep<P, NEEDF>(sa, v, st, mo);
     const int dims = sa.spatial_dims;
     int n1[6];
     bool live1[6];
@@ -815,7 +886,7 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
             // (selects, not two branches that store: merged into one store through a pointer phi, the two stores keep
             // st.pm / st.pprec from being promoted to registers)
             st.pprec[k] = 1.0 / ((it == 0) ? ka.cfg.prior_var[k] : new_cov);
-            st.pm[k] = (it == 0) ? ka.cfg.prior_mean[k] : st.pm[k];
+            st.pm[k] = ka.cfg.prior_mean[k]; // (set in iteration 0 and never changed: apply_priors, vb_lane_kernel.h)
             const double bb = 2 / new_cov;
             Fprior += -1.5 * (log(bb) + digamma(0.5)) - 0.5 - gammaln(0.5) - 0.5 * log(bb);
         }

@@ -325,8 +325,15 @@ __global__ __launch_bounds__(256) void geom_neighbours_kernel(const int32_t *coo
 }
 
 // Returns 0 (d_nn filled), 1 (geometry not suited: use the host path) or a negative error code.
+struct DenseMap
+{
+    DevMem map; // [span] voxel at box offset base + i, -1 = none
+    long long base = 0, span = 0;
+    int xsize = 0, ysize = 0;
+};
+
 int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d_nn, hipStream_t stream, std::string &err,
-    DevMem *keep_coords = nullptr, GeomScan *scan_out = nullptr)
+    DevMem *keep_coords = nullptr, GeomScan *scan_out = nullptr, DenseMap *keep_dense = nullptr)
 {
 #define FVB_GEOM_CHECK(expr)                                                                                 \
     do                                                                                                       \
@@ -380,6 +387,15 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
     {
         std::swap(keep_coords->p, d_coords.p);
         std::swap(keep_coords->stream, d_coords.stream);
+    }
+    if (keep_dense) // ... and with the map from box offsets to voxels (the prep kernel's tiles)
+    {
+        std::swap(keep_dense->map.p, d_dense.p);
+        std::swap(keep_dense->map.stream, d_dense.stream);
+        keep_dense->base = first;
+        keep_dense->span = span;
+        keep_dense->xsize = xsize;
+        keep_dense->ysize = ysize;
     }
     return 0;
 }
@@ -450,6 +466,7 @@ struct fvb_spatial_run
     int device_share = 1;    // how many such slabs run on THIS device at once (a device listed several times)
     bool gran_fine = false;  // multi_fast: the inboxes are fine-grained memory (another DEVICE may write them)
     DevMem d_up_pos;
+    DenseMap dense; // (kept from the neighbour table's kernels)
     std::vector<int32_t> h_pos_of; // (multi_fast: the numbering, for the slab below to address this slab's inboxes)
     int fast_prep(int it);
     int fast_sweep();
@@ -577,7 +594,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     DevMem d_coords;
     GeomScan scan;
     const int on_device = (V > 0 && !getenv("FVB_SPATIAL_HOST_GEOMETRY"))
-        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err, &d_coords, &scan) : 1;
+        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err, &d_coords, &scan, &dense) : 1;
     if (on_device < 0)
         return api_fail(on_device, err);
     if (on_device == 1)
@@ -992,6 +1009,24 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         sa.sw_level_pos = (const int32_t *)d_level_pos.p;
         sa.sw_level_count = (const int32_t *)d_level_count.p;
         sa.n_levels = (int32_t)level_pos.size();
+        if (dense.map.p && !getenv("FVB_SPATIAL_PREP_LINEAR")) // the prep kernel's tiles (vb_spatial.h)
+        {
+            const long long z0 = Z[owned_begin], z1 = Z[owned_end - 1];
+            const long long tnx = (dense.xsize + 7) / 8, tny = (dense.ysize + 7) / 8, tiles = (z1 - z0 + 1) * tnx * tny;
+            // (a mask that fills little of its box would spend the kernel on empty tiles)
+            if (tiles > 0 && tiles * 64 <= 4LL * n_owned + 4096 && tiles < (1LL << 30))
+            {
+                sa.dense = (const int32_t *)dense.map.p;
+                sa.dense_base = dense.base;
+                sa.dense_span = dense.span;
+                sa.xsize = dense.xsize;
+                sa.ysize = dense.ysize;
+                sa.tile_nx = (int32_t)tnx;
+                sa.tile_ny = (int32_t)tny;
+                sa.tile_z0 = (int32_t)z0;
+                sa.n_tiles = (int32_t)tiles;
+            }
+        }
     }
     sa.ka.n_unmasked = n_unmasked;
     // the argument block the per-level launches read (nothing in it changes per launch)
@@ -1080,7 +1115,8 @@ int fvb_spatial_run::fast_prep(int it)
     sa.sw_serial++; // this sweep's number
     const int n_owned = owned_end - owned_begin;
     // (a multiple of 8 workgroups: the kernel deals them out to the XCDs in contiguous eighths of the voxel list)
-    hipLaunchKernelGGL(k.prep, dim3((unsigned)(((n_owned + 63) / 64 + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
+    const int waves = sa.n_tiles > 0 ? sa.n_tiles : (n_owned + 63) / 64;
+    hipLaunchKernelGGL(k.prep, dim3((unsigned)((waves + 7) / 8 * 8)), dim3(64), 0, stream, (const SpatialArgs *)d_sa.p, it, sa.sw_serial);
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -512,6 +512,7 @@ def test_split_first_sweep_is_the_per_level_sweep_bit_for_bit(case, monkeypatch)
     for name, env in (("default", {}), ("slabs of 1", {"FVB_SPATIAL_SLAB_DZ": "1"}), ("slabs of 2", {"FVB_SPATIAL_SLAB_DZ": "2"}),
                       ("slabs of 3", {"FVB_SPATIAL_SLAB_DZ": "3"}),
                       ("slab numbering on the host", {"FVB_SPATIAL_HOST_NUMBERING": "1"}),
+                      ("prep kernel in index order", {"FVB_SPATIAL_PREP_LINEAR": "1"}),
                       ("geometry on the host", {"FVB_SPATIAL_HOST_GEOMETRY": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
