@@ -125,7 +125,7 @@ def bench_spatial(args, world, rank, device):
     """--workload c5: one step = one complete spatial VB run (Vb::DoCalculationsSpatial: geometry, set-up and
     `its` Gauss-Seidel sweeps) of the whole volume on one GPU, series resident in HBM."""
     if world != 1:
-        raise SystemExit("--workload c5 runs on one GPU (the slab decomposition is fabber_core_amd/spatial_mgpu.py)")
+        return bench_spatial_multi(args, world, rank, device)
     import cases
     from fabber_core_amd import vbabi
     from fabber_core_amd.device import DeviceProblem
@@ -198,6 +198,68 @@ def bench_spatial(args, world, rank, device):
                          "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32", "spatial_prior_type": args.prior_type,
                          "bad_voxels": int(np.count_nonzero(got["status"])), "ms_per_iteration": dev_ms / w["its"]},
               "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(result), flush=True)
+    return result
+
+
+def bench_spatial_multi(args, world, rank, device):
+    """--workload c5 --gpus N: the ONE volume of config 5 cut into N z-slabs, one per GPU (strong scaling). The slabs
+    sweep together - the lowest plane of slab r + 1 waits, voxel by voxel, for the means slab r's highest plane writes
+    into its inboxes through peer memory (vb_spatial.h) - so they are driven by ONE process: rank 0, through
+    fabber_vb_spatial_multi_* with every slab's series resident on its device before the timed region; the other ranks
+    of the launcher only keep the barriers. One step = one complete run (geometry, set-up, iterations, result images
+    packed on the devices), as at N = 1. FVB_BENCH_REHEARSAL=1: all slabs on the one GPU of a one-GPU box."""
+    import cases
+    from fabber_core_amd import hiplib, vbabi
+    w = WORKLOADS["c5"]
+    n = args.grid or w["grid"]
+    rehearsal = os.environ.get("FVB_BENCH_REHEARSAL") == "1"
+    launched = dist.is_available() and dist.is_initialized()
+
+    def barrier():
+        if launched:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    if rank != 0:
+        barrier()
+        barrier()
+        return None
+    extra = {} if args.prior_type == "M" else {"param_overrides": {"amp1": dict(type=args.prior_type)}}
+    holder, coords, y, _ = cases.c5_problem((n, n, n), max_iterations=w["its"], need_f=bool(args.need_f), **extra)
+    V, T, P = holder.cfg.n_voxels, w["T"], holder.cfg.n_params
+    sp = vbabi.SpatialHolder(coords)
+    devices = [0] * world if rehearsal else list(range(world))
+    run = hiplib.SpatialMultiRun(holder, sp, y, devices, want=("free_energy", "status", "iterations") if args.need_f else ("status", "iterations"))
+    for _ in range(args.warmup):
+        run.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.run()  # returns when every slab's stream has drained
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_slabs, route = run.slabs()
+    got = run.results()
+    run.close()
+    rows = holder.n_mvn_rows
+    alg_bytes = (4 * T + 4 * rows + w["its"] * 6 * 8) * V
+    ms = elapsed / args.steps * 1e3
+    result = {"metric": "voxels/sec to VB convergence", "value": V * args.steps / elapsed, "unit": "voxels/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+              "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": w["desc"], "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
+                         "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32", "spatial_prior_type": args.prior_type,
+                         "slabs": n_slabs, "route": route, "bad_voxels": int(np.count_nonzero(got["status"])),
+                         "parallelism": "%d z-slab(s) on %s, driven by rank 0 through fabber_vb_spatial_multi_* (series resident per device; "
+                                        "inboxes between slabs through peer memory)" % (n_slabs, "ONE GPU (rehearsal: the numbers say nothing about "
+                                        "scaling)" if rehearsal else "%d GPUs" % world)},
+              "roofline": {"bound": "hbm", "kernel": "spatial<exp,%d>: vb_spatial_* kernels of one run on every slab" % P,
+                           "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * (1 if rehearsal else world), "unit": "GB/s",
+                           "frac": alg_bytes / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * (1 if rehearsal else world)), "traffic": None,
+                           "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ms,
+                           "note": "wall time of one run on the host clock between barriers (several devices: no single stream to put events on)"},
+              "cpu_baseline": None}
     print(json.dumps(result), flush=True)
     return result
 

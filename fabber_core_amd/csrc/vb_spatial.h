@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecor
                 // never (slabs start in order and every slab only waits for the one below) - but if a hand-over is missed
                 // all the same, ONE wait runs to its limit: it raises the flag every other wait looks at, so the
                 // kernel drains at once and the host repeats the run with the per-level launches
-                if (++spins > (1 << 22) || ((spins & 63) == 0 && __hip_atomic_load(sa.sw_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                if (++spins > (1 << 20) || ((spins & 63) == 0 && __hip_atomic_load(sa.sw_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
                 {
                     __hip_atomic_store(sa.sw_flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;

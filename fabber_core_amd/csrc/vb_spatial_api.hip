@@ -1702,42 +1702,88 @@ int slab_transfer(SlabRun &from, int v_from, SlabRun &to, int v_to, int n, int P
 }
 } // namespace
 
-static thread_local bool s_multi_no_fast = false;
-
-static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
-    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int));
-
-int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
-    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int))
+static thread_local int s_unlink_pair = -1;
+void fabber_vb_test_unlink_slab_pair(int32_t pair)
 {
-    const auto t0 = std::chrono::steady_clock::now();
-    const int32_t rc = run_spatial_host_multi_impl(cfg, sp, data, out, devices, n_devices, progress_cb);
-    if (getenv("FVB_SPATIAL_TIMING"))
-        fprintf(stderr, "[fvb spatial] fabber_vb_run_spatial_host_multi: %.1f ms in all\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    return rc;
+    s_unlink_pair = pair;
 }
 
-static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
-    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int))
+// One volume on several devices, in three steps a caller can time apart: the slabs and their part of the problem on
+// their devices (open), a complete run on the resident data - geometry, set-up, every iteration, result images packed
+// on the devices - as often as asked (run), the owned voxels' results into the caller's images (results).
+struct fvb_spatial_multi
 {
-    int rc = api_validate(cfg, true);
-    if (rc)
-        return rc;
-    if (!sp || !sp->coords)
-        return api_fail(-42, "spatial description / coordinates missing");
-    if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
-        return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
-    if (spatial_noise_kind(cfg) < 0)
-        return api_fail(-44, spatial_noise_refusal);
-    if (cfg->model == FVB_MODEL_HOSTJAC)
-        return api_fail(-56, "a model evaluated on the host runs spatial VB on one device (fabber_vb_run_spatial_hostmodel_host)");
-    if (!out || !out->mvn)
-        return api_fail(-20, "outputs.mvn is required");
+    fvb_config cfg;
+    fvb_spatial sp;
+    std::vector<int32_t> coords; // (a copy: sp.coords points here)
+    std::vector<int> devs;
+    int V = 0, T = 0, P = 0, world = 0, halo = 1, rows = 0, max_halo = 1;
+    bool second = false, has_spatial = false, peers = true, want_f = false;
+    size_t esz = 4;
+    std::vector<std::unique_ptr<SlabRun> > slabs;
+    const char *route = "";
+    double ms_open = 0, ms_setup = 0, ms_loop = 0;
+
+    // body(r) for every slab, each on a host thread of its own; the first failure (code and message) is the caller's
+    int for_each_slab(const std::function<int(int)> &body)
+    {
+        std::vector<int> rcs(slabs.size(), 0);
+        std::vector<std::string> errs(slabs.size());
+        auto work = [&](int r) {
+            rcs[(size_t)r] = body(r);
+            if (rcs[(size_t)r] != 0)
+                errs[(size_t)r] = fabber_vb_last_error(); // (thread-local: carried to the caller's thread)
+        };
+        std::vector<std::thread> pool;
+        const bool threads = !getenv("FVB_SPATIAL_MULTI_SERIAL");
+        for (int r = 1; r < (int)slabs.size() && threads; r++)
+            pool.emplace_back(work, r);
+        work(0);
+        for (int r = 1; r < (int)slabs.size() && !threads; r++)
+            work(r);
+        for (auto &th : pool)
+            th.join();
+        for (size_t r = 0; r < slabs.size(); r++)
+            if (rcs[r] != 0)
+                return api_fail(rcs[r], errs[r]);
+        return 0;
+    }
+    int plan(const fvb_config *cfg_, const fvb_spatial *sp_, const int32_t *devices, int32_t n_devices);
+    int upload(const void *data, const fvb_outputs *out);
+    int execute(void (*progress_cb)(int, int), bool no_fast);
+    int run(void (*progress_cb)(int, int));
+    int download(const fvb_outputs *out);
+    void release();
+    ~fvb_spatial_multi()
+    {
+        release();
+    }
+};
+
+void fvb_spatial_multi::release()
+{
+    // (giving a slab's memory back unmaps it: a thread per slab)
+    std::vector<std::thread> pool;
+    for (size_t r = 1; r < slabs.size(); r++)
+        pool.emplace_back([this, r]() { slabs[r].reset(); });
+    if (!slabs.empty())
+        slabs[0].reset();
+    for (auto &th : pool)
+        th.join();
+    slabs.clear();
+}
+
+// ---- the slabs: cuts on z-plane boundaries, balanced by voxel count; fewer slabs if the planes do not go round ----
+int fvb_spatial_multi::plan(const fvb_config *cfg_, const fvb_spatial *sp_, const int32_t *devices, int32_t n_devices)
+{
+    cfg = *cfg_;
+    sp = *sp_;
+    V = cfg.n_voxels;
+    T = cfg.n_times;
+    P = cfg.n_params;
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
         return api_fail(-30, "no HIP device available (the VB engine has no CPU fallback)");
-    std::vector<int> devs;
     if (devices)
     {
         if (n_devices <= 0)
@@ -1752,29 +1798,15 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
     else
         for (int i = 0; i < visible; i++)
             devs.push_back(i);
-    const int V = cfg->n_voxels, T = cfg->n_times, P = cfg->n_params;
-    if (V == 0)
-        return 0;
-    if (!data)
-        return api_fail(-21, "data is NULL");
-    if (sp->locked_centres) // (rare, and nothing a second device would speed up: the one-device run)
-        return fabber_vb_run_spatial_host(cfg, sp, data, out, devs[0], progress_cb);
-    const int32_t *X = sp->coords, *Y = sp->coords + V, *Z = sp->coords + 2 * (size_t)V;
-    bool second = false, has_spatial = false;
+    coords.assign(sp_->coords, sp_->coords + 3 * (size_t)V);
+    sp.coords = coords.data();
+    const int32_t *Z = coords.data() + 2 * (size_t)V;
     for (int k = 0; k < P; k++)
     {
-        second |= (cfg->prior_type[k] == FVB_PRIOR_SPATIAL_P || cfg->prior_type[k] == FVB_PRIOR_SPATIAL_p);
-        has_spatial |= cfg->prior_type[k] >= FVB_PRIOR_SPATIAL_M;
+        second |= (cfg.prior_type[k] == FVB_PRIOR_SPATIAL_P || cfg.prior_type[k] == FVB_PRIOR_SPATIAL_p);
+        has_spatial |= cfg.prior_type[k] >= FVB_PRIOR_SPATIAL_M;
     }
-    const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto since = [&](std::chrono::steady_clock::time_point a) {
-        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-    };
-    // all slabs sweep together with the slab form of the split sweep (vb_spatial.h) unless that was tried and abandoned
-    // (s_multi_no_fast), the devices cannot reach each other's memory, or FVB_SPATIAL_PER_LEVEL asks for the
-    // level-chunk pipeline
-    bool peers = true;
+    // the slabs of a run that sweep together write into each other's memory: every pair of neighbours must be peers
     for (size_t r = 0; r + 1 < devs.size() && peers; r++)
         if (devs[r] != devs[r + 1])
         {
@@ -1782,11 +1814,10 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
             peers = hipDeviceCanAccessPeer(&can, devs[r], devs[r + 1]) == hipSuccess && can != 0;
             (void)hipGetLastError();
         }
-    const bool try_fast = has_spatial && peers && !s_multi_no_fast && !getenv("FVB_SPATIAL_PER_LEVEL") && !getenv("FVB_SPATIAL_MULTI_PIPELINE");
     // ghost planes: the split form reads first neighbours only (types P, p are local there, and their a_K sums are
-    // over first neighbours, priors.cc:280-301); the level-chunk pipeline's per-level kernel sums second neighbours
-    const int halo = (second && !try_fast) ? 2 : 1;
-    // ---- the slabs: cuts on z-plane boundaries, balanced by voxel count; fewer slabs if the planes do not go round ----
+    // over first neighbours, priors.cc:280-301); the level-chunk pipeline's per-level kernel - what a run falls back
+    // to - sums second neighbours too, so a problem with such priors keeps two planes either way
+    halo = second ? 2 : 1;
     std::vector<int> plane_start;
     for (int v = 0; v < V; v++)
     {
@@ -1800,8 +1831,7 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
     // A decomposition that does not work out (a very unbalanced mask, planes missing from the z range) is tried
     // again with one slab fewer, down to the one-device run - never refused.
     const int n_planes = (int)plane_start.size();
-    int world = (int)std::min<size_t>(devs.size(), std::max<size_t>(1, plane_start.size() / (size_t)(2 * halo)));
-    std::vector<std::unique_ptr<SlabRun> > slabs;
+    world = (int)std::min<size_t>(devs.size(), std::max<size_t>(1, plane_start.size() / (size_t)(2 * halo)));
     for (; world > 1; world--)
     {
         std::vector<int> cut(1, 0); // plane index at which slab r starts
@@ -1840,17 +1870,25 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
             break;
     }
     if (world <= 1)
-        return fabber_vb_run_spatial_host(cfg, sp, data, out, devs[0], progress_cb);
-    // ---- per slab: its part of the problem on its device, a run handle ----
-    const int n = P + spatial_noise_outputs(cfg), rows = n * (n + 1) / 2 + n + 1;
-    const size_t esz = cfg->data_f64 ? 8 : 4;
-    int max_halo = 1;
-    for (int r = 0; r < world; r++)
+    {
+        world = 1;
+        slabs.clear();
+    }
+    const int n = P + spatial_noise_outputs(&cfg);
+    rows = n * (n + 1) / 2 + n + 1;
+    esz = cfg.data_f64 ? 8 : 4;
+    max_halo = 1;
+    for (int r = 0; r < (int)slabs.size(); r++)
         max_halo = std::max(max_halo, std::max(slabs[r]->b - slabs[r]->g0, slabs[r]->g1 - slabs[r]->e));
-    // every slab is opened (buffers, uploads, neighbour table, numbering, set-up) by a host thread of its own: the
-    // devices work side by side, and on one device the uploads of one slab overlap the numbering of another
-    auto open_slab = [&](int r) -> int {
-        int rc = 0;
+    return 0;
+}
+
+// ---- per slab: its part of the problem on its device (a host thread per slab: the devices work side by side) ----
+int fvb_spatial_multi::upload(const void *data, const fvb_outputs *out)
+{
+    want_f = out->free_energy != nullptr;
+    const bool want_status = out->status != nullptr, want_it = out->iterations != nullptr;
+    auto upload_slab = [&](int r) -> int {
         SlabRun &sl = *slabs[r];
         const size_t Vl = (size_t)(sl.g1 - sl.g0);
         FVB_HIP_CHECK(hipSetDevice(sl.dev));
@@ -1860,50 +1898,49 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
             return hipMemcpy2DAsync(dst, Vl * elem, (const char *)src + (size_t)sl.g0 * elem, (size_t)V * elem, Vl * elem, nrows,
                 hipMemcpyHostToDevice, st);
         };
-        sl.d = *cfg;
+        sl.d = cfg;
         sl.d.n_voxels = (int32_t)Vl;
         FVB_HIP_CHECK(sl.b_data.alloc((size_t)T * Vl * esz, st));
         FVB_HIP_CHECK(upload_rows(sl.b_data.p, data, esz, (size_t)T));
-        if (cfg->design)
+        if (cfg.design)
         {
             FVB_HIP_CHECK(sl.b_design.alloc(sizeof(double) * (size_t)T * P, st));
-            FVB_HIP_CHECK(hipMemcpyAsync(sl.b_design.p, cfg->design, sizeof(double) * (size_t)T * P, hipMemcpyHostToDevice, st));
+            FVB_HIP_CHECK(hipMemcpyAsync(sl.b_design.p, cfg.design, sizeof(double) * (size_t)T * P, hipMemcpyHostToDevice, st));
             sl.d.design = (const double *)sl.b_design.p;
         }
-        if (cfg->phi_index)
+        if (cfg.phi_index)
         {
             FVB_HIP_CHECK(sl.b_phi.alloc((size_t)T, st));
-            FVB_HIP_CHECK(hipMemcpyAsync(sl.b_phi.p, cfg->phi_index, (size_t)T, hipMemcpyHostToDevice, st));
+            FVB_HIP_CHECK(hipMemcpyAsync(sl.b_phi.p, cfg.phi_index, (size_t)T, hipMemcpyHostToDevice, st));
             sl.d.phi_index = (const uint8_t *)sl.b_phi.p;
         }
-        if (cfg->init_mvn)
+        if (cfg.init_mvn)
         {
             FVB_HIP_CHECK(sl.b_init.alloc(sizeof(double) * rows * Vl, st));
-            FVB_HIP_CHECK(upload_rows(sl.b_init.p, cfg->init_mvn, sizeof(double), (size_t)rows));
+            FVB_HIP_CHECK(upload_rows(sl.b_init.p, cfg.init_mvn, sizeof(double), (size_t)rows));
             sl.d.init_mvn = (const double *)sl.b_init.p;
         }
         for (int k = 0; k < P; k++)
-            if (cfg->image_prior[k])
+            if (cfg.image_prior[k])
             {
                 FVB_HIP_CHECK(sl.b_img[k].alloc(sizeof(double) * Vl, st));
-                FVB_HIP_CHECK(upload_rows(sl.b_img[k].p, cfg->image_prior[k], sizeof(double), 1));
+                FVB_HIP_CHECK(upload_rows(sl.b_img[k].p, cfg.image_prior[k], sizeof(double), 1));
                 sl.d.image_prior[k] = (const double *)sl.b_img[k].p;
             }
         memset(&sl.dout, 0, sizeof(sl.dout));
         FVB_HIP_CHECK(sl.b_mvn.alloc(sizeof(double) * rows * Vl, st));
         sl.dout.mvn = (double *)sl.b_mvn.p;
-        if (out->free_energy)
+        if (want_f)
         {
             FVB_HIP_CHECK(sl.b_f.alloc(sizeof(double) * Vl, st));
-            FVB_HIP_CHECK(hipMemsetAsync(sl.b_f.p, 0xff, sizeof(double) * Vl, st)); // NaN (see fabber_vb_run_spatial_host)
             sl.dout.free_energy = (double *)sl.b_f.p;
         }
-        if (out->status)
+        if (want_status)
         {
             FVB_HIP_CHECK(sl.b_status.alloc(sizeof(int32_t) * Vl, st));
             sl.dout.status = (int32_t *)sl.b_status.p;
         }
-        if (out->iterations)
+        if (want_it)
         {
             FVB_HIP_CHECK(sl.b_it.alloc(sizeof(int32_t) * Vl, st));
             sl.dout.iterations = (int32_t *)sl.b_it.p;
@@ -1913,41 +1950,56 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
         FVB_HIP_CHECK(hipStreamSynchronize(st)); // (the uploads read pageable host memory)
         sl.coords.resize(3 * Vl);
         for (int dim = 0; dim < 3; dim++)
-            std::copy(sp->coords + (size_t)dim * V + sl.g0, sp->coords + (size_t)dim * V + sl.g1, sl.coords.begin() + (size_t)dim * Vl);
-        sl.sp = *sp;
+            std::copy(coords.begin() + (size_t)dim * V + sl.g0, coords.begin() + (size_t)dim * V + sl.g1, sl.coords.begin() + (size_t)dim * Vl);
+        sl.sp = sp;
         sl.sp.coords = sl.coords.data();
         sl.sp.owned_begin = sl.b - sl.g0;
         sl.sp.owned_end = sl.e - sl.g0;
         sl.sp.n_voxels_global = V;
+        return 0;
+    };
+    return for_each_slab(upload_slab);
+}
+
+// ---- a complete run on the resident data: set-up, the iterations, the packed result images (on the devices) ----
+int fvb_spatial_multi::run(void (*progress_cb)(int, int))
+{
+    int rc = execute(progress_cb, false);
+    s_unlink_pair = -1; // (the test hook holds for one attempt)
+    if (rc == 1) // the slabs could not sweep together (or gave that up): the level-chunk pipeline, the exact form
+        rc = execute(progress_cb, true);
+    return rc;
+}
+
+// Returns 1 where the run has to be repeated as the level-chunk pipeline.
+int fvb_spatial_multi::execute(void (*progress_cb)(int, int), bool no_fast)
+{
+    int rc;
+    const int32_t *X = coords.data(), *Y = X + V, *Z = X + 2 * (size_t)V;
+    const bool timing = getenv("FVB_SPATIAL_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    // all slabs sweep together with the slab form of the split sweep (vb_spatial.h) unless that was tried and abandoned,
+    // the devices cannot reach each other's memory, or FVB_SPATIAL_PER_LEVEL asks for the level-chunk pipeline
+    const bool try_fast = has_spatial && peers && !no_fast && !getenv("FVB_SPATIAL_PER_LEVEL") && !getenv("FVB_SPATIAL_MULTI_PIPELINE");
+    // ---- per slab: a run handle (neighbour table, numbering, set-up) ----
+    auto open_slab = [&](int r) -> int {
+        SlabRun &sl = *slabs[r];
+        FVB_HIP_CHECK(hipSetDevice(sl.dev));
+        delete sl.run;
+        sl.run = nullptr;
+        if (sl.dout.free_energy)
+            FVB_HIP_CHECK(hipMemsetAsync(sl.b_f.p, 0xff, sizeof(double) * (size_t)(sl.g1 - sl.g0), sl.stream)); // NaN (see fabber_vb_run_spatial_host)
         sl.run = new fvb_spatial_run;
         sl.run->allow_fast = sl.run->multi_fast = try_fast;
         sl.run->device_share = (int)std::count(devs.begin(), devs.begin() + world, sl.dev);
-        if ((rc = sl.run->open(&sl.d, &sl.sp, sl.b_data.p, &sl.dout, st)) != 0)
-            return rc;
-        return 0;
+        return sl.run->open(&sl.d, &sl.sp, sl.b_data.p, &sl.dout, sl.stream);
     };
-    {
-        std::vector<int> rcs((size_t)world, 0);
-        std::vector<std::string> errs((size_t)world);
-        auto work = [&](int r) {
-            rcs[(size_t)r] = open_slab(r);
-            if (rcs[(size_t)r] != 0)
-                errs[(size_t)r] = fabber_vb_last_error(); // (thread-local: carried to the caller's thread)
-        };
-        std::vector<std::thread> pool;
-        const bool threads = !getenv("FVB_SPATIAL_MULTI_SERIAL");
-        for (int r = 1; r < world && threads; r++)
-            pool.emplace_back(work, r);
-        work(0);
-        for (int r = 1; r < world && !threads; r++)
-            work(r);
-        for (auto &th : pool)
-            th.join();
-        for (int r = 0; r < world; r++)
-            if (rcs[(size_t)r] != 0)
-                return api_fail(rcs[(size_t)r], errs[(size_t)r]);
-    }
-    const double ms_open = since(t_begin);
+    if ((rc = for_each_slab(open_slab)) != 0)
+        return rc;
+    ms_setup = since(t_begin);
     const auto t_loop = std::chrono::steady_clock::now();
     // ---- all slabs sweep together: every slab's top plane writes into the inboxes of the slab above ----
     bool all_fast = try_fast;
@@ -1959,13 +2011,7 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
             all_fast = all_fast && slabs[r]->run->gran_fine;
     }
     if (try_fast && !all_fast) // (a slab the slab form does not take: the level-chunk pipeline for the whole run)
-    {
-        slabs.clear();
-        s_multi_no_fast = true;
-        rc = fabber_vb_run_spatial_host_multi(cfg, sp, data, out, devices, n_devices, progress_cb);
-        s_multi_no_fast = false;
-        return rc;
-    }
+        return 1;
     if (all_fast)
     {
         for (int r = 0; r + 1 < world; r++)
@@ -1980,22 +2026,20 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
                     // (hipDeviceCanAccessPeer said yes: all the same, the pipeline needs no peer mapping)
                     if (getenv("FVB_SPATIAL_VERBOSE"))
                         fprintf(stderr, "[fvb spatial] hipDeviceEnablePeerAccess(%d -> %d): %s - level-chunk pipeline\n", slabs[r]->dev, slabs[r + 1]->dev, hipGetErrorString(e));
-                    slabs.clear();
-                    s_multi_no_fast = true;
-                    rc = fabber_vb_run_spatial_host_multi(cfg, sp, data, out, devices, n_devices, progress_cb);
-                    s_multi_no_fast = false;
-                    return rc;
+                    return 1;
                 }
             }
+            if (r == s_unlink_pair) // (test hook: the slab above never hears from this one)
+                continue;
             if ((rc = slabs[r]->run->link_up(*slabs[r + 1]->run, slabs[r]->g0, slabs[r + 1]->g0)) != 0)
                 return rc;
         }
         std::vector<double> partials_f, sums_f((size_t)P * 2);
-        for (int it = 0; it < cfg->max_iterations; it++)
+        for (int it = 0; it < cfg.max_iterations; it++)
         {
             if (progress_cb)
-                progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
-            if (has_spatial && (it > 0 || sp->update_first_iter))
+                progress_cb(it, cfg.max_iterations); // inference_vb.cc:610
+            if (has_spatial && (it > 0 || sp.update_first_iter))
             {
                 std::fill(sums_f.begin(), sums_f.end(), 0.0);
                 for (int r = 0; r < world; r++)
@@ -2030,7 +2074,7 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
                 if ((rc = slabs[r]->run->fast_sweep()) != 0)
                     return rc;
             }
-            if (cfg->need_f) // the F term of the priors of the LAST voxel of the sweep is the last slab's
+            if (cfg.need_f) // the F term of the priors of the LAST voxel of the sweep is the last slab's
             {
                 double fp = 0;
                 FVB_HIP_CHECK(hipSetDevice(slabs[world - 1]->dev));
@@ -2076,11 +2120,7 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
             // with the launches the split sweep does not need - here the level-chunk pipeline
             if (getenv("FVB_SPATIAL_VERBOSE"))
                 fprintf(stderr, "[fvb spatial] slab sweep across devices abandoned, repeating the run with the level-chunk pipeline\n");
-            slabs.clear();
-            s_multi_no_fast = true;
-            rc = fabber_vb_run_spatial_host_multi(cfg, sp, data, out, devices, n_devices, progress_cb);
-            s_multi_no_fast = false;
-            return rc;
+            return 1;
         }
     }
     // ---- (otherwise) the global level range and the pipeline's ticks ----
@@ -2097,11 +2137,11 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
         chunk_levels = std::max(1, atoi(forced));
     const long long nchunks = std::max(1LL, (lmax - lmin + chunk_levels) / chunk_levels);
     std::vector<double> partials, sums((size_t)P * 2);
-    for (int it = 0; it < (all_fast ? 0 : cfg->max_iterations); it++)
+    for (int it = 0; it < (all_fast ? 0 : cfg.max_iterations); it++)
     {
         if (progress_cb)
-            progress_cb(it, cfg->max_iterations); // inference_vb.cc:610
-        if (has_spatial && (it > 0 || sp->update_first_iter))
+            progress_cb(it, cfg.max_iterations); // inference_vb.cc:610
+        if (has_spatial && (it > 0 || sp.update_first_iter))
         {
             // a_K: every slab's segment sums, added in the order of the voxel list (vb_spatial_ak_reduce_kernel's)
             std::fill(sums.begin(), sums.end(), 0.0);
@@ -2147,7 +2187,7 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
                     return rc;
             }
         }
-        if (cfg->need_f) // the F term of the priors of the LAST voxel of the sweep is the last slab's (inference_vb.cc:612,689,702)
+        if (cfg.need_f) // the F term of the priors of the LAST voxel of the sweep is the last slab's (inference_vb.cc:612,689,702)
         {
             double fp = 0;
             FVB_HIP_CHECK(hipSetDevice(slabs[world - 1]->dev));
@@ -2178,49 +2218,149 @@ static int32_t run_spatial_host_multi_impl(const fvb_config *cfg, const fvb_spat
                     return rc;
             }
     }
-    // ---- results: every slab packs its voxels, the owned ones go to the caller's images ----
+    // ---- every slab packs its voxels' results (on its device) ----
     for (int r = 0; r < world; r++)
     {
         FVB_HIP_CHECK(hipSetDevice(slabs[r]->dev));
-        FVB_HIP_CHECK(hipStreamSynchronize(slabs[r]->stream));
+        if ((rc = slabs[r]->run->finish()) != 0) // (ends with a wait for the slab's stream)
+            return rc;
     }
-    const double ms_loop = since(t_loop);
-    const auto t_out = std::chrono::steady_clock::now();
+    ms_loop = since(t_loop);
+    route = all_fast ? "all slabs sweep together" : "level-chunk pipeline";
+    if (timing)
+        fprintf(stderr, "[fvb spatial] %d slabs (%s): geometry + set-up %.1f ms, %d iterations + result images %.1f ms\n", world, route, ms_setup,
+            cfg.max_iterations, ms_loop);
+    return 0;
+}
+
+// ---- results: the owned voxels of every slab go to the caller's images ----
+int fvb_spatial_multi::download(const fvb_outputs *out)
+{
     for (int r = 0; r < world; r++)
     {
         SlabRun &sl = *slabs[r];
         FVB_HIP_CHECK(hipSetDevice(sl.dev));
-        if ((rc = sl.run->finish()) != 0)
-            return rc;
         const size_t Vl = (size_t)(sl.g1 - sl.g0), own = (size_t)(sl.e - sl.b), skip = (size_t)(sl.b - sl.g0);
         auto download_rows = [&](void *dst, const void *src, size_t elem, size_t nrows) {
             return hipMemcpy2D((char *)dst + (size_t)sl.b * elem, (size_t)V * elem, (const char *)src + skip * elem, Vl * elem, own * elem, nrows,
                 hipMemcpyDeviceToHost);
         };
         FVB_HIP_CHECK(download_rows(out->mvn, sl.dout.mvn, sizeof(double), (size_t)rows));
-        if (sl.dout.free_energy)
+        if (sl.dout.free_energy && out->free_energy)
             FVB_HIP_CHECK(download_rows(out->free_energy, sl.dout.free_energy, sizeof(double), 1));
-        if (sl.dout.status)
+        if (sl.dout.status && out->status)
             FVB_HIP_CHECK(download_rows(out->status, sl.dout.status, sizeof(int32_t), 1));
-        if (sl.dout.iterations)
+        if (sl.dout.iterations && out->iterations)
             FVB_HIP_CHECK(download_rows(out->iterations, sl.dout.iterations, sizeof(int32_t), 1));
     }
+    return 0;
+}
+
+static int32_t spatial_multi_validate(const fvb_config *cfg, const fvb_spatial *sp, const fvb_outputs *out)
+{
+    int rc = api_validate(cfg, true);
+    if (rc)
+        return rc;
+    if (!sp || !sp->coords)
+        return api_fail(-42, "spatial description / coordinates missing");
+    if (sp->spatial_dims < 0 || sp->spatial_dims > 3)
+        return api_fail(-43, "spatial-dims must be 0, 1, 2 or 3");
+    if (spatial_noise_kind(cfg) < 0)
+        return api_fail(-44, spatial_noise_refusal);
+    if (cfg->model == FVB_MODEL_HOSTJAC)
+        return api_fail(-56, "a model evaluated on the host runs spatial VB on one device (fabber_vb_run_spatial_hostmodel_host)");
+    if (!out || !out->mvn)
+        return api_fail(-20, "outputs.mvn is required");
+    return 0;
+}
+
+int32_t fabber_vb_spatial_multi_open(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *wanted,
+    const int32_t *devices, int32_t n_devices, fvb_spatial_multi **handle)
+{
+    if (!handle)
+        return api_fail(-47, "handle pointer is NULL");
+    *handle = nullptr;
+    int rc = spatial_multi_validate(cfg, sp, wanted);
+    if (rc)
+        return rc;
+    if (cfg->n_voxels == 0 || !data)
+        return api_fail(-21, "no voxels / data is NULL");
+    if (sp->locked_centres)
+        return api_fail(-57, "locked linearisation centres run on one device (fabber_vb_run_spatial_host)");
+    std::unique_ptr<fvb_spatial_multi> m(new fvb_spatial_multi);
+    if ((rc = m->plan(cfg, sp, devices, n_devices)) != 0)
+        return rc;
+    if (m->world <= 1)
+        return api_fail(-58, "the volume has too few planes for two slabs: fabber_vb_run_spatial_host / _device");
+    if ((rc = m->upload(data, wanted)) != 0)
+        return rc;
+    *handle = m.release();
+    return 0;
+}
+
+int32_t fabber_vb_spatial_multi_run(fvb_spatial_multi *handle, void (*progress_cb)(int, int))
+{
+    return handle ? handle->run(progress_cb) : api_fail(-47, "handle is NULL");
+}
+
+int32_t fabber_vb_spatial_multi_results(fvb_spatial_multi *handle, const fvb_outputs *out)
+{
+    if (!handle || !out || !out->mvn)
+        return api_fail(-47, "handle or outputs.mvn is NULL");
+    return handle->download(out);
+}
+
+int32_t fabber_vb_spatial_multi_slabs(fvb_spatial_multi *handle, int32_t *n_slabs, char *route, int32_t route_len)
+{
+    if (!handle)
+        return api_fail(-47, "handle is NULL");
+    if (n_slabs)
+        *n_slabs = handle->world;
+    if (route && route_len > 0)
+        snprintf(route, (size_t)route_len, "%s", handle->route);
+    return 0;
+}
+
+int32_t fabber_vb_spatial_multi_close(fvb_spatial_multi *handle)
+{
+    delete handle;
+    return 0;
+}
+
+int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
+    const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int))
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    int rc = spatial_multi_validate(cfg, sp, out);
+    if (rc)
+        return rc;
+    if (cfg->n_voxels == 0)
+        return 0;
+    if (!data)
+        return api_fail(-21, "data is NULL");
+    std::unique_ptr<fvb_spatial_multi> m(new fvb_spatial_multi);
+    if ((rc = m->plan(cfg, sp, devices, n_devices)) != 0)
+        return rc;
+    // (locked centres: rare, and nothing a second device would speed up; too few planes for two slabs: the one-device run)
+    if (sp->locked_centres || m->world <= 1)
+        return fabber_vb_run_spatial_host(cfg, sp, data, out, m->devs[0], progress_cb);
+    if ((rc = m->upload(data, out)) != 0)
+        return rc;
+    const double ms_up = since(t0);
+    if ((rc = m->run(progress_cb)) != 0)
+        return rc;
+    const auto t_out = std::chrono::steady_clock::now();
+    if ((rc = m->download(out)) != 0)
+        return rc;
     const double ms_out = since(t_out);
     const auto t_free = std::chrono::steady_clock::now();
-    {
-        // (giving a slab's memory back unmaps it: a thread per slab here too)
-        std::vector<std::thread> pool;
-        for (int r = 1; r < world; r++)
-            pool.emplace_back([&slabs, r]() { slabs[(size_t)r].reset(); });
-        slabs[0].reset();
-        for (auto &th : pool)
-            th.join();
-    }
-    slabs.clear();
-    if (timing)
-        fprintf(stderr, "[fvb spatial] %d slabs (%s): upload + geometry + set-up %.1f ms, %d iterations %.1f ms, results %.1f ms, "
-                        "giving the slabs' memory back %.1f ms\n", world,
-            all_fast ? "all slabs sweep together" : "level-chunk pipeline", ms_open, cfg->max_iterations, ms_loop, ms_out, since(t_free));
+    m.reset();
+    if (getenv("FVB_SPATIAL_TIMING"))
+        fprintf(stderr, "[fvb spatial] fabber_vb_run_spatial_host_multi: upload %.1f ms, results %.1f ms, giving the slabs' memory back %.1f ms, %.1f ms in all\n",
+            ms_up, ms_out, since(t_free), since(t0));
     return 0;
 }
 

@@ -326,6 +326,79 @@ def run_spatial_host(holder, spatial, data, device=0, progress_cb=None, devices=
     return arrs
 
 
+class SpatialMultiRun:
+    """One spatial VB problem resident on several devices (fabber_vb_spatial_multi_*): open uploads, run() is one
+    complete run on the resident data (may be repeated), results() downloads, close() frees."""
+
+    def __init__(self, holder, spatial, data, devices, want=("free_energy", "status", "iterations")):
+        self.holder, self.spatial = holder, spatial
+        cfg = holder.cfg
+        self._data = _prepare_data(holder, data)
+        V = cfg.n_voxels
+        self.arrs = dict(mvn=np.full((holder.n_mvn_rows, V), np.nan))
+        if "free_energy" in want:
+            self.arrs["free_energy"] = np.full(V, np.nan)
+        if "status" in want:
+            self.arrs["status"] = np.full(V, -1, dtype=np.int32)
+        if "iterations" in want:
+            self.arrs["iterations"] = np.full(V, -1, dtype=np.int32)
+        self.out = vbabi.FvbOutputs()
+        for k, a in self.arrs.items():
+            setattr(self.out, k, a.ctypes.data)
+        L = self.L = lib()
+        L.fabber_vb_spatial_multi_open.restype = C.c_int32
+        L.fabber_vb_spatial_multi_open.argtypes = [C.POINTER(vbabi.FvbConfig), C.POINTER(vbabi.FvbSpatial), C.c_void_p,
+                                                   C.POINTER(vbabi.FvbOutputs), C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        for name in ("fabber_vb_spatial_multi_run", "fabber_vb_spatial_multi_results"):
+            getattr(L, name).restype = C.c_int32
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.fabber_vb_spatial_multi_slabs.restype = C.c_int32
+        L.fabber_vb_spatial_multi_slabs.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
+        L.fabber_vb_spatial_multi_close.restype = C.c_int32
+        L.fabber_vb_spatial_multi_close.argtypes = [C.c_void_p]
+        ids = None if devices == "all" else (C.c_int32 * len(devices))(*devices)
+        self.h = C.c_void_p()
+        _check(L.fabber_vb_spatial_multi_open(C.byref(cfg), C.byref(spatial.sp), self._data.ctypes.data, C.byref(self.out), ids,
+                                              0 if ids is None else len(devices), C.byref(self.h)))
+
+    def run(self):
+        _check(self.L.fabber_vb_spatial_multi_run(self.h, None))
+
+    def slabs(self):
+        n = C.c_int32(0)
+        buf = C.create_string_buffer(64)
+        _check(self.L.fabber_vb_spatial_multi_slabs(self.h, C.byref(n), buf, 64))
+        return n.value, buf.value.decode()
+
+    def results(self):
+        _check(self.L.fabber_vb_spatial_multi_results(self.h, C.byref(self.out)))
+        r = dict(self.arrs)
+        if "status" in r:
+            r["setup_failed"] = (r["status"] & 0x100) != 0
+            r["status"] = r["status"] & 0xFF
+        return r
+
+    def close(self):
+        if self.h:
+            self.L.fabber_vb_spatial_multi_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def test_unlink_slab_pair(pair):
+    """Fault injection for tests (fabber_vb_test_unlink_slab_pair): the next multi-device spatial run of this thread
+    leaves the slab above `pair` without its inboxes' writer."""
+    L = lib()
+    L.fabber_vb_test_unlink_slab_pair.restype = None
+    L.fabber_vb_test_unlink_slab_pair.argtypes = [C.c_int32]
+    L.fabber_vb_test_unlink_slab_pair(pair)
+
+
 def neighbours(coords, spatial_dims=3):
     """First-neighbour table of the spatial driver (host code, no GPU): [V][6], -1 = none."""
     coords = np.ascontiguousarray(coords, dtype=np.int32)

@@ -362,14 +362,41 @@ int32_t fabber_vb_run_hostmodel_host(const fvb_config *cfg, const void *data, co
  * slab sweep of the one-device run (one launch per slab and iteration, all at once); a voxel whose z+1 neighbour lives on
  * the device above writes its new mean into that neighbour's inbox there (fine-grained peer memory, system-scope stores,
  * self-validating granules), where the lowest plane waits for it as it waits for a workgroup of its own device.
- * Second-neighbour priors (P, p), or a decomposition the slab form does not take: the slabs step through the SAME global
- * levels as a pipeline, slab r one chunk of levels behind slab r - 1, boundary planes handed upwards after every chunk.
+ * Types P and p take part as what the reference codes them to be - priors whose mean reads no neighbour (priors.cc:455) - and
+ * need no hand-over at all. A decomposition the slab form does not take (devices that are not peers, no fine-grained
+ * memory, a voxel that fails during a first sweep, a non-finite mean next to a type P / p prior, an inbox that never
+ * arrives): the slabs step through the SAME global levels as a pipeline, slab r one chunk of levels behind slab r - 1,
+ * boundary planes handed upwards after every chunk - the exact form, second-neighbour sums included.
  * Either way the a_K sums are added over the segments of the voxel list in voxel order: the images are those of the
  * one-device run bit for bit. Fewer slabs than devices where the volume has too few planes. Host pointers throughout;
  * models evaluated on the host are not taken (-56); with locked linearisation centres the run uses devices[0] alone.
  */
 int32_t fabber_vb_run_spatial_host_multi(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *out,
     const int32_t *devices, int32_t n_devices, void (*progress_cb)(int, int));
+
+/*
+ * The same in the steps a caller may want to time apart (bench.py --workload c5 --gpus N): open cuts the slabs and puts
+ * each slab's part of the problem on its device (`wanted`: which of the optional images - free_energy, status,
+ * iterations - the run should keep; only the non-NULL-ness of its members is read); run is ONE complete spatial VB run
+ * on the resident data - neighbour tables, numbering, set-up, every iteration, the result images packed on the devices -
+ * and may be called again (another run of the same problem); results copies the owned voxels' images to host memory;
+ * close gives everything back. -58: the volume has too few planes for two slabs (take fabber_vb_run_spatial_host);
+ * -57: locked linearisation centres. slabs: how many slabs there are and which route the last run took.
+ */
+typedef struct fvb_spatial_multi fvb_spatial_multi;
+int32_t fabber_vb_spatial_multi_open(const fvb_config *cfg, const fvb_spatial *sp, const void *data, const fvb_outputs *wanted,
+    const int32_t *devices, int32_t n_devices, fvb_spatial_multi **handle);
+int32_t fabber_vb_spatial_multi_run(fvb_spatial_multi *handle, void (*progress_cb)(int, int));
+int32_t fabber_vb_spatial_multi_results(fvb_spatial_multi *handle, const fvb_outputs *out);
+int32_t fabber_vb_spatial_multi_slabs(fvb_spatial_multi *handle, int32_t *n_slabs, char *route, int32_t route_len);
+int32_t fabber_vb_spatial_multi_close(fvb_spatial_multi *handle);
+
+/*
+ * Test hook (fault injection; changes nothing unless called): the next fabber_vb_spatial_multi_run / _run_spatial_host_multi
+ * of this thread leaves the inboxes of the slab above `pair` unlinked, so that slab's lowest plane waits for means that
+ * never arrive, gives up and the run is repeated as the level-chunk pipeline (tests/test_spatial_mgpu.py). -1: off.
+ */
+void fabber_vb_test_unlink_slab_pair(int32_t pair);
 
 /*
  * Spatial VB (Vb::DoCalculationsSpatial, inference_vb.cc:578-767) with such a model: any FwdModel of a model

@@ -293,6 +293,50 @@ def test_engine_slabs_against_the_single_device_run(typ, slabs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("typ", ["M", "P"])
+def test_resident_multi_device_run_can_be_repeated(typ):
+    """fabber_vb_spatial_multi_*: the slabs' data stay on their devices, run() is a complete run (geometry, set-up,
+    iterations, packing) and can be called again - what bench.py --workload c5 --gpus N times"""
+    h, sp, y = spatial_problem(typ)
+    ref = hiplib.run_spatial_host(h, sp, y)
+    m = hiplib.SpatialMultiRun(h, sp, y, [0, 0, 0])
+    for _ in range(2):
+        m.run()
+        got = m.results()
+        n, route = m.slabs()
+        assert n == 3 and route == "all slabs sweep together"
+        for k in ("mvn", "status", "iterations"):
+            assert np.array_equal(got[k], ref[k]), (typ, k)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_an_inbox_that_never_arrives_ends_in_the_level_chunk_pipeline():
+    """The hand-over between slabs is a wait for a self-validating granule. If one never arrives - here: the slab
+    below is left unlinked (fabber_vb_test_unlink_slab_pair), so the lowest plane of the slab above polls stale inboxes
+    - ONE wait runs to its limit and raises the flag every other wait looks at, the sweep kernels drain, and the run is
+    repeated as the level-chunk pipeline: the one-device bits, in seconds, not a hang"""
+    import time
+    h, sp, y = spatial_problem("M")
+    ref = hiplib.run_spatial_host(h, sp, y)
+    m = hiplib.SpatialMultiRun(h, sp, y, [0, 0, 0])
+    hiplib.test_unlink_slab_pair(1)
+    t0 = time.perf_counter()
+    m.run()
+    took = time.perf_counter() - t0
+    got = m.results()
+    n, route = m.slabs()
+    assert n == 3 and route == "level-chunk pipeline"
+    for k in ("mvn", "status", "iterations"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert took < 60, took
+    m.run()  # (the hook held for one attempt)
+    assert m.slabs()[1] == "all slabs sweep together"
+    assert np.array_equal(m.results()["mvn"], ref["mvn"])
+    m.close()
+
+
+@pytest.mark.gpu
 def test_engine_slabs_with_free_energy_ard_and_a_failing_voxel():
     h, sp, y = ard_problem()
     ref = hiplib.run_spatial_host(h, sp, y)
