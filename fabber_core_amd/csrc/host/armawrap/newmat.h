@@ -22,6 +22,7 @@
 #include <exception>
 #include <iomanip>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdlib.h>
 #include <sys/mman.h>
@@ -164,6 +165,81 @@ private:
     int m_pos;
 };
 
+// Big blocks (volumes: tens to hundreds of MB) are not given back to the system when an image dies but kept for the
+// next one of the same size: a run through the C ABI allocates ~1 GB of images between fabber_new and fabber_destroy, and
+// mapping, first-touching and unmapping them was a third of a million-voxel run (35 ms in fabber_destroy alone). The
+// cache is bounded (FVB_HOST_CACHE_BYTES, default 3 GiB; 0 = off), process-wide, and emptied by trim().
+class BigBlockCache
+{
+public:
+    static BigBlockCache &instance()
+    {
+        static BigBlockCache cache;
+        return cache;
+    }
+    void *take(std::size_t bytes)
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        for (std::size_t i = 0; i < m_free.size(); i++)
+            if (m_free[i].second == bytes)
+            {
+                void *p = m_free[i].first;
+                m_free[i] = m_free.back();
+                m_free.pop_back();
+                m_held -= bytes;
+                return p;
+            }
+        return nullptr;
+    }
+    bool give(void *p, std::size_t bytes)
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        if (m_held + bytes > m_cap)
+            return false;
+        m_free.push_back(std::make_pair(p, bytes));
+        m_held += bytes;
+        return true;
+    }
+    /** give back everything beyond `keep` bytes (largest blocks first) */
+    void trim(std::size_t keep)
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        while (m_held > keep && !m_free.empty())
+        {
+            std::size_t big = 0;
+            for (std::size_t i = 1; i < m_free.size(); i++)
+                if (m_free[i].second > m_free[big].second)
+                    big = i;
+            free(m_free[big].first);
+            m_held -= m_free[big].second;
+            m_free[big] = m_free.back();
+            m_free.pop_back();
+        }
+    }
+    std::size_t held()
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        return m_held;
+    }
+
+private:
+    BigBlockCache()
+        : m_held(0)
+        , m_cap(std::size_t(3) << 30)
+    {
+        if (const char *e = getenv("FVB_HOST_CACHE_BYTES"))
+            m_cap = (std::size_t)strtoull(e, nullptr, 10);
+    }
+    ~BigBlockCache()
+    {
+        for (std::size_t i = 0; i < m_free.size(); i++)
+            free(m_free[i].first);
+    }
+    std::mutex m_mu;
+    std::vector<std::pair<void *, std::size_t> > m_free;
+    std::size_t m_held, m_cap;
+};
+
 // Storage that can be sized WITHOUT being written: value-initialising the 168 MB result image of a million voxels (or
 // the 800 MB of a series) touches every page from one thread before the real contents overwrite them.
 template <class T>
@@ -188,8 +264,10 @@ struct DefaultInitAllocator : std::allocator<T>
         const std::size_t bytes = n * sizeof(T);
         if (bytes < BIG)
             return std::allocator<T>::allocate(n);
-        void *p = nullptr;
         const std::size_t rounded = (bytes + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
+        void *p = BigBlockCache::instance().take(rounded);
+        if (p)
+            return static_cast<T *>(p);
         if (posix_memalign(&p, HUGE_PAGE, rounded) != 0)
             throw std::bad_alloc();
 #ifdef MADV_HUGEPAGE
@@ -201,7 +279,7 @@ struct DefaultInitAllocator : std::allocator<T>
     {
         if (n * sizeof(T) < BIG)
             std::allocator<T>::deallocate(p, n);
-        else
+        else if (!BigBlockCache::instance().give(p, (n * sizeof(T) + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1)))
             free(p);
     }
     template <class U>

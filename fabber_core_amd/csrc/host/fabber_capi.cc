@@ -143,6 +143,11 @@ void fabber_destroy(void *fab)
     }
 }
 
+void fabber_amd_trim_host_cache(unsigned long long keep_bytes)
+{
+    NEWMAT::BigBlockCache::instance().trim((size_t)keep_bytes);
+}
+
 int fabber_set_opt(void *fab, const char *key, const char *value, char *err_buf)
 {
     if (!fab)

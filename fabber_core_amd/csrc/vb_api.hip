@@ -747,7 +747,44 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
 {
     FVB_HIP_CHECK(hipSetDevice(device));
     const int V = cfg->n_voxels;
-    const int n_blocks = (V + block_voxels - 1) / block_voxels;
+    // The blocks: the upload is about twice as fast as the fit (56 GB/s of series against ~75 voxels/us on C3), so after
+    // the first block the fits are what the call waits for - the first block is as small as fills the chip once (its
+    // upload is the pipeline's fill, nothing overlaps it), the last one too (its download is the drain), the ones in
+    // between the nominal size: a block more than twice its predecessor is still going up when that one's fit ends
+    // (measured on C3, tools/measure/host_pipeline.py: 131072 / 262144 / 262144 / 213568 / 131072 voxels 23.1 ms,
+    // four equal blocks 23.9, 131072 / 368960 / 368896 / 131072 25.1). FVB_HOST_BLOCK_SCHEDULE=a,b,c,... (voxels per
+    // block, the last one takes the rest) overrides it for experiments.
+    std::vector<int> bounds(1, 0);
+    if (const char *sched = getenv("FVB_HOST_BLOCK_SCHEDULE"))
+    {
+        for (const char *p = sched; *p && bounds.back() < V;)
+        {
+            const int n = std::max(64, atoi(p) / 64 * 64);
+            bounds.push_back(std::min(V, bounds.back() + n));
+            while (*p && *p != ',')
+                p++;
+            if (*p == ',')
+                p++;
+        }
+        if (bounds.back() < V)
+            bounds.push_back(V);
+    }
+    else
+    {
+        const int edge = std::max(64, block_voxels / 2 / 64 * 64);
+        if (V >= 2 * edge + block_voxels)
+        {
+            const int middle = (V - edge) / 64 * 64 - edge; // (every block but the last is whole wavefronts)
+            bounds.push_back(edge);
+            for (int done = 0; done < middle; done += block_voxels)
+                bounds.push_back(edge + std::min(middle, done + block_voxels));
+            bounds.push_back(V);
+        }
+        else
+            for (int v = block_voxels; bounds.back() < V; v += block_voxels)
+                bounds.push_back(std::min(V, v));
+    }
+    const int n_blocks = (int)bounds.size() - 1;
     const int n_unmasked = count_unmasked(cfg, cfg->phi_index);
     // (two streams take the blocks' kernels in turn: the first wavefronts of block b + 1 move into the SIMDs the last
     // stragglers of block b have left, instead of every block paying for its own tail)
@@ -760,14 +797,17 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     std::mutex lock;
     std::condition_variable cv;
     int launched = 0;       // blocks whose fit has been enqueued
+    int released = 0;       // blocks whose buffers have gone back to the pool
     bool abandoned = false; // the uploading side failed: no more blocks will come
     int rc_down = 0;
     std::string err_down;
     std::thread downloader([&] {
         if (hipSetDevice(device) != hipSuccess)
         {
+            std::unique_lock<std::mutex> hold(lock);
             rc_down = -32;
             err_down = "cannot select the device in the download thread";
+            cv.notify_all();
             return;
         }
         for (int b = 0; b < n_blocks; b++)
@@ -779,24 +819,32 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
                     return;
             }
             const int rc = blocks[(size_t)b]->stage_out(s_down);
+            std::unique_lock<std::mutex> hold(lock);
             if (rc && rc_down == 0)
             {
                 rc_down = rc;
                 err_down = g_last_error; // thread-local: carry it to the caller's thread
             }
-            std::unique_lock<std::mutex> hold(lock);
             blocks[(size_t)b].reset(); // (its buffers go back to the pool: at most three blocks are resident)
+            released = b + 1;
+            cv.notify_all();
         }
     });
     int rc = 0;
     for (int b = 0; b < n_blocks && rc == 0; b++)
     {
+        {
+            // at most three blocks hold device buffers at once (with copies that really are asynchronous - buffers the
+            // caller pinned - this loop would otherwise stage the whole problem before the first download ends)
+            std::unique_lock<std::mutex> hold(lock);
+            cv.wait(hold, [&] { return b - released < 3 || rc_down != 0; });
+        }
         std::unique_ptr<HostBlock> blk(new HostBlock);
         blk->cfg = cfg;
         blk->data = data;
         blk->out = out;
-        blk->v0 = b * block_voxels;
-        blk->v1 = std::min(V, (b + 1) * block_voxels);
+        blk->v0 = bounds[(size_t)b];
+        blk->v1 = bounds[(size_t)b + 1];
         blk->kernel_voxels = V;
         rc = blk->stage_in(s_up);
         if (rc == 0)

@@ -71,6 +71,12 @@ int fabber_model_evaluate(void *fab, unsigned int n_params, float *params, unsig
 int fabber_model_evaluate_output(void *fab, unsigned int n_params, float *params, unsigned int n_ts, float *indata,
     const char *output_name, float *output, char *err_buf);
 
+/* ---- not in the reference's header ----
+ * The host library keeps the big image buffers of a finished run (up to FVB_HOST_CACHE_BYTES, default 3 GiB) for the
+ * next one instead of unmapping ~1 GB in fabber_destroy and faulting it in again in the next fabber_set_data /
+ * fabber_dorun. This gives back everything beyond keep_bytes. */
+void fabber_amd_trim_host_cache(unsigned long long keep_bytes);
+
 #ifdef __cplusplus
 }
 #endif

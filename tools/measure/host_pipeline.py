@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--calls", type=int, default=5)
     ap.add_argument("--voxels", type=int, default=1_000_000)
     ap.add_argument("--once", type=int, default=None)
+    ap.add_argument("--schedules", default="", help="semicolon-separated FVB_HOST_BLOCK_SCHEDULE values to try after the block sizes")
     a = ap.parse_args()
     import cases
     from fabber_core_amd import hiplib
@@ -42,6 +43,17 @@ def main():
             ts.append((time.perf_counter() - t0) * 1e3)
         out[b] = {"min_ms": float(np.min(ts)), "mean_ms": float(np.mean(ts))}
         print(b, out[b], flush=True)
+    for sched in [x for x in a.schedules.split(";") if x]:
+        os.environ["FVB_HOST_BLOCK_SCHEDULE"] = sched
+        hiplib.run_host(h, y, into=res)
+        ts = []
+        for _ in range(a.calls):
+            t0 = time.perf_counter()
+            hiplib.run_host(h, y, into=res)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[sched] = {"min_ms": float(np.min(ts)), "mean_ms": float(np.mean(ts))}
+        print("schedule", sched, out[sched], flush=True)
+    os.environ.pop("FVB_HOST_BLOCK_SCHEDULE", None)
     print(json.dumps(out))
 
 
