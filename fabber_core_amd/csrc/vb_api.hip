@@ -393,6 +393,31 @@ void api_release_pools(uint64_t keep_bytes)
 }
 } // namespace fvb
 
+__global__ __launch_bounds__(64) void device_math_kernel(int what, int n, const double *in, double *out)
+{
+    __shared__ double exp_tab[64];
+    exp_tab[threadIdx.x] = FVB_EXP_TABLE[threadIdx.x]; // (as the kernels that use exp_acc do: vb_spatial.h)
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n)
+        return;
+    if (what == 0)
+        out[i] = exp_acc(in[i], exp_tab);
+    else if (what == 1)
+        out[i] = exp(in[i]);
+    else
+    {
+        double a[10], r[10], logabs;
+        int sign;
+        for (int k = 0; k < 10; k++)
+            a[k] = in[(size_t)i * 10 + k];
+        const bool ok = mvn_invert<4>(a, r, logabs, sign);
+        for (int k = 0; k < 10; k++)
+            out[(size_t)i * 11 + k] = ok ? r[k] : __builtin_nan("");
+        out[(size_t)i * 11 + 10] = logabs;
+    }
+}
+
 extern "C" {
 
 int32_t fabber_vb_mvn_rows(int32_t n)
@@ -1102,6 +1127,31 @@ double fabber_vb_transform(int32_t which, int32_t tr, double x)
     default:
         return to_fabber_var(tr, x);
     }
+}
+
+// The same building blocks evaluated ON THE DEVICE (tests/test_hip_parity.py: the kernels are compiled with
+// contraction allowed, so the error-free transforms inside exp_acc and the frexp-product log-determinant are checked
+// as the device compiles them, not only through their host twin). what: 0 exp_acc with its table in LDS as the
+// kernels keep it, 1 the device library's exp, 2 mvn_invert<4> of the packed 4 x 4 matrix at in[10 i ..]: out[11 i ..]
+// = the packed inverse and log|det|. Host pointers; n values / matrices.
+int32_t fabber_vb_device_math(int32_t what, int32_t n, const double *in, double *out)
+{
+    if (fabber_vb_device_count() <= 0)
+        return fail(-30, "no HIP device available");
+    if (n <= 0 || !in || !out || what < 0 || what > 2)
+        return fail(-60, "fabber_vb_device_math: bad arguments");
+    const size_t n_in = (size_t)n * (what == 2 ? 10 : 1), n_out = (size_t)n * (what == 2 ? 11 : 1);
+    double *d_in = nullptr, *d_out = nullptr;
+    FVB_HIP_CHECK(hipMalloc(&d_in, sizeof(double) * n_in));
+    FVB_HIP_CHECK(hipMalloc(&d_out, sizeof(double) * n_out));
+    FVB_HIP_CHECK(hipMemcpy(d_in, in, sizeof(double) * n_in, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(device_math_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, what, n, (const double *)d_in, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return e == hipSuccess ? 0 : fail(-100 - (int)e, hipGetErrorString(e));
 }
 
 // Host twin of the in-register LDL^T inverse for P = 1..6 (unit test of vb_math.h)

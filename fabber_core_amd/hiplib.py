@@ -268,6 +268,20 @@ def convergence_trace(conv, F, max_iterations=10, max_trials=10, min_fchange=0.0
     return done[:m].astype(bool), save[:m].astype(bool), revert[:m].astype(bool), alpha[:m]
 
 
+def device_math(what, values):
+    """Building blocks of vb_math.h evaluated on the device (fabber_vb_device_math): what = "exp_acc" | "exp" on a
+    vector, or "invert4" on packed 4 x 4 symmetric matrices [n][10] -> (packed inverses [n][10], log|det| [n])."""
+    L = lib()
+    L.fabber_vb_device_math.restype = C.c_int32
+    L.fabber_vb_device_math.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    x = np.ascontiguousarray(values, dtype=np.float64)
+    code = {"exp_acc": 0, "exp": 1, "invert4": 2}[what]
+    n = x.shape[0]
+    out = np.empty((n, 11) if code == 2 else n)
+    _check(L.fabber_vb_device_math(code, n, x.ctypes.data, out.ctypes.data))
+    return (out[:, :10], out[:, 10]) if code == 2 else out
+
+
 def ldl_inverse(a):
     """Host twin of the in-register LDL^T inverse; a: symmetric PxP. Returns (inv, logabs, sign, ok)."""
     a = np.asarray(a, dtype=np.float64)

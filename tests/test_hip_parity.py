@@ -502,3 +502,46 @@ def test_c4_model_properties_at_two_million_voxels():
     assert hiplib.kernel_name(h) == "lane_ar1<linear,4>"
     _full_size_properties(h, y, lambda n: cases.linear_problem(n, 200, seed=1, max_iterations=10, noise=vbabi.NOISE_AR1)[0],
                           "C4 model 2e6", sample=2048)
+
+
+@gpu
+def test_math_building_blocks_as_the_device_compiles_them():
+    """The kernels are compiled with floating-point contraction allowed. exp_acc's compensated reduction
+    and the frexp-product log-determinant of the symmetric sweep are error-free-transform idioms that contraction can
+    change, and tests/test_math_host.py only sees their HOST twin: here the device code itself, against long double /
+    NumPy and against the twin."""
+    rng = np.random.default_rng(77)
+    x = np.concatenate([rng.uniform(-40, 40, 20000), rng.uniform(-1e-3, 1e-3, 2000), [0.0, -0.0, 700.0, -700.0, 709.0, -745.0]])
+    got = hiplib.device_math("exp_acc", x)
+    truth = np.exp(x.astype(np.longdouble))
+    ulp = np.spacing(np.abs(truth.astype(np.float64)))
+    err = np.abs((got.astype(np.longdouble) - truth) / ulp.astype(np.longdouble)).astype(np.float64)
+    assert err.max() < 0.55, err.max()  # (0.52 ulp measured for the host twin; the device library's exp: ~1 ulp)
+    L = hiplib.lib()
+    twin = np.array([L.fabber_vb_exp_acc(float(v)) for v in x[:4000]])
+    assert np.array_equal(twin, got[:4000])  # the same bits as the host twin
+    lib_err = np.abs((hiplib.device_math("exp", x).astype(np.longdouble) - truth) / ulp.astype(np.longdouble)).astype(np.float64)
+    assert 0.5 < lib_err.max() <= 1.0 + 1e-9  # (what DESIGN 5.4 says of the device library's exp: a 1-ulp exp)
+    special = hiplib.device_math("exp_acc", np.array([np.nan, np.inf, -np.inf]))
+    assert np.isnan(special[0]) and special[1] == np.inf and special[2] == 0.0
+    # the symmetric sweep and its log-determinant (one logarithm of the pivots' product, exponents apart)
+    mats, packed = [], []
+    for i in range(500):
+        B = rng.standard_normal((7, 4)) * 10.0 ** rng.uniform(-3, 3, 4)
+        a = B.T @ B + 1e-9 * np.eye(4)
+        mats.append(a)
+        packed.append([a[r, c] for r in range(4) for c in range(r + 1)])
+    inv, logdet = hiplib.device_math("invert4", np.array(packed))
+    for a, ip, ld in zip(mats, inv, logdet):
+        ref = np.linalg.inv(a)
+        full = np.zeros((4, 4))
+        k = 0
+        for r in range(4):
+            for c in range(r + 1):
+                full[r, c] = full[c, r] = ip[k]
+                k += 1
+        cond = np.linalg.cond(a)
+        assert np.max(np.abs(full - ref)) <= 1e-13 * cond * np.max(np.abs(ref)) + 1e-300
+        assert abs(ld - np.linalg.slogdet(a)[1]) <= 1e-12 * max(1.0, abs(ld))
+        tw_inv, tw_ld, _, ok = hiplib.ldl_inverse(a)
+        assert ok and abs(tw_ld - ld) <= 4e-16 * max(1.0, abs(ld))
