@@ -46,6 +46,7 @@ struct SpatialArgs
     KernelArgs ka;
     double *state;          // [SpLayout<P>::ROWS][V]
     const int32_t *nn;      // [V][6] first neighbours (0-based, -1 = none), reference order
+    const int32_t *nn_dir;  // [V] which offset (+x -x +y -y +z -z = 0 .. 5) each list slot was found with, 3 bits per slot
     const int32_t *order;   // voxel ids sorted by level
     double *aK;             // [P] smoothing precision per (spatial) parameter
     double *partials;       // [n_blocks][P][2] reduction scratch: one entry per SEGMENT of the voxel list
@@ -74,15 +75,18 @@ struct SpatialArgs
     int32_t n_pos;           // positions (padded to a multiple of 16)
     int32_t n_spatial;       // parameters of types M, m ...
     int32_t spatial_param[FVB_MAX_PARAMS]; // ... and which they are
-    double *sw_x;            // [n_spatial][n_pos] means of those parameters, swept in place
-    double *sw_pm;           // [n_spatial][n_pos] their prior means as the sweep left them
-    double *sw_rhs0;         // [P][n_pos] eq (20) right-hand side: complete where it needs no neighbour, else its base
-    double *sw_pprec;        // [n_spatial][n_pos] prior precision of the spatial parameter
+    double *sw_x;            // [n_spatial][n_pos] OUT: the new means of those parameters
+    double *sw_pm;           // [n_spatial][n_pos] OUT: their prior means
+    // the record of a voxel, eq (20) for a swept parameter k with the terms of the OTHER parameters summed already:
+    //   m_k = fma(Sig_kk', rhs_k', ...fma(Sig_kk, rhs_k, pre_k)),  rhs_k = fma(pprec_k, mu0_k, base_k)  (k, k': swept)
+    double *sw_pre;          // [n_spatial][n_pos] sum over the parameters that are not swept of Sig_kj rhs_j (index order)
+    double *sw_rhsk;         // [n_spatial][n_pos] base_k
+    double *sw_pprec;        // [n_spatial][n_pos] prior precision of the swept parameter
     double *sw_q;            // [n_spatial][n_pos] (1 / prior precision) x spatial precision
-    double *sw_rec;          // [n_spatial][n_pos] 1 / number of live neighbours
-    double *sw_sig;          // [n_spatial][P][n_pos] the spatial parameters' rows of Sigma
-    int32_t *sw_npos;        // [6][n_pos] positions of the live first neighbours, -1 = none
-    int32_t *sw_alive;       // [n_pos] 1 = the voxel takes part in the sweep
+    double *sw_sigk;         // [n_spatial][n_spatial][n_pos] Sig_kk'
+    double *sw_nbr;          // [n_spatial][3][n_pos] the means the +x, +y, +z neighbours had BEFORE the sweep (+0.0: none)
+    int32_t *sw_npos;        // [4][n_pos] positions of the -x, -y, -z and +z neighbours, -1 = none
+    int32_t *sw_alive;       // [n_pos] 0 = the voxel takes no part in the sweep, else 1 + its number of live neighbours
     // positions are slab-major, a slab = sl_dz z-planes, inside a slab level-major (level = x + y + z): the voxels of
     // one (slab, level) are a contiguous RUN; sl_first_run[s] .. sl_first_run[s + 1] are slab s's runs
     const int32_t *sw_level_pos;   // [n_runs] first position of a run
@@ -96,7 +100,6 @@ struct SpatialArgs
     const int32_t *sl_first_run; // [n_slabs + 1]
     int32_t sl_width;        // lanes that work on one run (a multiple of 64 that divides 1024)
     int32_t sl_max_run;      // longest run (the LDS buffers hold two of them per spatial parameter)
-    double *sw_nbr;          // [n_spatial][6][n_pos] the neighbours' means BEFORE the sweep (what a later neighbour contributes)
     // the prep kernel walks the volume in tiles of 8 x 8 voxels of a plane (tile_nx x tile_ny tiles per plane, planes
     // tile_z0 ...): the voxel at (x, y, z) is dense[z xsize ysize + y xsize + x - dense_base], -1 = none. 0 tiles: in
     // index order, 64 consecutive voxels per wavefront
@@ -285,6 +288,48 @@ __device__ __forceinline__ bool is_swept_type(int t)
 __device__ __forceinline__ bool sp_precise(const SpatialArgs &sa)
 {
     return sa.it + 1 < sa.ka.precise_passes;
+}
+
+// eq (20) for a parameter whose prior mean waits for its neighbours (types M, m): the terms of the parameters that do
+// NOT wait first (index order), then those that do (index order) - the split form's prep kernel sums the first group
+// ahead of the ordered sweep (sw_pre), and every form of the first sweep must round alike.
+template <int P>
+__device__ __forceinline__ double theta_mean_swept_last(const double (&Sig)[P * (P + 1) / 2], const double (&rhs)[P], int i, const int32_t *types)
+{
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        s = is_swept_type(types[j]) ? s : __builtin_fma(Sig[tri(i, j)], rhs[j], s);
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        s = is_swept_type(types[j]) ? __builtin_fma(Sig[tri(i, j)], rhs[j], s) : s;
+    return s;
+}
+
+// update_theta (vb_lane_kernel.h) without the LM form (LMalpha = 0 in the spatial loop), the swept parameters' means in
+// the order above
+template <int P>
+__device__ __forceinline__ bool sp_update_theta(const KernelArgs &ka, VoxelState<P> &st, const Moments<P> &mo)
+{
+    const double phibar = st.b * st.c;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            st.Lam[tri(i, j)] = phibar * mo.A[tri(i, j)] + ((i == j) ? st.pprec[i] : 0.0); // eq (19)
+    st.precValid = true;
+    st.covValid = false;
+    double rhs[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        rhs[i] = theta_rhs(theta_rhs_base<P>(phibar, mo, i), st.pprec[i], st.pm[i]);
+    if (!ensure_cov<P>(st))
+        return false;
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        st.m[i] = is_swept_type(ka.cfg.prior_type[i]) ? theta_mean_swept_last<P>(st.Sig, rhs, i, ka.cfg.prior_type)
+                                                       : theta_mean<P>(st.Sig, rhs, i); // eq (20)
+    return true;
 }
 
 // The noise model seen from the FIRST sweep (inference_vb.cc:643-651). UpdateTheta needs J'XJ and J'X(y - g) only, and
@@ -710,7 +755,7 @@ __global__ __launch_bounds__(64) void vb_spatial_theta_kernel(const SpatialArgs 
         }
     }
     int status = FVB_OK;
-    if (!update_theta<P>(st, mo, 0.0)) // LMalpha = 0 in the spatial loop (:649)
+    if (!sp_update_theta<P>(ka, st, mo)) // LMalpha = 0 in the spatial loop (:649)
         status = FVB_BAD_RESULT;
     if (NEEDF && status == FVB_OK)
     {
@@ -828,14 +873,27 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     Moments<P> mo;
     sp_load_prep<P, NEEDF>(sa, v, st, mo);
     const int dims = sa.spatial_dims;
+    // the listed neighbours BY DIRECTION (+x -x +y -y +z -z, the order the reference finds them in): slot d holds the
+    // neighbour found with offset d, or the voxel itself marked dead; a sum over d = 0 .. 5 that adds +0.0 for a dead
+    // slot is the sum over the list in list order, bit for bit
     int n1[6];
     bool live1[6];
-#pragma unroll
-    for (int a = 0; a < 6; a++)
     {
-        const int u = sa.nn[(size_t)v * 6 + a];
-        n1[a] = (u < 0) ? v : u;
-        live1[a] = (u >= 0);
+        const int dir = sa.nn_dir[v];
+        int listed[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+            listed[a] = sa.nn[(size_t)v * 6 + a];
+#pragma unroll
+        for (int d = 0; d < 6; d++)
+        {
+            int u = -1;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+                u = (((dir >> (3 * a)) & 7) == d) ? listed[a] : u;
+            n1[d] = (u < 0) ? v : u;
+            live1[d] = (u >= 0);
+        }
     }
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -871,12 +929,10 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
             {
                 sa.sw_pprec[si * NP + pos] = st.pprec[k];
                 sa.sw_q[si * NP + pos] = pcov * spatial_prec;
-                sa.sw_rec[si * NP + pos] = 1 / double(nn);
-                sa.sw_x[si * NP + pos] = st.m[k];
-                // what each neighbour contributes if the sweep reaches it AFTER this voxel: its mean now
+                // what the +x, +y, +z neighbours contribute - the sweep reaches them AFTER this voxel -: their means now
 #pragma unroll
-                for (int a = 0; a < 6; a++)
-                    sa.sw_nbr[((size_t)si * 6 + a) * NP + pos] = live1[a] ? sa.state[(size_t)(L::M + k) * V + n1[a]] : 0.0;
+                for (int a = 0; a < 3; a++)
+                    sa.sw_nbr[((size_t)si * 3 + a) * NP + pos] = live1[2 * a] ? sa.state[(size_t)(L::M + k) * V + n1[2 * a]] : 0.0;
             }
             si++;
         }
@@ -943,28 +999,39 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
     }
     if (sa.n_spatial > 0) // (uniform) the records of the ordered sweep
     {
+        const size_t ns = (size_t)sa.n_spatial;
+        double rhs[P];
+#pragma unroll
+        for (int k = 0; k < P; k++)
+            rhs[k] = theta_rhs(theta_rhs_base<P>(phibar, mo, k), st.pprec[k], st.pm[k]); // (complete where k is not swept)
         si = 0;
 #pragma unroll
         for (int k = 0; k < P; k++)
-        {
-            const double base = theta_rhs_base<P>(phibar, mo, k);
-            const int type = ka.cfg.prior_type[k];
-            if (is_swept_type(type))
+            if (is_swept_type(ka.cfg.prior_type[k]))
             {
-                sa.sw_rhs0[k * NP + pos] = base;
+                double pre = 0; // theta_mean_swept_last's first group
 #pragma unroll
                 for (int j = 0; j < P; j++)
-                    sa.sw_sig[((size_t)si * P + j) * NP + pos] = st.Sig[tri(k, j)];
+                    pre = is_swept_type(ka.cfg.prior_type[j]) ? pre : __builtin_fma(st.Sig[tri(k, j)], rhs[j], pre);
+                sa.sw_pre[si * NP + pos] = pre;
+                sa.sw_rhsk[si * NP + pos] = theta_rhs_base<P>(phibar, mo, k);
+                int sj = 0;
+#pragma unroll
+                for (int j = 0; j < P; j++)
+                    if (is_swept_type(ka.cfg.prior_type[j]))
+                    {
+                        sa.sw_sigk[((size_t)si * ns + sj) * NP + pos] = st.Sig[tri(k, j)];
+                        sj++;
+                    }
                 si++;
             }
-            else
-                sa.sw_rhs0[k * NP + pos] = theta_rhs(base, st.pprec[k], st.pm[k]);
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-            sa.sw_npos[a * NP + pos] = live1[a] ? sa.pos_of[n1[a]] : -1;
+        // where the sweep finds the -x, -y, -z neighbours' NEW means (positions), and whose inbox the +z neighbour's is
+        sa.sw_npos[0 * NP + pos] = live1[1] ? sa.pos_of[n1[1]] : -1;
+        sa.sw_npos[1 * NP + pos] = live1[3] ? sa.pos_of[n1[3]] : -1;
+        sa.sw_npos[2 * NP + pos] = live1[5] ? sa.pos_of[n1[5]] : -1;
+        sa.sw_npos[3 * NP + pos] = live1[4] ? sa.pos_of[n1[4]] : -1;
     }
-    sa.sw_alive[pos] = 1;
+    sa.sw_alive[pos] = 1 + nn_live;
     // the posterior's new covariance and the priors are final here (the state's means stay the OLD ones
     // until the noise kernel has seen them: F "before" is evaluated with them)
     {
@@ -993,41 +1060,41 @@ __global__ __launch_bounds__(64) void vb_spatial_prep_kernel(const SpatialArgs *
 // contribute the means they had BEFORE the sweep; the prep kernel has put those next to the record (sw_nbr).
 // 1024 lanes = G groups of sl_width lanes; group g takes the runs g, g + G, ... of the slab and requests its
 // next record (and its inbox) right after finishing one: G levels of time to arrive.
-template <int P, int NS>
+template <int NS>
 struct SlabRecord
 {
-    int alive;
-    int np[6];
-    double rhs0[P];
-    double pprec[NS], q[NS], rec[NS];
-    double sig[NS][P];
-    double nbr[NS][6];
+    int alive;  // 0, or 1 + the number of live neighbours
+    int np[4];  // positions of the -x, -y, -z, +z neighbours (-1 none, FVB_NP_BELOW / FVB_NP_ABOVE: on another device)
+    double pre[NS], rhsk[NS], pprec[NS], q[NS];
+    double sigk[NS][NS];
+    double nbr[NS][3];
     unsigned long long in_lo[NS], in_hi[NS];
     __device__ __forceinline__ void load(const SpatialArgs &sa, int pos, int ns)
     {
+        // every load unconditional (a lane without a voxel reads position 0 and ignores it): a load that had to
+        // wait for the `alive` word first would cost the step a second memory round trip
         const size_t NP = (size_t)sa.n_pos;
         const bool have = pos >= 0;
         pos = have ? pos : 0;
         const int alive_word = sa.sw_alive[pos];
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+        for (int a = 0; a < 4; a++)
             np[a] = sa.sw_npos[a * NP + pos];
-#pragma unroll
-        for (int j = 0; j < P; j++)
-            rhs0[j] = sa.sw_rhs0[j * NP + pos];
 #pragma unroll
         for (int s = 0; s < NS; s++)
             if (s < ns)
             {
+                pre[s] = sa.sw_pre[s * NP + pos];
+                rhsk[s] = sa.sw_rhsk[s * NP + pos];
                 pprec[s] = sa.sw_pprec[s * NP + pos];
                 q[s] = sa.sw_q[s * NP + pos];
-                rec[s] = sa.sw_rec[s * NP + pos];
 #pragma unroll
-                for (int j = 0; j < P; j++)
-                    sig[s][j] = sa.sw_sig[((size_t)s * P + j) * NP + pos];
+                for (int s2 = 0; s2 < NS; s2++)
+                    if (s2 < ns)
+                        sigk[s][s2] = sa.sw_sigk[((size_t)s * ns + s2) * NP + pos];
 #pragma unroll
-                for (int a = 0; a < 6; a++)
-                    nbr[s][a] = sa.sw_nbr[((size_t)s * 6 + a) * NP + pos];
+                for (int a = 0; a < 3; a++)
+                    nbr[s][a] = sa.sw_nbr[((size_t)s * 3 + a) * NP + pos];
                 const unsigned long long *g = sa.sw_gran + ((size_t)s * NP + pos) * 2;
                 if (sa.sl_remote) // (wave-uniform)
                 {
@@ -1042,21 +1109,20 @@ struct SlabRecord
             }
         alive = have ? alive_word : 0;
     }
+    // the -z neighbour lives in the slab below (another workgroup, or another device): its new mean arrives in the inbox
+    __device__ __forceinline__ bool from_below(int slab_begin) const
+    {
+        return ((np[2] >= 0) && (np[2] < slab_begin)) || (np[2] == FVB_NP_BELOW);
+    }
 };
 
 // A voxel whose z-1 neighbour lives in the slab below waits here until its inbox holds THIS sweep's value. The
 // inbox was requested with the record; a workgroup's groups reach their turn several levels early, so a value that
 // was not there yet is polled for while the levels before this one are still being worked on.
-template <int P, int NS>
-__device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecord<P, NS> &r, int pos, int ns, int slab_begin)
+template <int NS>
+__device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecord<NS> &r, int pos, int ns, int slab_begin)
 {
-    if (!r.alive)
-        return;
-    bool from_below = false; // (at most one neighbour)
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-        from_below |= ((r.np[a] >= 0) && (r.np[a] < slab_begin)) || (r.np[a] == FVB_NP_BELOW);
-    if (!from_below)
+    if (!r.alive || !r.from_below(slab_begin))
         return;
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
@@ -1093,59 +1159,61 @@ __device__ __forceinline__ void slab_wait_inbox(const SpatialArgs &sa, SlabRecor
 }
 
 // one voxel of the run [begin, begin + count): slot = its index in the run. prev_* = the slab's previous run
-// (its means are in lds_prev), slab_begin / slab_end = the slab's positions. Straight-line code: a workgroup has
-// two to eight waves at work on a level, so every instruction's latency is on the chain; the six neighbours are
-// selected, not branched on (a missing neighbour adds the +0.0 the prep kernel stored for it: x + 0.0 is x, and
-// the sum starts from +0.0, so it is the sum over the live neighbours bit for bit).
-// The part of a step that the NEXT level waits for: neighbours' means -> this voxel's mean in LDS. Returns the
-// means and prior means; slab_store writes them to memory after the level's barrier.
-template <int P, int NS>
-__device__ __forceinline__ void slab_step(const SpatialArgs &sa, SlabRecord<P, NS> &r, int pos, int slot, int ns, int prev_begin,
-    int prev_count, int slab_begin, const double *lds_prev, double *lds_cur, int lds_stride, double (&m_out)[NS], double (&pm_out)[NS])
+// (its means are in lds_prev), slab_begin = the slab's first position. Straight-line code: a workgroup has
+// two to eight waves at work on a level, so every instruction's latency is on the chain; the six directions are
+// selected, not branched on (a direction without a live neighbour adds +0.0: x + 0.0 is x, and the sum starts from
+// +0.0, so it is the sum over the listed neighbours in list order bit for bit).
+// rec_tab: 1 / n for n = 0 .. 6 (LDS). This is the part of a step that the NEXT level waits for: neighbours' means ->
+// this voxel's mean in LDS; slab_store writes the means and prior means to memory after the level's counter.
+template <int NS>
+__device__ __forceinline__ void slab_step(const SpatialArgs &sa, SlabRecord<NS> &r, int slot, int ns, int prev_begin, int prev_count,
+    int slab_begin, const double *rec_tab, const double *lds_prev, double *lds_cur, int lds_stride, double (&m_out)[NS], double (&pm_out)[NS])
 {
-    const size_t NP = (size_t)sa.n_pos;
-    const unsigned long long serial = sa.sw_serial;
-    double rhs[P];
+    double rhs[NS];
+    bool in_prev[3];
+    int off[3];
 #pragma unroll
-    for (int j = 0; j < P; j++)
-        rhs[j] = r.rhs0[j];
+    for (int a = 0; a < 3; a++)
+    {
+        const unsigned o = (unsigned)(r.np[a] - prev_begin);
+        in_prev[a] = o < (unsigned)prev_count;
+        off[a] = in_prev[a] ? (int)o : 0;
+    }
+    const bool below = r.from_below(slab_begin);
 #pragma unroll
     for (int s = 0; s < NS; s++)
         if (s < ns)
         {
+            const int k = sa.spatial_param[s];
+            const bool dirichlet = sa.ka.cfg.prior_type[k] == FVB_PRIOR_SPATIAL_m; // (uniform)
+            const double rec = rec_tab[dirichlet ? 2 * sa.spatial_dims : r.alive - 1];
             const double val_in = __longlong_as_double((long long)((r.in_hi[s] << 32) | (r.in_lo[s] & 0xffffffffull)));
-            double from_lds[6];
-            bool in_prev[6];
+            double earlier[3];
 #pragma unroll
-            for (int a = 0; a < 6; a++)
-            {
-                const unsigned off = (unsigned)(r.np[a] - prev_begin);
-                in_prev[a] = off < (unsigned)prev_count;
-                from_lds[a] = lds_prev[s * lds_stride + (in_prev[a] ? (int)off : 0)];
-            }
-            double contrib = 0;
+            for (int a = 0; a < 3; a++)
+                earlier[a] = in_prev[a] ? lds_prev[s * lds_stride + off[a]] : 0.0;
+            earlier[2] = below ? val_in : earlier[2];
+            double contrib = 0; // +x -x +y -y +z -z
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+            for (int a = 0; a < 3; a++)
             {
-                const bool below = ((r.np[a] >= 0) && (r.np[a] < slab_begin)) || (r.np[a] == FVB_NP_BELOW);
-                contrib += in_prev[a] ? from_lds[a] : (below ? val_in : r.nbr[s][a]);
+                contrib += r.nbr[s][a];
+                contrib += earlier[a];
             }
-            const double spatial_mean = contrib * r.rec[s];
+            const double spatial_mean = contrib * rec;
             const double pm = r.q[s] * spatial_mean;
             pm_out[s] = pm;
-            const int k = sa.spatial_param[s];
-#pragma unroll
-            for (int j = 0; j < P; j++)
-                rhs[j] = (j == k) ? theta_rhs(rhs[j], r.pprec[s], pm) : rhs[j];
+            rhs[s] = theta_rhs(r.rhsk[s], r.pprec[s], pm);
         }
 #pragma unroll
     for (int s = 0; s < NS; s++)
         if (s < ns)
         {
-            double m = 0;
+            double m = r.pre[s];
 #pragma unroll
-            for (int j = 0; j < P; j++)
-                m = __builtin_fma(r.sig[s][j], rhs[j], m);
+            for (int s2 = 0; s2 < NS; s2++)
+                if (s2 < ns)
+                    m = __builtin_fma(r.sigk[s][s2], rhs[s2], m);
             lds_cur[s * lds_stride + slot] = m;
             m_out[s] = m;
         }
@@ -1153,21 +1221,14 @@ __device__ __forceinline__ void slab_step(const SpatialArgs &sa, SlabRecord<P, N
 
 // ... and the part nobody in the slab waits for: the mean into the inbox of the z+1 neighbour if that lives in the
 // slab above, mean and prior mean to memory for the kernels after this one
-template <int P, int NS>
-__device__ __forceinline__ void slab_store(const SpatialArgs &sa, const SlabRecord<P, NS> &r, int pos, int ns, int slab_end,
+template <int NS>
+__device__ __forceinline__ void slab_store(const SpatialArgs &sa, const SlabRecord<NS> &r, int pos, int ns, int slab_end,
     const double (&m)[NS], const double (&pm)[NS])
 {
     const size_t NP = (size_t)sa.n_pos;
     const unsigned long long serial = sa.sw_serial;
-    int above = -1;
-    bool ghost_above = false;
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-    {
-        above = (r.np[a] >= slab_end) ? r.np[a] : above;
-        ghost_above |= (r.np[a] == FVB_NP_ABOVE);
-    }
-    const int up = (ghost_above && sa.sw_gran_up) ? sa.sw_up_pos[pos] : -1;
+    const int above = (r.np[3] >= slab_end) ? r.np[3] : -1;
+    const int up = (r.np[3] == FVB_NP_ABOVE && sa.sw_gran_up) ? sa.sw_up_pos[pos] : -1;
 #pragma unroll
     for (int s = 0; s < NS; s++)
         if (s < ns)
@@ -1191,16 +1252,20 @@ __device__ __forceinline__ void slab_store(const SpatialArgs &sa, const SlabReco
         }
 }
 
-template <int P, int NS>
+template <int NS>
 __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const SpatialArgs sa)
 {
-    extern __shared__ double s_mem[]; // [2][ns][sl_max_run] means of the last two runs, then the slab's run table
+    extern __shared__ double s_mem[]; // 1 / n for n = 0 .. 7, [2][ns][sl_max_run] means of the last two runs, the slab's run table
     const int ns = sa.n_spatial;
     const int W = sa.sl_width, G = 1024 / W;
     const int g = threadIdx.x / W, lane = threadIdx.x % W; // (W is a multiple of 64: g is wave-uniform)
     const int stride = sa.sl_max_run;
     const int run0 = sa.sl_first_run[blockIdx.x], n_runs = sa.sl_first_run[blockIdx.x + 1] - run0;
-    int *tab = (int *)(s_mem + (size_t)2 * ns * stride); // [2][n_runs]: first position, count; then one counter
+    double *rec_tab = s_mem;
+    double *means = s_mem + 8;
+    int *tab = (int *)(means + (size_t)2 * ns * stride); // [2][n_runs]: first position, count; then one counter
+    if (threadIdx.x < 8)
+        rec_tab[threadIdx.x] = 1 / double(threadIdx.x); // (the prior's 1 / double(nn), priors.cc:445,450: inf for nn = 0)
     for (int i = threadIdx.x; i < n_runs; i += 1024)
     {
         tab[i] = sa.sw_level_pos[run0 + i];
@@ -1218,17 +1283,17 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
     // counter - the only thing a level waits for is the level before it.
     int *progress = tab + 2 * n_runs;
     const int waves_per_group = W / 64;
-    SlabRecord<P, NS> r;
+    SlabRecord<NS> r;
     if (g < n_runs)
         r.load(sa, lane < tab[n_runs + g] ? tab[g] + lane : -1, ns);
     for (int li = g; li < n_runs; li += G)
     {
         const int begin = tab[li], count = tab[n_runs + li];
         const int prev_begin = li > 0 ? tab[li - 1] : 0, prev_count = li > 0 ? tab[n_runs + li - 1] : 0;
-        const double *lds_prev = s_mem + (size_t)((li + 1) & 1) * ns * stride;
-        double *lds_cur = s_mem + (size_t)(li & 1) * ns * stride;
+        const double *lds_prev = means + (size_t)((li + 1) & 1) * ns * stride;
+        double *lds_cur = means + (size_t)(li & 1) * ns * stride;
         if (lane < count)
-            slab_wait_inbox<P, NS>(sa, r, begin + lane, ns, slab_begin);
+            slab_wait_inbox<NS>(sa, r, begin + lane, ns, slab_begin);
         // level li - 1 complete? (then level li - 2's means, which this level overwrites, have been read too)
         const int need = li * waves_per_group;
         while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
@@ -1237,24 +1302,24 @@ __global__ __launch_bounds__(1024) void vb_spatial_slab_sweep_kernel(const Spati
         double m[NS], pm[NS];
         const bool work = lane < count && r.alive;
         if (work)
-            slab_step<P, NS>(sa, r, begin + lane, lane, ns, prev_begin, prev_count, slab_begin, lds_prev, lds_cur, stride, m, pm);
+            slab_step<NS>(sa, r, lane, ns, prev_begin, prev_count, slab_begin, rec_tab, lds_prev, lds_cur, stride, m, pm);
         for (int i = lane + W; i < count; i += W) // (runs longer than the group is wide: 1024 lanes, one group)
         {
-            SlabRecord<P, NS> one;
+            SlabRecord<NS> one;
             one.load(sa, begin + i, ns);
             if (!one.alive)
                 continue;
-            slab_wait_inbox<P, NS>(sa, one, begin + i, ns, slab_begin);
+            slab_wait_inbox<NS>(sa, one, begin + i, ns, slab_begin);
             double m1[NS], pm1[NS];
-            slab_step<P, NS>(sa, one, begin + i, i, ns, prev_begin, prev_count, slab_begin, lds_prev, lds_cur, stride, m1, pm1);
-            slab_store<P, NS>(sa, one, begin + i, ns, slab_end, m1, pm1);
+            slab_step<NS>(sa, one, i, ns, prev_begin, prev_count, slab_begin, rec_tab, lds_prev, lds_cur, stride, m1, pm1);
+            slab_store<NS>(sa, one, begin + i, ns, slab_end, m1, pm1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0)
             __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // while the next group works: results to memory, then this group's next record
         if (work)
-            slab_store<P, NS>(sa, r, begin + lane, ns, slab_end, m, pm);
+            slab_store<NS>(sa, r, begin + lane, ns, slab_end, m, pm);
         const int nx = li + G;
         if (nx < n_runs)
             r.load(sa, lane < tab[n_runs + nx] ? tab[nx] + lane : -1, ns);
@@ -1478,8 +1543,8 @@ SpatialKernelFn spatial_noise_acc(bool need_f)
             need_f ? (SpatialPrepFn)vb_spatial_prep_kernel<PP, true> : (SpatialPrepFn)vb_spatial_prep_kernel<PP, false>, \
             need_f ? (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, true, true>                     \
                    : (SpatialKernelFn)vb_spatial_noise_kernel<MODEL<PP>, PP, false, true>,                   \
-            { vb_spatial_slab_sweep_kernel<PP, 1>, vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>,        \
-                vb_spatial_slab_sweep_kernel<PP, PP> }, 0,                                                   \
+            { vb_spatial_slab_sweep_kernel<1>, vb_spatial_slab_sweep_kernel<2>,                               \
+                vb_spatial_slab_sweep_kernel<(PP <= 4 ? 4 : 8)> }, 0,                                        \
             spatial_noise_acc<MODEL<PP>, PP, false>(need_f), spatial_noise_acc<MODEL<PP>, PP, true>(need_f) };
 
 } // namespace fvb

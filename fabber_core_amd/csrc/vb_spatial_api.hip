@@ -51,9 +51,14 @@ int sign_of(int x)
 
 // First-neighbour table in the reference's order (+x, -x, +y, -y, +z, -z, limited by
 // spatial-dims), -1 where there is no neighbour. Returns "" or an error message.
-std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector<int32_t> &nn)
+// dirs (optional): [V] which of the reference's six offsets (+x -x +y -y +z -z = 0 .. 5, inference_vb.cc:863-869) each
+// listed neighbour was found with, 3 bits per list slot (7 = none): the split sweep's records are laid out by
+// direction, and a sum over the listed neighbours in list order is then a sum over the directions in order
+std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector<int32_t> &nn, std::vector<int32_t> *dirs = nullptr)
 {
     nn.assign((size_t)V * 6, -1);
+    if (dirs)
+        dirs->assign((size_t)V, 0777777);
     if (V == 0)
         return "";
     const int32_t *X = coords, *Y = coords + V, *Z = coords + 2 * (size_t)V;
@@ -115,7 +120,11 @@ std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector
                     continue;
                 const int32_t found = dense[(size_t)rel];
                 if (found >= 0)
+                {
+                    if (dirs)
+                        (*dirs)[(size_t)v] = ((*dirs)[(size_t)v] & ~(7 << (3 * slot))) | (n << (3 * slot));
                     row[slot++] = found;
+                }
             }
         }
         return "";
@@ -152,6 +161,8 @@ std::string build_neighbours(const int32_t *coords, int V, int dims, std::vector
             while (row[slot] >= 0)
                 slot++;
             row[slot] = (int32_t)found;
+            if (dirs)
+                (*dirs)[(size_t)v] = ((*dirs)[(size_t)v] & ~(7 << (3 * slot))) | (n << (3 * slot));
         }
     }
     // every neighbour relation must be mutual (:958-962)
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256) void geom_dense_kernel(const int32_t *coords, 
 // Vb::CalcNeighbours (inference_vb.cc:830-964) for non-negative co-ordinates: the wrap-around tests
 // (:906-925) read "x is on the last / first column", "y is on the last / first row"
 __global__ __launch_bounds__(256) void geom_neighbours_kernel(const int32_t *coords, int V, int xsize, int ysize, long long base,
-    long long span, int max_delta, const int32_t *dense, int32_t *nn)
+    long long span, int max_delta, const int32_t *dense, int32_t *nn, int32_t *dirs)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V)
@@ -303,6 +314,7 @@ __global__ __launch_bounds__(256) void geom_neighbours_kernel(const int32_t *coo
     const bool ok[6] = { x < xsize - 1, x > 0, y < ysize - 1, y > 0, true, true };
     int32_t row[6] = { -1, -1, -1, -1, -1, -1 };
     int slot = 0;
+    int32_t dir = 0777777; // (see build_neighbours)
 #pragma unroll
     for (int n = 0; n < 6; n++)
     {
@@ -316,9 +328,11 @@ __global__ __launch_bounds__(256) void geom_neighbours_kernel(const int32_t *coo
             for (int q = 0; q < 6; q++) // (compile-time indices: the row stays in registers)
                 if (q == slot)
                     row[q] = found;
+            dir = (dir & ~(7 << (3 * slot))) | (n << (3 * slot));
             slot++;
         }
     }
+    dirs[v] = dir;
 #pragma unroll
     for (int q = 0; q < 6; q++)
         nn[(size_t)v * 6 + q] = row[q];
@@ -332,7 +346,7 @@ struct DenseMap
     int xsize = 0, ysize = 0;
 };
 
-int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d_nn, hipStream_t stream, std::string &err,
+int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d_nn, int32_t *d_dirs, hipStream_t stream, std::string &err,
     DevMem *keep_coords = nullptr, GeomScan *scan_out = nullptr, DenseMap *keep_dense = nullptr)
 {
 #define FVB_GEOM_CHECK(expr)                                                                                 \
@@ -377,7 +391,7 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
     hipLaunchKernelGGL(geom_dense_kernel, dim3(grid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, xsize, ysize, first,
         (int32_t *)d_dense.p);
     hipLaunchKernelGGL(geom_neighbours_kernel, dim3(grid), dim3(256), 0, stream, (const int32_t *)d_coords.p, V, xsize, ysize,
-        first, span, dims * 2 - 1, (const int32_t *)d_dense.p, d_nn);
+        first, span, dims * 2 - 1, (const int32_t *)d_dense.p, d_nn, d_dirs);
     FVB_GEOM_CHECK(hipGetLastError());
     FVB_GEOM_CHECK(hipStreamSynchronize(stream)); // the temporaries are freed on return
 #undef FVB_GEOM_CHECK
@@ -457,7 +471,7 @@ struct fvb_spatial_run
     std::vector<int32_t> level_begin;
     std::vector<long long> level_value; // the level (weighted co-ordinate sum) of each entry of level_begin
     int level_w[3] = { 1, 1, 1 };
-    DevMem d_state, d_nn, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums, d_seg_start;
+    DevMem d_state, d_nn, d_nn_dir, d_order, d_aK, d_partials, d_fprior, d_status, d_sa, d_sums, d_seg_start;
     int n_segments = 0;
     double t_geometry_ms = 0, t_neighbours_ms = 0;
     // the split first sweep (vb_spatial.h): whole-volume runs, or one of several slabs that sweep together
@@ -590,20 +604,22 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     // ---- geometry: neighbour table on the device where the geometry allows, else on the host ----
     const auto t_start = std::chrono::steady_clock::now();
     FVB_HIP_CHECK(d_nn.alloc(sizeof(int32_t) * (size_t)V * 6, stream));
+    FVB_HIP_CHECK(d_nn_dir.alloc(sizeof(int32_t) * (size_t)std::max(V, 1), stream));
     std::string err;
     DevMem d_coords;
     GeomScan scan;
     const int on_device = (V > 0 && !getenv("FVB_SPATIAL_HOST_GEOMETRY"))
-        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, stream, err, &d_coords, &scan, &dense) : 1;
+        ? build_neighbours_device(sp.coords, V, sp.spatial_dims, (int32_t *)d_nn.p, (int32_t *)d_nn_dir.p, stream, err, &d_coords, &scan, &dense) : 1;
     if (on_device < 0)
         return api_fail(on_device, err);
     if (on_device == 1)
     {
-        std::vector<int32_t> nn;
-        err = build_neighbours(sp.coords, V, sp.spatial_dims, nn);
+        std::vector<int32_t> nn, dirs;
+        err = build_neighbours(sp.coords, V, sp.spatial_dims, nn, &dirs);
         if (!err.empty())
             return api_fail(-41, err);
         FVB_HIP_CHECK(hipMemcpyAsync(d_nn.p, nn.data(), sizeof(int32_t) * (size_t)V * 6, hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipMemcpyAsync(d_nn_dir.p, dirs.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipStreamSynchronize(stream)); // nn is a local
     }
     t_neighbours_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -927,6 +943,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     sa.ka.precise_passes = api_precise_passes();
     sa.state = (double *)d_state.p;
     sa.nn = (const int32_t *)d_nn.p;
+    sa.nn_dir = (const int32_t *)d_nn_dir.p;
     sa.order = (const int32_t *)d_order.p;
     sa.aK = (double *)d_aK.p;
     sa.ak_sums = (double *)d_sums.p;
@@ -959,11 +976,11 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         FVB_HIP_CHECK(d_level_count.alloc(sizeof(int32_t) * level_count.size(), stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_pos.p, level_pos.data(), sizeof(int32_t) * level_pos.size(), hipMemcpyHostToDevice, stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_level_count.p, level_count.data(), sizeof(int32_t) * level_count.size(), hipMemcpyHostToDevice, stream));
-        // doubles: x, pm, pprec, q, rec [ns][NP] each; rhs0 [P][NP]; sig [ns][P][NP]; nbr [ns][6][NP]
-        const size_t n_f64 = std::max<size_t>(1, (5 * ns + (ns ? (size_t)P : 0) + ns * (size_t)P + 6 * ns) * NP);
+        // doubles: x, pm, pre, rhsk, pprec, q [ns][NP] each; sigk [ns][ns][NP]; nbr [ns][3][NP]
+        const size_t n_f64 = std::max<size_t>(1, (6 * ns + ns * ns + 3 * ns) * NP);
         FVB_HIP_CHECK(d_sw_f64.alloc(sizeof(double) * n_f64, stream));
-        const size_t n_i32 = 7 * NP;
-        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * n_i32, stream)); // npos [6][NP], alive [NP]
+        const size_t n_i32 = 5 * NP;
+        FVB_HIP_CHECK(d_sw_i32.alloc(sizeof(int32_t) * n_i32, stream)); // npos [4][NP], alive [NP]
         FVB_HIP_CHECK(d_sw_sync.alloc(64, stream));                      // flags
         const size_t gran_bytes = std::max<size_t>(16, sizeof(unsigned long long) * 2 * ns * NP);
         if (multi_fast)
@@ -983,12 +1000,12 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         double *f = (double *)d_sw_f64.p;
         sa.sw_x = f;
         sa.sw_pm = f + ns * NP;
-        sa.sw_pprec = f + 2 * ns * NP;
-        sa.sw_q = f + 3 * ns * NP;
-        sa.sw_rec = f + 4 * ns * NP;
-        sa.sw_rhs0 = f + 5 * ns * NP;
-        sa.sw_sig = f + (5 * ns + (ns ? (size_t)P : 0)) * NP;
-        sa.sw_nbr = f + (5 * ns + (ns ? (size_t)P : 0) + ns * (size_t)P) * NP;
+        sa.sw_pre = f + 2 * ns * NP;
+        sa.sw_rhsk = f + 3 * ns * NP;
+        sa.sw_pprec = f + 4 * ns * NP;
+        sa.sw_q = f + 5 * ns * NP;
+        sa.sw_sigk = f + 6 * ns * NP;
+        sa.sw_nbr = f + (6 * ns + ns * ns) * NP;
         FVB_HIP_CHECK(d_slab_first.alloc(sizeof(int32_t) * slab_first.size(), stream));
         FVB_HIP_CHECK(hipMemcpyAsync(d_slab_first.p, slab_first.data(), sizeof(int32_t) * slab_first.size(), hipMemcpyHostToDevice, stream));
         sa.n_slabs = (int32_t)slab_first.size() - 1;
@@ -999,7 +1016,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         for (size_t b = 0; b + 1 < slab_first.size(); b++)
             max_runs_per_slab = std::max(max_runs_per_slab, (int)(slab_first[b + 1] - slab_first[b]));
         sa.sw_npos = (int32_t *)d_sw_i32.p;
-        sa.sw_alive = (int32_t *)d_sw_i32.p + 6 * NP;
+        sa.sw_alive = (int32_t *)d_sw_i32.p + 4 * NP;
         sa.sw_flags = (int32_t *)d_sw_sync.p + 4;
         sa.pos_of = (const int32_t *)d_pos_of.p;
         sa.n_pos = n_pos;
@@ -1126,7 +1143,9 @@ int fvb_spatial_run::fast_sweep()
         return 0;
     const int which = sa.n_spatial <= 1 ? 0 : (sa.n_spatial == 2 ? 1 : 2);
     // one workgroup of 1024 lanes per slab (within the device's compute units, see the numbering)
-    const size_t lds = sizeof(double) * 2 * (size_t)sa.n_spatial * sa.sl_max_run + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
+    if (sa.n_spatial > 8)
+        return api_fail(-40, "more than eight parameters with a first-neighbour prior");
+    const size_t lds = sizeof(double) * (8 + 2 * (size_t)sa.n_spatial * sa.sl_max_run) + sizeof(int32_t) * (2 * (size_t)max_runs_per_slab + 2);
     if (lds > 48 * 1024)
         FVB_HIP_CHECK(hipFuncSetAttribute((const void *)k.slab_sweep[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k.slab_sweep[which], dim3((unsigned)sa.n_slabs), dim3(1024), lds, stream, sa);

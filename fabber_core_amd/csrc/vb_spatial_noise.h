@@ -673,9 +673,9 @@ SpatialKernels spatial_nz_table(bool need_f, const char *name)
     k.prep = need_f ? (SpatialPrepFn)vb_spatial_prep_kernel<PP, true, NZ> : (SpatialPrepFn)vb_spatial_prep_kernel<PP, false>;
     k.noise_fast = need_f ? (SpatialKernelFn)vb_spatial_noise_nz_kernel<MODEL<PP>, PP, true, true, NZ>
                           : (SpatialKernelFn)vb_spatial_noise_nz_kernel<MODEL<PP>, PP, false, true, NZ>;
-    k.slab_sweep[0] = vb_spatial_slab_sweep_kernel<PP, 1>;
-    k.slab_sweep[1] = vb_spatial_slab_sweep_kernel<PP, (PP < 2 ? PP : 2)>;
-    k.slab_sweep[2] = vb_spatial_slab_sweep_kernel<PP, PP>;
+    k.slab_sweep[0] = vb_spatial_slab_sweep_kernel<1>;
+    k.slab_sweep[1] = vb_spatial_slab_sweep_kernel<2>;
+    k.slab_sweep[2] = vb_spatial_slab_sweep_kernel<(PP <= 4 ? 4 : 8)>;
     k.lds_classes = NZ::LDS_CLASSES ? 1 : 0;
     return k;
 }
