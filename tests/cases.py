@@ -220,3 +220,17 @@ def c5_problem(shape, seed=20260105, noise_sd=0.1, n_times=100, dt=0.02, max_ite
     opts.update(cfg_opts)
     h = vbabi.build_config(vbabi.MODEL_EXP, V, n_times, num_exps=2, dt=dt, max_iterations=max_iterations, **opts)
     return h, coords, y, amp1
+
+
+def cubic_cases():
+    """The cubic-polynomial problems whose fp64 builds differ by more than the 1e-6 base tolerance (columns 1 ... t^3
+    ~ 1e4 over 20 - 24 timepoints: ARD, masked timepoints, the noise options): name -> (holder, data). Held against a
+    binary128 ground truth (tests/golden/make_cubic_truth.py -> cubic_truth_binary128.npz) instead of a raised bound."""
+    out = {}
+    out["ARD last"] = poly_problem(900, 20, 3, seed=5, max_iterations=12, need_f=True, param_overrides={"c3": dict(type="A")})
+    out["ARD middle"] = poly_problem(900, 20, 3, seed=6, max_iterations=4, need_f=True,
+                                     param_overrides={"c1": dict(type="A"), "c2": dict(mean=1.0, prec=0.5)})
+    out["masked"] = poly_problem(333, 24, 3, seed=21, max_iterations=15, masked_timepoints=(3, 7, 24), need_f=True)
+    out["prior-noise-stddev"] = poly_problem(333, 24, 3, seed=21, max_iterations=15, prior_noise_stddev=0.5)
+    out["locked-noise-stdev"] = poly_problem(333, 24, 3, seed=21, max_iterations=15, locked_noise_stdev=0.07)
+    return out

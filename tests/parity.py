@@ -270,3 +270,36 @@ def truth_trace_stats(holder, truth_means, r):
     rel = np.where(np.isnan(rel), np.inf, rel)
     return dict(median=float(np.median(rel)), p90=float(np.quantile(rel, 0.9)), p99=float(np.quantile(rel, 0.99)),
                 within_1e4=float(np.mean(rel <= NORTH_STAR)), failed=float(np.mean(r["status"] != 0)))
+
+
+def cubic_case_against_truth(name, run_gpu):
+    """tests/cases.py:cubic_cases()[name] on the device (run_gpu(holder, data)) and on both CPU builds, each measured
+    against the binary128 ground truth (tests/golden/cubic_truth_binary128.npz): the device's median and 99th percentile
+    within 1.5 x the worse CPU build's, its worst voxel within 2 x; status and iterations identical; F likewise."""
+    import hashlib
+    import os
+    import cases
+    import oracle
+    h, y = cases.cubic_cases()[name]
+    T = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cubic_truth_binary128.npz"))
+    key = name.replace(" ", "_")
+    assert str(T[key + "/data_sha256"]) == hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest()
+    truth = {k: T[key + "/" + k] for k in ("mvn", "free_energy", "status", "iterations")}
+    cpu, fma, gpu = oracle.run(h, y), oracle.run_fma(h, y), run_gpu(h, y)
+    assert np.all(truth["status"] == 0)
+    ok = np.ones(h.cfg.n_voxels, dtype=bool)
+    stats = {}
+    for tag, r in (("cpu", cpu), ("fma", fma), ("gpu", gpu)):
+        assert np.array_equal(r["status"], truth["status"]) and np.array_equal(r["iterations"], truth["iterations"]), tag
+        e_mean, e_cov, _ = voxel_errors(h, truth, r, ok)
+        f_err = (np.abs(truth["free_energy"] - r["free_energy"]) / np.maximum(1.0, np.abs(truth["free_energy"]))) if h.cfg.need_f else np.zeros(1)
+        stats[tag] = dict(med=np.median(e_mean), p99=np.percentile(e_mean, 99), worst=e_mean.max(), cov=e_cov.max(), f=f_err.max())
+    print(name, {t: {k: float("%.3g" % v) for k, v in st.items()} for t, st in stats.items()})
+    worse = {k: max(stats["cpu"][k], stats["fma"][k]) for k in stats["cpu"]}
+    g = stats["gpu"]
+    assert g["med"] <= max(1.5 * worse["med"], 1e-9), (name, stats)
+    assert g["p99"] <= max(1.5 * worse["p99"], TOL_MEAN), (name, stats)
+    assert g["worst"] <= max(2.0 * worse["worst"], TOL_MEAN), (name, stats)
+    assert g["cov"] <= max(2.0 * worse["cov"], TOL_COV), (name, stats)
+    assert g["f"] <= max(2.0 * worse["f"], TOL_F), (name, stats)
+    return stats

@@ -250,15 +250,8 @@ def test_priors_ard_and_image():
     opts = dict(param_overrides={"c1": dict(type="I", prec=4.0)}, image_priors={"c1": img})
     h, y = cases.poly_problem(V, 20, 2, seed=4, max_iterations=12, need_f=True, **opts)
     check(h, y, check_f=True, what="image prior")
-    # ARD on the LAST parameter: its free-energy term is the one that survives 'Fprior ='
-    h, y = cases.poly_problem(V, 20, 3, seed=5, max_iterations=12, need_f=True, param_overrides={"c3": dict(type="A")})
-    check(h, y, check_f=True, what="ARD last", allow_floor=True)
-    # ARD on a middle parameter: updates the prior, contributes nothing to F
-    # (4 iterations: ARD's precision update amplifies rounding - two CPU builds of the oracle
-    # are already 2e-3 apart on single voxels after 12 iterations of this problem)
-    h, y = cases.poly_problem(V, 20, 3, seed=6, max_iterations=4, need_f=True,
-                              param_overrides={"c1": dict(type="A"), "c2": dict(mean=1.0, prec=0.5)})
-    check(h, y, check_f=True, what="ARD middle", allow_floor=True)
+    # ARD on the LAST parameter (its free-energy term is the one that survives 'Fprior =') and on a middle one (updates
+    # the prior, contributes nothing to F) on the cubic polynomial: test_cubic_cases_against_the_ground_truth
 
 
 def test_transform_overrides():
@@ -273,13 +266,27 @@ def test_transform_overrides():
     check(h, y, what="fractional")
 
 
-def test_noise_options_and_masked_timepoints():
-    h, y = cases.poly_problem(333, 24, 3, seed=21, max_iterations=15, masked_timepoints=(3, 7, 24), need_f=True)
-    check(h, y, check_f=True, what="masked", allow_floor=True)
-    h, y = cases.poly_problem(333, 24, 3, seed=21, max_iterations=15, prior_noise_stddev=0.5)
-    check(h, y, what="prior-noise-stddev", allow_floor=True)
-    h, y = cases.poly_problem(333, 24, 3, seed=21, max_iterations=15, locked_noise_stdev=0.07)
-    check(h, y, what="locked-noise-stdev", allow_floor=True)
+@pytest.mark.parametrize("name", ["ARD last", "ARD middle", "masked", "prior-noise-stddev", "locked-noise-stdev"])
+def test_cubic_cases_against_the_ground_truth(name):
+    """The cubic polynomial over 20 - 24 timepoints (design columns 1 ... t^3 ~ 1e4) with ARD priors, masked timepoints
+    and the noise options: two fp64 CPU builds of the oracle are 3e-6 - 3e-5 apart on single voxels, so a per-voxel
+    bound against ONE of them says little (rounds 1 - 3 raised it to a multiple of that distance). Instead every
+    implementation is measured against what the algorithm computes - the oracle's statements in binary128
+    (tests/golden/make_cubic_truth.py) - and the kernels are held to the CPU builds' own distance from it: median and
+    99th percentile within 1.5 x the worse CPU build's, the worst voxel within 2 x (the worst voxel of one CPU build is
+    up to 2 x the other's); status and iteration counts identical; F likewise."""
+    parity.cubic_case_against_truth(name, hipengine.run)
+
+
+def test_noise_options_on_a_well_conditioned_problem():
+    """masked timepoints, prior-noise-stddev and locked-noise-stdev, strict per voxel against the oracle (a quadratic
+    over 12 timepoints; the cubic cases are test_cubic_cases_against_the_ground_truth)"""
+    h, y = cases.poly_problem(333, 12, 2, seed=21, max_iterations=15, masked_timepoints=(3, 7, 12), need_f=True)
+    check(h, y, check_f=True, what="masked (quadratic)")
+    h, y = cases.poly_problem(333, 12, 2, seed=21, max_iterations=15, prior_noise_stddev=0.5)
+    check(h, y, what="prior-noise-stddev (quadratic)")
+    h, y = cases.poly_problem(333, 12, 2, seed=21, max_iterations=15, locked_noise_stdev=0.07)
+    check(h, y, what="locked-noise-stdev (quadratic)")
 
 
 def test_continue_from_mvn_and_float64_data():
@@ -504,7 +511,6 @@ def test_c4_model_properties_at_two_million_voxels():
                           "C4 model 2e6", sample=2048)
 
 
-@gpu
 def test_math_building_blocks_as_the_device_compiles_them():
     """The kernels are compiled with floating-point contraction allowed. exp_acc's compensated reduction
     and the frexp-product log-determinant of the symmetric sweep are error-free-transform idioms that contraction can

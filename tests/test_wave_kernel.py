@@ -134,8 +134,9 @@ def test_priors_transforms_restart_and_history():
     h, y = cases.poly_problem(V, 20, 2, seed=4, max_iterations=12, need_f=True,
                               param_overrides={"c1": dict(type="I", prec=4.0)}, image_priors={"c1": img})
     check(h, y, check_f=True, what="image prior")
-    h, y = cases.poly_problem(V, 20, 3, seed=5, max_iterations=12, need_f=True, param_overrides={"c3": dict(type="A")})
-    check(h, y, check_f=True, what="ARD last", allow_floor=True)  # cubic polynomial, see tests/test_hip_parity.py check()
+    # (ARD on the cubic polynomial: against the binary128 ground truth, as the lane kernels in tests/test_hip_parity.py)
+    for name in ("ARD last", "ARD middle", "masked"):
+        parity.cubic_case_against_truth(name, hipengine.run)
     h, y = cases.exp_problem(V, 50, 1, 0.04, seed=9, max_iterations=10,
                              param_overrides={"amp1": dict(transform="S"), "r1": dict(transform="A", mean=1.0, prec=1e-2)})
     check(h, y, what="softplus/abs")
