@@ -550,4 +550,4 @@ def test_math_building_blocks_as_the_device_compiles_them():
         assert np.max(np.abs(full - ref)) <= 1e-13 * cond * np.max(np.abs(ref)) + 1e-300
         assert abs(ld - np.linalg.slogdet(a)[1]) <= 1e-12 * max(1.0, abs(ld))
         tw_inv, tw_ld, _, ok = hiplib.ldl_inverse(a)
-        assert ok and abs(tw_ld - ld) <= 4e-16 * max(1.0, abs(ld))
+        assert ok and abs(tw_ld - ld) <= 1e-14 * max(1.0, abs(ld))  # (the device's log against glibc's: a few ulp)
