@@ -274,8 +274,8 @@ def truth_trace_stats(holder, truth_means, r):
 
 def cubic_case_against_truth(name, run_gpu):
     """tests/cases.py:cubic_cases()[name] on the device (run_gpu(holder, data)) and on both CPU builds, each measured
-    against the binary128 ground truth (tests/golden/cubic_truth_binary128.npz): the device's median and 99th percentile
-    within 1.5 x the worse CPU build's, its worst voxel within 2 x; status and iterations identical; F likewise."""
+    against the binary128 ground truth (tests/golden/cubic_truth_binary128.npz): every voxel of the device's result within
+    the base tolerances (1e-6 of max(|mean|, sd), 2e-4 sd_i sd_j, 1e-6 on F) of the truth; status and iterations identical."""
     import hashlib
     import os
     import cases
@@ -295,11 +295,12 @@ def cubic_case_against_truth(name, run_gpu):
         f_err = (np.abs(truth["free_energy"] - r["free_energy"]) / np.maximum(1.0, np.abs(truth["free_energy"]))) if h.cfg.need_f else np.zeros(1)
         stats[tag] = dict(med=np.median(e_mean), p99=np.percentile(e_mean, 99), worst=e_mean.max(), cov=e_cov.max(), f=f_err.max())
     print(name, {t: {k: float("%.3g" % v) for k, v in st.items()} for t, st in stats.items()})
-    worse = {k: max(stats["cpu"][k], stats["fma"][k]) for k in stats["cpu"]}
+    # Measured (round 4): the kernels' worst voxel is 3e-9 - 2e-7 from the truth where the CPU builds' is 2e-7 - 4e-5 -
+    # what the earlier rounds' raised bounds absorbed was the ORACLE's error (its LU inverse on a design whose columns
+    # span four orders of magnitude; the kernels' symmetric sweep loses less). So the device is held to the BASE
+    # tolerances against the truth, per voxel, and - as a guard on the comparison itself - the CPU builds to 1e-4.
     g = stats["gpu"]
-    assert g["med"] <= max(1.5 * worse["med"], 1e-9), (name, stats)
-    assert g["p99"] <= max(1.5 * worse["p99"], TOL_MEAN), (name, stats)
-    assert g["worst"] <= max(2.0 * worse["worst"], TOL_MEAN), (name, stats)
-    assert g["cov"] <= max(2.0 * worse["cov"], TOL_COV), (name, stats)
-    assert g["f"] <= max(2.0 * worse["f"], TOL_F), (name, stats)
+    assert g["worst"] <= TOL_MEAN and g["cov"] <= TOL_COV and g["f"] <= TOL_F, (name, stats)
+    for tag in ("cpu", "fma"):
+        assert stats[tag]["worst"] <= NORTH_STAR, (name, tag, stats)
     return stats
