@@ -423,11 +423,13 @@ static int spatial_noise_kind(const fvb_config *cfg)
         return cfg->n_phis == 1 ? FVB_SPNZ_WHITE : (cfg->n_phis == 2 ? FVB_SPNZ_PATTERN2 : (cfg->n_phis <= 4 ? FVB_SPNZ_PATTERN4 : -1));
     if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 1 && cfg->ar_cross_terms == 0)
         return FVB_SPNZ_AR1;
+    if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 2 && cfg->ar_cross_terms >= 0 && cfg->ar_cross_terms <= 2)
+        return FVB_SPNZ_ARN2 + cfg->ar_cross_terms;
     return -1;
 }
 static const char *const spatial_noise_refusal
-    = "spatial VB runs white noise with up to 4 noise precisions and AR(1) noise with one echo; more precisions and two-echo AR(1) "
-      "noise (num-echoes=2) run voxelwise only";
+    = "spatial VB runs white noise with up to 4 noise precisions and AR(1) noise (one or two echoes); 5 - 8 noise precisions run "
+      "voxelwise only";
 // the kernel table of a configuration (setup == NULL: none was built for this model / parameter count / noise model)
 static SpatialKernels spatial_kernels_for(const fvb_config *cfg)
 {
@@ -435,6 +437,8 @@ static SpatialKernels spatial_kernels_for(const fvb_config *cfg)
     const bool need_f = cfg->need_f != 0;
     if (kind < 0)
         return SpatialKernels{};
+    if (kind >= FVB_SPNZ_ARN2)
+        return get_spatial_kernels_nz_arn(cfg->model, P, need_f, kind);
     switch (cfg->model)
     {
     case FVB_MODEL_POLY:

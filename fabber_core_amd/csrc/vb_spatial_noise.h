@@ -24,6 +24,7 @@
 #pragma once
 
 #include "vb_lane_ar_kernel.h"
+#include "vb_lane_arn_kernel.h"
 #include "vb_lane_pattern_kernel.h"
 #include "vb_spatial.h"
 
@@ -448,6 +449,278 @@ struct SpAr1
     }
 };
 
+// ---- AR(1) in its general form: two interleaved echoes, 2 / 3 / 4 AR coefficients (ar1-cross-terms none / same / dual) ----
+// The two-echo lane kernel's scheme (vb_lane_arn_kernel.h) inside the spatial loop: the twelve lines' moments are not
+// kept; the state image holds the EFFECTIVE moments J'XJ, J'X(y - g) (X = sum_n E[phi_n] Q_n with the alpha posterior's
+// marginal weights; B = C = 1) that the first sweep needs, the alpha posterior, the two precisions' posteriors and the
+// twelve line scalars S_l = k'M_l k + tr(Sigma J'M_l J) of the last pass. Per iteration the second-sweep kernel streams
+// the series twice, as the voxelwise kernel does: pass 2 about the OLD centre with the first sweep's new means and
+// covariance (S_l -> UpdateAlpha, UpdatePhi, noisemodel_ar.cc:447-556, and F "phi"), then the re-centre's pass 1 with
+// the new alpha / phi posterior (effective moments, the at-centre S_l for F "lin" and the next iteration's "before").
+// The first sweep's F "theta" (new means, old centre) is a pass of its own - the policy carries the MODEL for it; it
+// runs only where F is evaluated.
+template <class Model, int P, int NA>
+struct SpArN
+{
+    typedef SpLayout<P> L;
+    static constexpr int PT = L::PT, NT = NA * (NA + 1) / 2;
+    static constexpr int AM = L::ROWS, AC = AM + NA, ALD = AC + NT, PB = ALD + 1, PC = PB + 2, SS = PC + 2;
+    static constexpr int EXTRA_ROWS = NA + NT + 1 + 4 + 12;
+    static constexpr int WAVES = 1; // (as vb_lane_arn_kernel: what does not fit 256 registers lands in the other half of the file)
+    static constexpr bool LDS_CLASSES = false;
+    struct Full
+    {
+        ArnAlpha<NA> al;
+        double pb[2], pc[2];
+        ArnMoments<P> mo;
+        double S[2][6];
+        double Sig[PT]; // the posterior covariance the next forms pass belongs to
+    };
+    static __device__ __forceinline__ int n_noise_out(const KernelArgs &)
+    {
+        return NA + 2;
+    }
+    static __device__ __forceinline__ ModelArgs model_args(const KernelArgs &ka)
+    {
+        ModelArgs ma;
+        ma.iopt0 = ka.cfg.model_iopt[0];
+        ma.dopt0 = ka.cfg.model_dopt[0];
+        ma.design = ka.cfg.design;
+        return ma;
+    }
+    static __device__ __forceinline__ void load_full(const SpatialArgs &sa, int v, Full &f)
+    {
+        const size_t V = (size_t)sa.ka.cfg.n_voxels;
+        const double *p = sa.state + v;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            f.al.mean[i] = p[(size_t)(AM + i) * V];
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+            f.al.cov[i] = p[(size_t)(AC + i) * V];
+        f.al.logdetPrec = p[(size_t)ALD * V];
+        f.al.update_marginal();
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+        {
+            f.pb[e] = p[(size_t)(PB + e) * V];
+            f.pc[e] = p[(size_t)(PC + e) * V];
+        }
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+        {
+            f.mo.A[i] = p[(size_t)(L::A + i) * V];
+            f.Sig[i] = p[(size_t)(L::SIG + i) * V];
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            f.mo.u[i] = p[(size_t)(L::U + i) * V];
+            f.mo.ml[i] = p[(size_t)(L::ML + i) * V];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                f.S[n][k] = p[(size_t)(SS + n * 6 + k) * V];
+    }
+    static __device__ __forceinline__ void store_full(const SpatialArgs &sa, int v, const Full &f)
+    {
+        const size_t V = (size_t)sa.ka.cfg.n_voxels;
+        double *p = sa.state + v;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            p[(size_t)(AM + i) * V] = f.al.mean[i];
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+            p[(size_t)(AC + i) * V] = f.al.cov[i];
+        p[(size_t)ALD * V] = f.al.logdetPrec;
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+        {
+            p[(size_t)(PB + e) * V] = f.pb[e];
+            p[(size_t)(PC + e) * V] = f.pc[e];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                p[(size_t)(SS + n * 6 + k) * V] = f.S[n][k];
+    }
+    // Ar1cNoiseModel::HardcodedInitialDists (noisemodel_ar.cc:379-403) or Ar1cParams::InputFromMVN (:302-316), then
+    // Ar1cNoiseModel::Precalculate (:749-769)
+    static __device__ __forceinline__ void init_noise(const SpatialArgs &sa, const double *src, VoxelState<P> &st, Full &f)
+    {
+        const KernelArgs &ka = sa.ka;
+        const size_t V = (size_t)ka.cfg.n_voxels;
+        constexpr int n = P + NA + 2, nCov = n * (n + 1) / 2;
+        if (src)
+        {
+#pragma unroll
+            for (int i = 0; i < NA; i++)
+            {
+                f.al.mean[i] = src[(size_t)(nCov + P + i) * V];
+#pragma unroll
+                for (int j = 0; j <= i; j++)
+                    f.al.cov[tri(i, j)] = src[(size_t)tri(P + i, P + j) * V];
+            }
+            double inv[NT], la;
+            int sg;
+            (void)ldl_inverse<NA>(f.al.cov, inv, la, sg);
+            f.al.logdetPrec = -la;
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+            {
+                const double nm = src[(size_t)(nCov + P + NA + e) * V];
+                const double nv = src[(size_t)tri(P + NA + e, P + NA + e) * V];
+                f.pb[e] = nv / nm;
+                f.pc[e] = nm / f.pb[e];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < NA; i++)
+            {
+                f.al.mean[i] = 0;
+#pragma unroll
+                for (int j = 0; j <= i; j++)
+                    f.al.cov[tri(i, j)] = (i == j) ? 1.0 / AR_ALPHA_PRIOR_PREC : 0.0;
+            }
+            f.al.logdetPrec = NA * log(AR_ALPHA_PRIOR_PREC);
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                f.pb[e] = ka.cfg.noise_post_b[e];
+        }
+        f.al.update_marginal();
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            f.pc[e] = ka.cfg.noise_prior_c[e] + ((double)(ka.cfg.n_times / 2) - 1) * 0.5;
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            f.Sig[i] = st.Sig[i];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                f.S[n][k] = 0;
+    }
+    // the re-centre: effective moments with the present alpha / phi posterior and the line scalars at the centre
+    template <class M2>
+    static __device__ __forceinline__ int recentre(const SpatialArgs &sa, const ModelArgs &ma, int v, const double (&centre)[P], Full &f,
+        bool precise, const uint8_t *)
+    {
+        double cw[2][6], zero[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            zero[i] = 0;
+        arn_coefficients<NA>(f.al, f.pb, f.pc, cw);
+        return arn_pass<Model, P, NA, true, true>(sa.ka, ma, ArStridedFeed<P>{ sa.ka, v }, centre, cw, f.mo, f.Sig, zero, f.S, precise);
+    }
+    // Ar1cNoiseModel::UpdateNoise = UpdateAlpha + UpdatePhi (noisemodel_ar.cc:405-417, 447-556) from the line scalars of a
+    // pass about the centre the moments belong to, with the first sweep's means and covariance
+    template <class M2>
+    static __device__ __forceinline__ int update_noise(const SpatialArgs &sa, const ModelArgs &ma, int v, VoxelState<P> &st, Full &f,
+        const uint8_t *)
+    {
+        double cw[2][6], nd[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            nd[i] = f.mo.ml[i] - st.m[i];
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            f.Sig[i] = st.Sig[i];
+        arn_coefficients<NA>(f.al, f.pb, f.pc, cw);
+        // (the Jacobian as the linearisation about ml computed it: sp_load's rule for `precise`)
+        (void)arn_pass<Model, P, NA, false, true>(sa.ka, ma, ArStridedFeed<P>{ sa.ka, v }, f.mo.ml, cw, f.mo, st.Sig, nd, f.S,
+            sa.it < sa.ka.precise_passes);
+        int status = update_noise_arn<NA>(sa.ka, f.al, f.pb, f.pc, f.S);
+        if (status == FVB_OK && sa.locked_linear)
+        {
+            // no re-centre follows (inference_vb.cc:695-696): the effective moments about the same centre with the new
+            // alpha / phi posterior (the line scalars stay those of the pass above: F "lin" is F "phi" then)
+            double keep[2][6], zero[P];
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                zero[i] = 0;
+            arn_coefficients<NA>(f.al, f.pb, f.pc, cw);
+            double centre[P];
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                centre[i] = f.mo.ml[i];
+            status = arn_pass<Model, P, NA, true, false>(sa.ka, ma, ArStridedFeed<P>{ sa.ka, v }, centre, cw, f.mo, st.Sig, zero, keep,
+                sa.it < sa.ka.precise_passes);
+        }
+        return status;
+    }
+    static __device__ __forceinline__ bool F_full(const SpatialArgs &sa, VoxelState<P> &st, Full &f, bool, double Fprior, double &F,
+        bool &finite)
+    {
+        return calc_free_energy_arn<P, NA>(sa.ka, st, f.al, f.pb, f.pc, f.S, Fprior, F, finite);
+    }
+    static __device__ __forceinline__ void effective(const SpatialArgs &, const Full &f, VoxelState<P> &st, Moments<P> &w)
+    {
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            w.A[i] = f.mo.A[i];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+        {
+            w.u[i] = f.mo.u[i];
+            w.ml[i] = f.mo.ml[i];
+        }
+        w.s = 0;
+        w.precise = false;
+        st.b = st.c = 1; // (E[phi] is inside the effective moments)
+    }
+    // the first sweep's free energy: "before" reads the line scalars the last re-centre left (same centre, same
+    // covariance); "theta" - new means and covariance about the old centre - streams the series once
+    static __device__ __forceinline__ bool sweep_F(const SpatialArgs &sa, int v, VoxelState<P> &st, const Moments<P> &, bool at_centre,
+        double Fprior, double &F, bool &finite)
+    {
+        Full f;
+        load_full(sa, v, f);
+        if (!at_centre)
+        {
+            double cw[2][6], nd[P];
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                nd[i] = f.mo.ml[i] - st.m[i];
+            arn_coefficients<NA>(f.al, f.pb, f.pc, cw);
+            (void)arn_pass<Model, P, NA, false, true>(sa.ka, model_args(sa.ka), ArStridedFeed<P>{ sa.ka, v }, f.mo.ml, cw, f.mo, st.Sig, nd, f.S,
+                sa.it < sa.ka.precise_passes);
+        }
+        return calc_free_energy_arn<P, NA>(sa.ka, st, f.al, f.pb, f.pc, f.S, Fprior, F, finite);
+    }
+    // Ar1cParams::OutputAsMVN (noisemodel_ar.cc:287-300): (alphas, phi_1, phi_2)
+    static __device__ __forceinline__ void pack_noise(const SpatialArgs &sa, int v, double *dst)
+    {
+        const size_t V = (size_t)sa.ka.cfg.n_voxels;
+        constexpr int n = P + NA + 2, nCov = n * (n + 1) / 2;
+        const double *p = sa.state + v;
+#pragma unroll
+        for (int r = P; r < n; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++)
+                dst[(size_t)tri(r, c) * V] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+        {
+#pragma unroll
+            for (int j = 0; j <= i; j++)
+                dst[(size_t)tri(P + i, P + j) * V] = p[(size_t)(AC + tri(i, j)) * V];
+            dst[(size_t)(nCov + P + i) * V] = p[(size_t)(AM + i) * V];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+        {
+            const double b = p[(size_t)(PB + e) * V], c = p[(size_t)(PC + e) * V];
+            dst[(size_t)tri(P + NA + e, P + NA + e) * V] = b * b * c;
+            dst[(size_t)(nCov + P + NA + e) * V] = b * c;
+        }
+    }
+};
+
 // cfg.phi_index into LDS (dynamic, T bytes) for the policies that read it per timepoint; every lane takes part
 template <class NZ>
 __device__ __forceinline__ const uint8_t *sp_classes(const KernelArgs &ka)
@@ -646,8 +919,12 @@ enum
     FVB_SPNZ_WHITE = 0,    // white noise, one precision: the kernels of vb_spatial.h
     FVB_SPNZ_PATTERN2 = 1, // white noise, 2 precisions
     FVB_SPNZ_PATTERN4 = 2, // white noise, 3 - 4 precisions
-    FVB_SPNZ_AR1 = 3       // AR(1), one echo
+    FVB_SPNZ_AR1 = 3,      // AR(1), one echo
+    FVB_SPNZ_ARN2 = 4,     // AR(1), two echoes, ar1-cross-terms none (2 AR coefficients)
+    FVB_SPNZ_ARN3 = 5,     // ... same (3)
+    FVB_SPNZ_ARN4 = 6      // ... dual (4)
 };
+SpatialKernels get_spatial_kernels_nz_arn(int model, int P, bool need_f, int kind); // vb_spatial_nz_arn_*.hip
 SpatialKernels get_spatial_kernels_nz_poly(int P, bool need_f, int kind);
 SpatialKernels get_spatial_kernels_nz_linear(int P, bool need_f, int kind);
 SpatialKernels get_spatial_kernels_nz_exp(int P, bool need_f, int kind);
@@ -679,6 +956,15 @@ SpatialKernels spatial_nz_table(bool need_f, const char *name)
     k.lds_classes = NZ::LDS_CLASSES ? 1 : 0;
     return k;
 }
+#define FVB_SPATIAL_ARN_CASE(MODEL, TAG, PP)                                                                 \
+    case PP:                                                                                                 \
+        if (kind == FVB_SPNZ_ARN2)                                                                           \
+            return spatial_nz_table<MODEL, PP, SpArN<MODEL<PP>, PP, 2> >(need_f, "spatial<" TAG "," #PP ",ar2:2>"); \
+        if (kind == FVB_SPNZ_ARN3)                                                                           \
+            return spatial_nz_table<MODEL, PP, SpArN<MODEL<PP>, PP, 3> >(need_f, "spatial<" TAG "," #PP ",ar2:3>"); \
+        if (kind == FVB_SPNZ_ARN4)                                                                           \
+            return spatial_nz_table<MODEL, PP, SpArN<MODEL<PP>, PP, 4> >(need_f, "spatial<" TAG "," #PP ",ar2:4>"); \
+        return SpatialKernels{};
 #define FVB_SPATIAL_NZ_CASE(MODEL, TAG, PP)                                                                  \
     case PP:                                                                                                 \
         if (kind == FVB_SPNZ_PATTERN2)                                                                       \

@@ -1,0 +1,16 @@
+// Spatial VB under the general AR(1) noise model (two echoes; SpArN, vb_spatial_noise.h): poly model
+#include "vb_spatial_noise.h"
+
+namespace fvb
+{
+SpatialKernels get_spatial_kernels_nz_arn_poly(int P, bool need_f, int kind)
+{
+    switch (P)
+    {
+        FVB_SPATIAL_ARN_CASE(PolyModel, "poly", 2)
+        FVB_SPATIAL_ARN_CASE(PolyModel, "poly", 3)
+    default:
+        return SpatialKernels{};
+    }
+}
+} // namespace fvb

@@ -392,7 +392,8 @@ def test_engine_slabs_on_a_very_unbalanced_mask(typ):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("noise_kw", [dict(noise=vbabi.NOISE_AR1), dict(noise_pattern="12")])
+@pytest.mark.parametrize("noise_kw", [dict(noise=vbabi.NOISE_AR1), dict(noise_pattern="12"),
+                                      dict(noise=vbabi.NOISE_AR1, num_echoes=2, ar_cross_terms="dual")])
 def test_engine_slabs_under_other_noise_models(noise_kw):
     """the slab driver runs the same kernels: AR(1) noise and two noise precisions, bit for bit the one-device run"""
     coords = masked_coords((8, 7, 10), seed=41, keep=0.9)

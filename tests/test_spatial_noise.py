@@ -115,14 +115,25 @@ def test_oracle_locked_linearisation_centres():
 def spatial_check(h, sp, y, what, **kw):
     cpu = oracle.run_spatial(h, sp, y)
     got = hiplib.run_spatial_host(h, sp, y)
-    cpu2 = oracle.run_spatial_fma(h, sp, y)
-    for r in (cpu, cpu2):
+    cpu2 = [oracle.run_spatial_fma(h, sp, y)]
+    if h.cfg.model == vbabi.MODEL_EXP and kw.get("allow_floor"):
+        # (where a test measures the CPU-vs-CPU floor on the exponential model: the build whose exp has the device's
+        # accuracy class is one of the CPU builds - DESIGN 5.4, tests/test_random_configs.py)
+        cpu2.append(oracle.run_spatial_exp1ulp(h, sp, y))
+    for r in [cpu] + cpu2:
         r.setdefault("f_history_len", np.zeros(h.cfg.n_voxels, dtype=np.int32))
     return parity.strict(h, cpu, got, what=what, cpu2=cpu2, **kw), got
 
 
 NOISES = {"ar": dict(noise=AR), "pattern12": dict(noise_pattern="12"), "pattern1231": dict(noise_pattern="1231"),
-          "pattern1234": dict(noise_pattern="1234")}
+          "pattern1234": dict(noise_pattern="1234"),
+          # two interleaved echoes, 2 / 3 / 4 AR coefficients (round 4: the SpArN policy, vb_spatial_noise.h)
+          "ar2none": dict(noise=AR, num_echoes=2, ar_cross_terms="none"), "ar2same": dict(noise=AR, num_echoes=2, ar_cross_terms="same"),
+          "ar2dual": dict(noise=AR, num_echoes=2, ar_cross_terms="dual")}
+
+
+def is_ar(noise):
+    return noise.startswith("ar")
 
 
 @gpu
@@ -133,17 +144,17 @@ def test_spatial_priors_under_other_noise_models(typ, noise):
     (P, p) read the effective moments the second sweep left, whatever the noise model"""
     _, coords = masked_volume((11, 9, 7), seed=3)
     V, T = coords.shape[1], 40
-    _, y = smooth_line_data(coords, T, seed=4, rho=0.3 if noise == "ar" else 0.0)
+    _, y = smooth_line_data(coords, T, seed=4, rho=0.3 if is_ar(noise) else 0.0)
     h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=8, param_overrides={"c0": dict(type=typ)}, **NOISES[noise])
     spatial_check(h, vbabi.SpatialHolder(coords), y, "spatial %s %s" % (typ, noise))
 
 
 @gpu
-@pytest.mark.parametrize("noise", ["ar", "pattern12"])
+@pytest.mark.parametrize("noise", ["ar", "pattern12", "ar2dual", "ar2none"])
 def test_nonlinear_model_with_free_energy_ard_and_two_spatial_parameters(noise):
     _, coords = masked_volume((10, 8, 6), seed=5)
     V = coords.shape[1]
-    _, y = smooth_exp_data(coords, 50, 0.04, seed=6, rho=0.3 if noise == "ar" else 0.0)
+    _, y = smooth_exp_data(coords, 50, 0.04, seed=6, rho=0.3 if is_ar(noise) else 0.0)
     h = vbabi.build_config(vbabi.MODEL_EXP, V, 50, num_exps=1, dt=0.04, max_iterations=7, need_f=True,
                            param_overrides={"amp1": dict(type="M"), "r1": dict(type="A")}, **NOISES[noise])
     # (the two CPU builds are 1.0e-6 apart on this fit already: the bound follows the measured floor)
@@ -154,7 +165,7 @@ def test_nonlinear_model_with_free_energy_ard_and_two_spatial_parameters(noise):
 
 
 @gpu
-@pytest.mark.parametrize("noise", ["ar", "pattern12"])
+@pytest.mark.parametrize("noise", ["ar", "pattern12", "ar2dual", "ar2same"])
 def test_linear_design_and_float32_series(noise):
     """C4's model (design matrix, four regressors) under a spatial prior, the series as the C ABI hands it over"""
     _, coords = masked_volume((9, 8, 6), seed=7)
@@ -163,7 +174,7 @@ def test_linear_design_and_float32_series(noise):
     X = np.stack([np.ones(T), t / T, np.sin(2 * np.pi * t / 25), np.cos(2 * np.pi * t / 25)], axis=1)
     rng = np.random.default_rng(8)
     beta = rng.normal(0, 3, (4, V)) + np.stack([np.sin(coords[0] / 2.0) * 4, 0 * coords[0], 0 * coords[0], 0 * coords[0]])
-    y = (X @ beta + ar_noise(T, V, 0.3 if noise == "ar" else 0.0, 1.0, 9)).astype(np.float32)
+    y = (X @ beta + ar_noise(T, V, 0.3 if is_ar(noise) else 0.0, 1.0, 9)).astype(np.float32)
     h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, max_iterations=6, param_overrides={"beta_1": dict(type="M")} if False else None,
                            **NOISES[noise])
     names = [p["name"] for p in h.params]
@@ -172,7 +183,7 @@ def test_linear_design_and_float32_series(noise):
 
 
 @gpu
-@pytest.mark.parametrize("noise", ["ar", "pattern12"])
+@pytest.mark.parametrize("noise", ["ar", "pattern12", "ar2dual"])
 @pytest.mark.parametrize("typ", ["M", "P"])
 def test_failing_voxels_under_other_noise_models(typ, noise):
     """Vb::IgnoreVoxel: the voxels with a non-finite sample fail (with F: at the first CalculateF of the sweep) and
@@ -194,13 +205,13 @@ def test_failing_voxels_under_other_noise_models(typ, noise):
 
 
 @gpu
-@pytest.mark.parametrize("noise", ["ar", "pattern12"])
+@pytest.mark.parametrize("noise", ["ar", "pattern12", "ar2dual", "ar2same"])
 def test_continue_from_mvn_under_other_noise_models(noise):
     """3 + 3 iterations through continue-from-mvn: the noise posterior (alpha and phi; every precision) is taken from
     the MVN (Ar1cParams / WhiteParams::InputFromMVN)"""
     _, coords = masked_volume((8, 7, 5), seed=13)
     V, T = coords.shape[1], 30
-    _, y = smooth_line_data(coords, T, seed=14, rho=0.3 if noise == "ar" else 0.0)
+    _, y = smooth_line_data(coords, T, seed=14, rho=0.3 if is_ar(noise) else 0.0)
     kw = dict(degree=1, param_overrides={"c0": dict(type="M")}, **NOISES[noise])
     first = hiplib.run_spatial_host(vbabi.build_config(vbabi.MODEL_POLY, V, T, max_iterations=3, **kw), vbabi.SpatialHolder(coords), y)
     h = vbabi.build_config(vbabi.MODEL_POLY, V, T, max_iterations=3, init_mvn=first["mvn"], **kw)
@@ -208,14 +219,14 @@ def test_continue_from_mvn_under_other_noise_models(noise):
 
 
 @gpu
-@pytest.mark.parametrize("noise", ["white", "ar", "pattern12"])
+@pytest.mark.parametrize("noise", ["white", "ar", "pattern12", "ar2dual"])
 def test_locked_linearisation_centres(noise):
     # (a full block: with fixed centres nothing ever looks at the means again - ReCentre is what throws on non-finite
     # values - so the NaN prior mean of a voxel without neighbours, priors.cc:448-451, would spread through the
     # whole volume, in the reference as here)
     _, coords = masked_volume((8, 7, 5), seed=15, keep=1.0)
     V = coords.shape[1]
-    _, y = smooth_exp_data(coords, 40, 0.05, seed=16, rho=0.3 if noise == "ar" else 0.0)
+    _, y = smooth_exp_data(coords, 40, 0.05, seed=16, rho=0.3 if is_ar(noise) else 0.0)
     centres = np.stack([np.full(V, np.log(0.8)), np.full(V, np.log(1.3))])
     for need_f in (False, True):
         h = vbabi.build_config(vbabi.MODEL_EXP, V, 40, num_exps=1, dt=0.05, max_iterations=5, need_f=need_f,
@@ -228,9 +239,6 @@ def test_what_spatial_vb_still_refuses_says_so():
     _, coords = masked_volume((4, 4, 3), seed=17, keep=1.0)
     V = coords.shape[1]
     y = np.random.default_rng(0).normal(2, 0.1, (20, V))
-    h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=1, noise=AR, num_echoes=2)
-    with pytest.raises(RuntimeError, match="two-echo"):
-        hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), y)
     h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=1, noise_pattern="12345")
     with pytest.raises(RuntimeError, match="4 noise precisions"):
         hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), y)
@@ -258,9 +266,11 @@ def test_reference_vbtest_noise_fits(method, noise):
 
 
 @gpu
-def test_spatialvb_with_ar_noise_and_a_spatial_prior_through_the_c_abi():
-    """noise=ar + PSP_byname1_type=M through fabber_dorun: the result images carry the AR block (alpha_1, alpha_2,
-    phi) and match the engine's own entry point"""
+@pytest.mark.parametrize("echoes,cross", [(1, "none"), (2, "dual"), (2, "none")])
+def test_spatialvb_with_ar_noise_and_a_spatial_prior_through_the_c_abi(echoes, cross):
+    """noise=ar + PSP_byname1_type=M through fabber_dorun: the result images carry the AR block (the AR coefficients,
+    then one precision per echo) and match the engine's own entry point; one echo, and two with and without the cross
+    terms (num-echoes=2, ar1-cross-terms: noisemodel_ar.cc:322-332)"""
     from fabber_core_amd import fabber
     shape = (7, 6, 5)
     coords = vbabi.grid_coords(shape)
@@ -269,10 +279,13 @@ def test_spatialvb_with_ar_noise_and_a_spatial_prior_through_the_c_abi():
     data = np.ascontiguousarray(y.T.reshape(shape[2], shape[1], shape[0], T).transpose(2, 1, 0, 3)).astype(np.float32)
     opts = {"noise": "ar", "model": "poly", "degree": 1, "method": "spatialvb", "max-iterations": 5, "save-mvn": True, "save-mean": True,
             "PSP_byname1": "c0", "PSP_byname1_type": "M"}
+    if echoes == 2:
+        opts.update({"num-echoes": 2, "ar1-cross-terms": cross})
     out = fabber.run(data, opts)
-    n = 2 + 3
+    n = 2 + (2 + {"none": 0, "same": 1, "dual": 2}[cross] + echoes)
     assert out["finalMVN"].shape[3] == vbabi.mvn_rows(n)
-    h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=5, noise=AR, param_overrides={"c0": dict(type="M")})
+    h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=5, noise=AR, num_echoes=echoes, ar_cross_terms=cross,
+                           param_overrides={"c0": dict(type="M")})
     y32 = data.transpose(2, 1, 0, 3).reshape(V, T).T.copy()
     ref = hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), y32)
     got = out["finalMVN"].transpose(2, 1, 0, 3).reshape(V, -1).T
