@@ -28,7 +28,7 @@ HIP_SOURCES = ["vb_api.hip", "vb_lane_poly.hip", "vb_lane_linear.hip", "vb_lane_
                "vb_spatial_linear.hip", "vb_spatial_exp.hip", "vb_spatial_host.hip", "vb_spatial_more.hip",
                "vb_spatial_nz_poly.hip", "vb_spatial_nz_linear.hip", "vb_spatial_nz_linear2.hip", "vb_spatial_nz_exp.hip", "vb_spatial_nz_host.hip",
                "vb_spatial_nz_arn.hip", "vb_spatial_nz_arn_linear2.hip", "vb_spatial_nz_arn_linear3.hip", "vb_spatial_nz_arn_linear4.hip", "vb_spatial_nz_arn_poly.hip",
-               "vb_spatial_nz_arn_exp2.hip", "vb_spatial_nz_arn_exp4.hip", "vb_wave.hip", "vb_hostmodel_api.hip", "vb_nlls.hip"]
+               "vb_spatial_nz_arn_exp2.hip", "vb_spatial_nz_arn_exp4.hip", "vb_spatial_nz_p8_linear.hip", "vb_spatial_nz_p8_poly.hip", "vb_spatial_nz_p8_exp.hip", "vb_wave.hip", "vb_hostmodel_api.hip", "vb_nlls.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math",
              "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 

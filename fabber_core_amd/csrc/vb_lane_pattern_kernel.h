@@ -59,6 +59,20 @@ __device__ __forceinline__ void pattern_accumulate(PatternMoments<P, N> &mo, con
     mo.s[K] += r * r;
 }
 
+// the class of a timepoint is the same for every voxel: choosing the register set its products go to is a wave-uniform
+// branch (classes beyond N - masked timepoints, 255 - go nowhere)
+template <int P, int N, int K>
+__device__ __forceinline__ void pattern_dispatch(PatternMoments<P, N> &mo, const double (&J)[P], double r, int k)
+{
+    if constexpr (K < N)
+    {
+        if (k == K)
+            pattern_accumulate<K>(mo, J, r);
+        else
+            pattern_dispatch<P, N, K + 1>(mo, J, r, k);
+    }
+}
+
 // wave-uniform class of timepoint t: 0..N-1, or -1 for a masked timepoint. The table lives in LDS (filled
 // once per wavefront from cfg.phi_index): a read from global memory here would sit behind the prefetched
 // samples in the in-order return queue and its wait would drain them.
@@ -126,14 +140,7 @@ __device__ __forceinline__ int recentre_pattern(const KernelArgs &ka, const Mode
         bad_offset |= !is_finite(g);
         const double r = y_cur - g;
         const int k = pattern_class(classes, t);
-        if (k == 0)
-            pattern_accumulate<0>(mo, J, r);
-        else if (k == 1)
-            pattern_accumulate<1>(mo, J, r);
-        else if (N > 2 && k == 2)
-            pattern_accumulate<(N > 2 ? 2 : 0)>(mo, J, r);
-        else if (N > 3 && k == 3)
-            pattern_accumulate<(N > 3 ? 3 : 0)>(mo, J, r);
+        pattern_dispatch<P, N, 0>(mo, J, r, k); // (a wave-uniform chain of branches over the N register sets)
     };
     FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
     return bad_offset ? FVB_BAD_OFFSET : (bad_jac ? FVB_BAD_JACOBIAN : FVB_OK);
@@ -280,14 +287,10 @@ __device__ __forceinline__ void exact_residual_pattern(const KernelArgs &ka, con
         const double r = y_cur - g + Jd;
         const double r2 = r * r;
         const int k = pattern_class(classes, t);
-        if (k == 0)
-            kk[0] += r2;
-        else if (k == 1)
-            kk[1] += r2;
-        else if (N > 2 && k == 2)
-            kk[N > 2 ? 2 : 0] += r2;
-        else if (N > 3 && k == 3)
-            kk[N > 3 ? 3 : 0] += r2;
+#pragma unroll
+        for (int q = 0; q < N; q++) // (uniform: the class is the same in every lane)
+            if (k == q)
+                kk[q] += r2;
     };
     FVB_FOR_EACH_TIMEPOINT(lane_prefetch_depth<P>(), ka, v, V, T, step)
 }

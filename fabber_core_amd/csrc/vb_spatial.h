@@ -119,7 +119,7 @@ struct SpatialArgs
     int32_t up_n_pos;               // n_pos of the slab above
     int32_t sl_remote;              // 1: inboxes are written by another device: system-scope accesses
     // ---- noise models other than white noise with one precision (vb_spatial_noise.h) ----
-    double nz_count[4];      // noise-pattern: timepoints of each class (trace of Q_k, noisemodel_white.cc:207-225)
+    double nz_count[8];      // noise-pattern: timepoints of each class (trace of Q_k, noisemodel_white.cc:207-225)
     int32_t locked_linear;   // locked-linear-from-mvn: the second sweep does not re-centre (inference_vb.cc:695-696)
     const double *locked_centres; // [P][V] the fixed centres (set-up re-centre, inference_vb.cc:225-232), or NULL
 };

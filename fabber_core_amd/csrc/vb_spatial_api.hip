@@ -420,7 +420,7 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
 static int spatial_noise_kind(const fvb_config *cfg)
 {
     if (cfg->noise == FVB_NOISE_WHITE)
-        return cfg->n_phis == 1 ? FVB_SPNZ_WHITE : (cfg->n_phis == 2 ? FVB_SPNZ_PATTERN2 : (cfg->n_phis <= 4 ? FVB_SPNZ_PATTERN4 : -1));
+        return cfg->n_phis == 1 ? FVB_SPNZ_WHITE : (cfg->n_phis == 2 ? FVB_SPNZ_PATTERN2 : (cfg->n_phis <= 4 ? FVB_SPNZ_PATTERN4 : (cfg->n_phis <= 8 ? FVB_SPNZ_PATTERN8 : -1)));
     if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 1 && cfg->ar_cross_terms == 0)
         return FVB_SPNZ_AR1;
     if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 2 && cfg->ar_cross_terms >= 0 && cfg->ar_cross_terms <= 2)
@@ -428,8 +428,7 @@ static int spatial_noise_kind(const fvb_config *cfg)
     return -1;
 }
 static const char *const spatial_noise_refusal
-    = "spatial VB runs white noise with up to 4 noise precisions and AR(1) noise (one or two echoes); 5 - 8 noise precisions run "
-      "voxelwise only";
+    = "spatial VB runs white noise with up to 8 noise precisions and AR(1) noise with one or two echoes";
 // the kernel table of a configuration (setup == NULL: none was built for this model / parameter count / noise model)
 static SpatialKernels spatial_kernels_for(const fvb_config *cfg)
 {
@@ -437,8 +436,10 @@ static SpatialKernels spatial_kernels_for(const fvb_config *cfg)
     const bool need_f = cfg->need_f != 0;
     if (kind < 0)
         return SpatialKernels{};
-    if (kind >= FVB_SPNZ_ARN2)
+    if (kind >= FVB_SPNZ_ARN2 && kind <= FVB_SPNZ_ARN4)
         return get_spatial_kernels_nz_arn(cfg->model, P, need_f, kind);
+    if (kind == FVB_SPNZ_PATTERN8)
+        return get_spatial_kernels_nz_pattern8(cfg->model, P, need_f);
     switch (cfg->model)
     {
     case FVB_MODEL_POLY:
@@ -560,7 +561,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     FVB_HIP_CHECK(d_state.alloc(sizeof(double) * (size_t)k.state_rows * V, stream));
     FVB_HIP_CHECK(d_status.alloc(sizeof(int32_t) * (size_t)V, stream));
     int n_unmasked = cfg.n_times;
-    double nz_count[4] = { (double)cfg.n_times, 0, 0, 0 }; // timepoints per noise precision (trace of Q_k)
+    double nz_count[8] = { (double)cfg.n_times, 0, 0, 0, 0, 0, 0, 0 }; // timepoints per noise precision (trace of Q_k)
     if (cfg.phi_index) // (a device pointer here: read it back once)
     {
         std::vector<uint8_t> h(cfg.n_times);
@@ -571,7 +572,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         for (int t = 0; t < cfg.n_times; t++)
         {
             n_unmasked += (h[t] != 255);
-            if (h[t] < 4)
+            if (h[t] < 8)
                 nz_count[h[t]] += 1;
         }
     }
@@ -591,7 +592,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
         early.status = (int32_t *)d_status.p;
         early.owned_begin = owned_begin;
         early.owned_end = owned_end;
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 8; i++)
             early.nz_count[i] = nz_count[i];
         early.locked_centres = sp.locked_centres;
         early.locked_linear = sp.locked_centres != nullptr;
@@ -964,7 +965,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
     sa.owned_begin = owned_begin;
     sa.owned_end = owned_end;
     sa.n_voxels_global = sp.n_voxels_global > 0 ? sp.n_voxels_global : V;
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
         sa.nz_count[i] = nz_count[i];
     sa.locked_centres = sp.locked_centres;
     sa.locked_linear = sp.locked_centres != nullptr;

@@ -922,8 +922,10 @@ enum
     FVB_SPNZ_AR1 = 3,      // AR(1), one echo
     FVB_SPNZ_ARN2 = 4,     // AR(1), two echoes, ar1-cross-terms none (2 AR coefficients)
     FVB_SPNZ_ARN3 = 5,     // ... same (3)
-    FVB_SPNZ_ARN4 = 6      // ... dual (4)
+    FVB_SPNZ_ARN4 = 6,     // ... dual (4)
+    FVB_SPNZ_PATTERN8 = 7  // white noise, 5 - 8 precisions
 };
+SpatialKernels get_spatial_kernels_nz_pattern8(int model, int P, bool need_f); // vb_spatial_nz_p8_*.hip
 SpatialKernels get_spatial_kernels_nz_arn(int model, int P, bool need_f, int kind); // vb_spatial_nz_arn_*.hip
 SpatialKernels get_spatial_kernels_nz_poly(int P, bool need_f, int kind);
 SpatialKernels get_spatial_kernels_nz_linear(int P, bool need_f, int kind);
@@ -965,6 +967,9 @@ SpatialKernels spatial_nz_table(bool need_f, const char *name)
         if (kind == FVB_SPNZ_ARN4)                                                                           \
             return spatial_nz_table<MODEL, PP, SpArN<MODEL<PP>, PP, 4> >(need_f, "spatial<" TAG "," #PP ",ar2:4>"); \
         return SpatialKernels{};
+#define FVB_SPATIAL_P8_CASE(MODEL, TAG, PP)                                                                  \
+    case PP:                                                                                                 \
+        return spatial_nz_table<MODEL, PP, SpPattern<PP, 8> >(need_f, "spatial<" TAG "," #PP ",pattern8>");
 #define FVB_SPATIAL_NZ_CASE(MODEL, TAG, PP)                                                                  \
     case PP:                                                                                                 \
         if (kind == FVB_SPNZ_PATTERN2)                                                                       \

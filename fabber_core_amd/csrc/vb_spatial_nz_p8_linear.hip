@@ -1,0 +1,18 @@
+// Spatial VB with 5 - 8 noise precisions (SpPattern<P, 8>, vb_spatial_noise.h): linear model
+#include "vb_spatial_noise.h"
+
+namespace fvb
+{
+SpatialKernels get_spatial_kernels_nz_p8_linear(int P, bool need_f)
+{
+    switch (P)
+    {
+        FVB_SPATIAL_P8_CASE(LinearModel, "linear", 1)
+        FVB_SPATIAL_P8_CASE(LinearModel, "linear", 2)
+        FVB_SPATIAL_P8_CASE(LinearModel, "linear", 3)
+        FVB_SPATIAL_P8_CASE(LinearModel, "linear", 4)
+    default:
+        return SpatialKernels{};
+    }
+}
+} // namespace fvb

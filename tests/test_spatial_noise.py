@@ -126,7 +126,8 @@ def spatial_check(h, sp, y, what, **kw):
 
 
 NOISES = {"ar": dict(noise=AR), "pattern12": dict(noise_pattern="12"), "pattern1231": dict(noise_pattern="1231"),
-          "pattern1234": dict(noise_pattern="1234"),
+          "pattern1234": dict(noise_pattern="1234"), "pattern12345": dict(noise_pattern="1234512345"),
+          "pattern8": dict(noise_pattern="1234567812345678"),
           # two interleaved echoes, 2 / 3 / 4 AR coefficients (round 4: the SpArN policy, vb_spatial_noise.h)
           "ar2none": dict(noise=AR, num_echoes=2, ar_cross_terms="none"), "ar2same": dict(noise=AR, num_echoes=2, ar_cross_terms="same"),
           "ar2dual": dict(noise=AR, num_echoes=2, ar_cross_terms="dual")}
@@ -235,13 +236,15 @@ def test_locked_linearisation_centres(noise):
 
 
 @gpu
-def test_what_spatial_vb_still_refuses_says_so():
-    _, coords = masked_volume((4, 4, 3), seed=17, keep=1.0)
-    V = coords.shape[1]
-    y = np.random.default_rng(0).normal(2, 0.1, (20, V))
-    h = vbabi.build_config(vbabi.MODEL_POLY, V, 20, degree=1, noise_pattern="12345")
-    with pytest.raises(RuntimeError, match="4 noise precisions"):
-        hiplib.run_spatial_host(h, vbabi.SpatialHolder(coords), y)
+def test_nine_noise_precisions_are_refused_everywhere_through_the_c_abi():
+    """round 4: two-echo AR(1) and 5 - 8 noise precisions run under spatial VB too; what is left is what the engine does
+    not take at all (more than FVB_MAX_PHIS = 8 precisions), with a message, voxelwise and spatial alike"""
+    from fabber_core_amd import fabber
+    rng = np.random.default_rng(0)
+    data = rng.normal(2, 0.1, (4, 4, 3, 27)).astype(np.float32)
+    for method in ("vb", "spatialvb"):
+        with pytest.raises(Exception, match="(?i)precision|pattern|phis"):
+            fabber.run(data, {"model": "poly", "degree": 1, "method": method, "noise": "white", "noise-pattern": "123456789", "max-iterations": 2})
 
 
 # ---- the reference's own test through the C ABI -----------------------------------------------------
