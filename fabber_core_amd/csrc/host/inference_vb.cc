@@ -109,6 +109,11 @@ struct Vb::EngineStorage
     vector<Parameter> params;
     vector<string> model_outputs;
     bool has_device_model;
+    // more than FVB_MAX_PARAMS parameters: the per-parameter entries as a table (fvb_config.params_ext)
+    vector<int32_t> wide_transform, wide_type;
+    vector<double> wide_mean, wide_var, wide_prec, wide_post_mean, wide_post_var;
+    vector<const double *> wide_images;
+    fvb_param_table wide;
 };
 
 static OptionSpec VB_OPTIONS[] = {
@@ -249,9 +254,23 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
     st.params.clear();
     m_model->GetParameters(rundata, st.params);
     const int P = (int)st.params.size();
-    if (P > FVB_MAX_PARAMS)
-        throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters are not supported by the MI355X engine");
+    if (P > FVB_MAX_PARAMS_EXT)
+        throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS_EXT) + " parameters are not supported by the MI355X engine");
     cfg.n_params = P;
+    // beyond FVB_MAX_PARAMS the per-parameter entries travel as a table (the wave-per-voxel kernel takes such problems:
+    // voxelwise VB, white noise, a built-in model - the engine says so where that is not the case)
+    const bool wide = P > FVB_MAX_PARAMS;
+    if (wide)
+    {
+        st.wide_transform.assign(P, 0);
+        st.wide_type.assign(P, 0);
+        st.wide_mean.assign(P, 0);
+        st.wide_var.assign(P, 0);
+        st.wide_prec.assign(P, 0);
+        st.wide_post_mean.assign(P, 0);
+        st.wide_post_var.assign(P, 0);
+        st.wide_images.assign(P, (const double *)NULL);
+    }
     DeviceModelSpec spec;
     // A model without a device body (any model library written for the reference), or any model
     // when host-model is set, is evaluated on the host: 2P+1 Evaluate calls per voxel and
@@ -282,13 +301,13 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
     for (int k = 0; k < P; k++)
     {
         const Parameter &p = st.params[k];
-        cfg.transform[k] = p.transform->DeviceCode();
-        cfg.prior_type[k] = Prior::DeviceCode(p.prior_type);
-        cfg.prior_mean[k] = p.prior.mean();
-        cfg.prior_var[k] = p.prior.var();
-        cfg.prior_prec[k] = p.prior.prec();
-        cfg.post_mean[k] = p.post.mean();
-        cfg.post_var[k] = p.post.var();
+        (wide ? st.wide_transform[k] : cfg.transform[k]) = p.transform->DeviceCode();
+        (wide ? st.wide_type[k] : cfg.prior_type[k]) = Prior::DeviceCode(p.prior_type);
+        (wide ? st.wide_mean[k] : cfg.prior_mean[k]) = p.prior.mean();
+        (wide ? st.wide_var[k] : cfg.prior_var[k]) = p.prior.var();
+        (wide ? st.wide_prec[k] : cfg.prior_prec[k]) = p.prior.prec();
+        (wide ? st.wide_post_mean[k] : cfg.post_mean[k]) = p.post.mean();
+        (wide ? st.wide_post_var[k] : cfg.post_var[k]) = p.post.var();
         if (p.prior_type == PRIOR_IMAGE)
         {
             const Matrix &img = rundata.GetVoxelData(p.options.find("image")->second);
@@ -297,8 +316,21 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
             st.image_priors[k].resize(cfg.n_voxels);
             for (int v = 0; v < cfg.n_voxels; v++)
                 st.image_priors[k][v] = img.at0(0, v);
-            cfg.image_prior[k] = st.image_priors[k].data();
+            (wide ? st.wide_images[k] : cfg.image_prior[k]) = st.image_priors[k].data();
         }
+    }
+
+    if (wide)
+    {
+        st.wide.transform = st.wide_transform.data();
+        st.wide.prior_type = st.wide_type.data();
+        st.wide.prior_mean = st.wide_mean.data();
+        st.wide.prior_var = st.wide_var.data();
+        st.wide.prior_prec = st.wide_prec.data();
+        st.wide.post_mean = st.wide_post_mean.data();
+        st.wide.post_var = st.wide_post_var.data();
+        st.wide.image_prior = st.wide_images.data();
+        cfg.params_ext = &st.wide;
     }
 
     // ---- noise ----

@@ -62,8 +62,10 @@ int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_no
         return fail(-2, "fvb_config.abi_version mismatch");
     if (cfg->n_voxels < 0 || cfg->n_times <= 0)
         return fail(-3, "bad n_voxels / n_times");
-    if (cfg->n_params <= 0 || cfg->n_params > FVB_MAX_PARAMS)
-        return fail(-4, "n_params out of range");
+    if (cfg->n_params <= 0 || cfg->n_params > (cfg->params_ext ? FVB_MAX_PARAMS_EXT : FVB_MAX_PARAMS))
+        return fail(-4, cfg->params_ext ? "n_params out of range" : "n_params out of range (more than FVB_MAX_PARAMS parameters: fvb_config.params_ext)");
+    if (cfg->params_ext && (cfg->noise != FVB_NOISE_WHITE || allow_spatial))
+        return fail(-4, "a parameter table (more than FVB_MAX_PARAMS parameters) runs voxelwise VB under white noise only");
     // (a result image without noise entries - method=nlls - can only be post-processed)
     if ((cfg->n_phis <= 0 && !(allow_no_noise && cfg->n_phis == 0)) || cfg->n_phis > FVB_MAX_PHIS)
         return fail(-5, "n_phis out of range");
@@ -94,6 +96,10 @@ int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_no
         return fail(-12, "poly model: n_params != degree + 1");
     for (int k = 0; k < cfg->n_params; k++)
     {
+        // (validate() sees the configuration as the caller built it: with device entry points the table itself is device
+        // memory and is not looked into here)
+        if (cfg->params_ext)
+            break;
         if (cfg->prior_type[k] == FVB_PRIOR_IMAGE && !cfg->image_prior[k])
             return fail(-13, "image prior without an image");
         if (cfg->prior_type[k] > FVB_PRIOR_ARD && !allow_spatial)
@@ -205,6 +211,7 @@ int count_unmasked(const fvb_config *cfg, const uint8_t *phi_index_host)
 }
 
 // ---- post-processing kernel: InferenceTechnique::SaveResults / Vb::SaveResults ----------------
+template <int MAXP>
 __global__ __launch_bounds__(256) void vb_postproc_kernel(
     const fvb_config cfg, const void *data, const double *mvn, const fvb_postproc pp, const int n_noise)
 {
@@ -214,12 +221,12 @@ __global__ __launch_bounds__(256) void vb_postproc_kernel(
     const size_t V = (size_t)cfg.n_voxels;
     const int P = cfg.n_params, n = P + n_noise, T = cfg.n_times;
     const int nCov = n * (n + 1) / 2;
-    double means[FVB_MAX_PARAMS];
+    double means[MAXP];
     for (int p = 0; p < P; p++)
     {
         const double m = mvn[(size_t)(nCov + p) * V + v];
         const double var = mvn[(size_t)(p * (p + 1) / 2 + p) * V + v];
-        const int tr = cfg.transform[p];
+        const int tr = cfg.params_ext ? cfg.params_ext->transform[p] : cfg.transform[p];
         // FwdModel::ToModel, fwdmodel.cc:326-337
         const double mm = to_model(tr, m);
         const double mv = to_model_var(tr, var);
@@ -287,6 +294,61 @@ struct DevBuf
     {
         stream = s;
         return fvb::api_pool_alloc(&p, bytes ? bytes : 8, s);
+    }
+};
+
+// A host fvb_param_table (fvb_config.params_ext: more than FVB_MAX_PARAMS parameters) on the device: the seven arrays,
+// the image priors of the voxels [v0, v0 + Vb) and the table itself
+struct DeviceParamTable
+{
+    DevBuf block;
+    std::vector<std::unique_ptr<DevBuf> > images;
+    const fvb_param_table *device = nullptr;
+    int upload(const fvb_config *cfg, size_t v0, size_t Vb, hipStream_t stream)
+    {
+        const fvb_param_table *h = cfg->params_ext;
+        const size_t P = (size_t)cfg->n_params, V = (size_t)cfg->n_voxels;
+        // [table][transform, prior_type: int32 P each][5 double arrays][image pointers]
+        const size_t off_i = sizeof(fvb_param_table), off_d = off_i + 2 * P * sizeof(int32_t) + (2 * P * sizeof(int32_t)) % 8;
+        const size_t off_p = off_d + 5 * P * sizeof(double), bytes = off_p + P * sizeof(double *);
+        std::vector<char> host(bytes, 0);
+        FVB_HIP_CHECK(block.alloc(bytes, stream));
+        char *dev = (char *)block.p;
+        fvb_param_table t;
+        t.transform = (const int32_t *)(dev + off_i);
+        t.prior_type = t.transform + P;
+        t.prior_mean = (const double *)(dev + off_d);
+        t.prior_var = t.prior_mean + P;
+        t.prior_prec = t.prior_var + P;
+        t.post_mean = t.prior_prec + P;
+        t.post_var = t.post_mean + P;
+        t.image_prior = (const double *const *)(dev + off_p);
+        memcpy(host.data(), &t, sizeof(t));
+        memcpy(host.data() + off_i, h->transform, P * sizeof(int32_t));
+        memcpy(host.data() + off_i + P * sizeof(int32_t), h->prior_type, P * sizeof(int32_t));
+        const double *src[5] = { h->prior_mean, h->prior_var, h->prior_prec, h->post_mean, h->post_var };
+        for (int a = 0; a < 5; a++)
+            memcpy(host.data() + off_d + (size_t)a * P * sizeof(double), src[a], P * sizeof(double));
+        const double **img = (const double **)(host.data() + off_p);
+        for (size_t k = 0; k < P; k++)
+        {
+            if (h->prior_type[k] < 0 || h->prior_type[k] > FVB_PRIOR_ARD)
+                return fail(-14, "a parameter table takes prior types N, I and ARD");
+            if (h->prior_type[k] == FVB_PRIOR_IMAGE && !(h->image_prior && h->image_prior[k]))
+                return fail(-13, "image prior without an image");
+            if (h->image_prior && h->image_prior[k])
+            {
+                images.emplace_back(new DevBuf);
+                FVB_HIP_CHECK(images.back()->alloc(sizeof(double) * Vb, stream));
+                FVB_HIP_CHECK(hipMemcpyAsync(images.back()->p, h->image_prior[k] + v0, sizeof(double) * Vb, hipMemcpyHostToDevice, stream));
+                img[k] = (const double *)images.back()->p;
+            }
+        }
+        (void)V;
+        FVB_HIP_CHECK(hipMemcpyAsync(block.p, host.data(), bytes, hipMemcpyHostToDevice, stream));
+        FVB_HIP_CHECK(hipStreamSynchronize(stream)); // (`host` is a local; the image priors are the caller's pageable memory)
+        device = (const fvb_param_table *)block.p;
+        return 0;
     }
 };
 
@@ -618,6 +680,7 @@ struct HostBlock
     fvb_config d;
     fvb_outputs dout;
     DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
+    DeviceParamTable ptable;
     hipEvent_t up_done = nullptr, fit_done = nullptr;
     ~HostBlock()
     {
@@ -658,7 +721,14 @@ struct HostBlock
             FVB_HIP_CHECK(upload(b_init.p, cfg->init_mvn, sizeof(double), rows));
             d.init_mvn = (const double *)b_init.p;
         }
-        for (int k = 0; k < P; k++)
+        if (cfg->params_ext) // more than FVB_MAX_PARAMS parameters: the per-parameter entries as a table on the device
+        {
+            const int rc = ptable.upload(cfg, (size_t)v0, Vb, stream);
+            if (rc)
+                return rc;
+            d.params_ext = ptable.device;
+        }
+        for (int k = 0; k < P && !cfg->params_ext; k++)
             if (cfg->image_prior[k])
             {
                 FVB_HIP_CHECK(b_img[k].alloc(sizeof(double) * Vb, stream));
@@ -1015,8 +1085,12 @@ int32_t fabber_vb_postproc_device(const fvb_config *cfg, const void *data, const
     if (cfg->n_voxels == 0)
         return 0;
     const unsigned grid = (unsigned)((cfg->n_voxels + 255) / 256);
-    hipLaunchKernelGGL(vb_postproc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *cfg, data, mvn, *pp,
-        noise_outputs(cfg));
+    if (cfg->n_params > FVB_MAX_PARAMS)
+        hipLaunchKernelGGL(vb_postproc_kernel<FVB_MAX_PARAMS_EXT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *cfg, data, mvn, *pp,
+            noise_outputs(cfg));
+    else
+        hipLaunchKernelGGL(vb_postproc_kernel<FVB_MAX_PARAMS>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *cfg, data, mvn, *pp,
+            noise_outputs(cfg));
     FVB_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1038,6 +1112,19 @@ int32_t fabber_vb_postproc_host(const fvb_config *cfg, const void *data, const d
     const size_t esz = cfg->data_f64 ? 8 : 4;
     fvb_config d = *cfg;
     DevBuf b_data, b_design, b_mvn;
+    DeviceParamTable ptable;
+    if (cfg->params_ext)
+    {
+        fvb_config no_images = *cfg; // (the images of image priors play no part in the result images)
+        fvb_param_table t = *cfg->params_ext;
+        t.image_prior = nullptr;
+        std::vector<int32_t> types((size_t)P, FVB_PRIOR_NORMAL);
+        t.prior_type = types.data();
+        no_images.params_ext = &t;
+        if ((rc = ptable.upload(&no_images, 0, V, nullptr)) != 0)
+            return rc;
+        d.params_ext = ptable.device;
+    }
     if (data)
     {
         FVB_HIP_CHECK(b_data.alloc(T * V * esz));

@@ -31,6 +31,10 @@
 
 namespace fvb
 {
+// the per-parameter entries of the configuration: the fixed arrays, or the table of a problem with more than
+// FVB_MAX_PARAMS parameters (fvb_config.params_ext: this kernel is the one that takes those)
+#define FVB_KPARAM(ka, field, k) ((ka).cfg.params_ext ? (ka).cfg.params_ext->field[k] : (ka).cfg.field[k])
+
 // LDS layout in doubles (followed by T int32 for the phi index of each timepoint)
 struct WaveLayout
 {
@@ -238,7 +242,7 @@ __device__ __forceinline__ int wave_recentre(const KernelArgs &ka, const ModelAr
     {
     FVB_WAVE_FOR(i, P)
     {
-        const int tr = ka.cfg.transform[i];
+        const int tr = FVB_KPARAM(ka, transform, i);
         const double centre = sh[L.m + i];
         double delta = centre * 1e-5; // fwdmodel_linear.cc:157-161
         if (delta < 0)
@@ -354,14 +358,14 @@ __device__ __forceinline__ bool wave_apply_priors(const KernelArgs &ka, WaveCtx 
     double *sh = cx.sh;
     bool has_ard = false;
     for (int k = 0; k < P; k++)
-        has_ard |= (ka.cfg.prior_type[k] == FVB_PRIOR_ARD);
+        has_ard |= (FVB_KPARAM(ka, prior_type, k) == FVB_PRIOR_ARD);
     bool ok = true;
     if (has_ard)
         ok = wave_ensure_cov(cx);
     double fk = 0;
     FVB_WAVE_FOR(k, P)
     {
-        const int type = ka.cfg.prior_type[k];
+        const int type = FVB_KPARAM(ka, prior_type, k);
         if (type == FVB_PRIOR_ARD) // priors.cc:150-181
         {
             const double post_mean = sh[L.m + k];
@@ -369,8 +373,8 @@ __device__ __forceinline__ bool wave_apply_priors(const KernelArgs &ka, WaveCtx 
             const double new_cov = post_mean * post_mean + post_cov;
             if (it == 0)
             {
-                sh[L.pprec + k] = 1.0 / ka.cfg.prior_var[k];
-                sh[L.pm + k] = ka.cfg.prior_mean[k];
+                sh[L.pprec + k] = 1.0 / FVB_KPARAM(ka, prior_var, k);
+                sh[L.pm + k] = FVB_KPARAM(ka, prior_mean, k);
             }
             else
                 sh[L.pprec + k] = 1.0 / new_cov;
@@ -382,13 +386,13 @@ __device__ __forceinline__ bool wave_apply_priors(const KernelArgs &ka, WaveCtx 
         }
         else if (type == FVB_PRIOR_IMAGE) // priors.cc:133-142
         {
-            sh[L.pm + k] = ka.cfg.image_prior[k][cx.v];
-            sh[L.pprec + k] = ka.cfg.prior_prec[k];
+            sh[L.pm + k] = FVB_KPARAM(ka, image_prior, k)[cx.v];
+            sh[L.pprec + k] = FVB_KPARAM(ka, prior_prec, k);
         }
         else // priors.cc:108-117
         {
-            sh[L.pm + k] = ka.cfg.prior_mean[k];
-            sh[L.pprec + k] = ka.cfg.prior_prec[k];
+            sh[L.pm + k] = FVB_KPARAM(ka, prior_mean, k);
+            sh[L.pprec + k] = FVB_KPARAM(ka, prior_prec, k);
         }
     }
     Fprior = __shfl(fk, P - 1); // the value of the LAST prior ('=' not '+=' in the reference)
@@ -695,12 +699,12 @@ __global__ __launch_bounds__(64) void vb_wave_kernel(const KernelArgs ka, const 
         }
         FVB_WAVE_FOR(i, P)
         {
-            double mean = (ka.cfg.prior_type[i] == FVB_PRIOR_IMAGE) ? ka.cfg.image_prior[i][v] : ka.cfg.post_mean[i];
+            double mean = (FVB_KPARAM(ka, prior_type, i) == FVB_PRIOR_IMAGE) ? FVB_KPARAM(ka, image_prior, i)[v] : FVB_KPARAM(ka, post_mean, i);
             if (ka.cfg.model == FVB_MODEL_EXP && (i % 2) == 0)
                 mean = data_max / (P / 2 + i / 2);
-            const int tr = ka.cfg.transform[i];
+            const int tr = FVB_KPARAM(ka, transform, i);
             sh[L.m + i] = to_fabber(tr, mean); // FwdModel::ToFabber, fwdmodel.cc:315-324
-            sh[L.Sig + i * P + i] = to_fabber_var(tr, ka.cfg.post_var[i]);
+            sh[L.Sig + i * P + i] = to_fabber_var(tr, FVB_KPARAM(ka, post_var, i));
         }
         FVB_WAVE_FOR(phi, N)
         {

@@ -14,7 +14,7 @@ import numpy as np
 
 FVB_MAX_PARAMS = 32
 FVB_MAX_PHIS = 8
-FVB_ABI_VERSION = 7
+FVB_ABI_VERSION = 8
 
 MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
 TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)
@@ -27,6 +27,12 @@ NOISE_WHITE, NOISE_AR1 = 0, 1
 STATUS_OK, STATUS_BAD_OFFSET, STATUS_BAD_JACOBIAN, STATUS_BAD_FREE_ENERGY, STATUS_BAD_RESULT, STATUS_BAD_AR_ALPHA = range(6)
 
 _dp = C.POINTER(C.c_double)
+
+
+class FvbParamTable(C.Structure):
+    """fvb_param_table: the per-parameter entries of a problem with more than FVB_MAX_PARAMS parameters"""
+    _fields_ = [("transform", C.c_void_p), ("prior_type", C.c_void_p), ("prior_mean", C.c_void_p), ("prior_var", C.c_void_p),
+                ("prior_prec", C.c_void_p), ("post_mean", C.c_void_p), ("post_var", C.c_void_p), ("image_prior", C.c_void_p)]
 
 
 class FvbConfig(C.Structure):
@@ -64,6 +70,7 @@ class FvbConfig(C.Structure):
         ("f_history_rows", C.c_int32),
         ("data_f64", C.c_int32),
         ("ar_cross_terms", C.c_int32),
+        ("params_ext", C.c_void_p),
     ]
 
 
@@ -216,10 +223,18 @@ def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps
     else:
         raise ValueError(model)
     P = len(params)
-    assert P <= FVB_MAX_PARAMS
     cfg.n_params = P
     param_overrides = param_overrides or {}
     image_priors = image_priors or {}
+    # more than FVB_MAX_PARAMS parameters: the per-parameter entries go into an fvb_param_table (cfg.params_ext)
+    wide = P > FVB_MAX_PARAMS
+    tab = None
+    if wide:
+        tab = dict(transform=np.zeros(P, dtype=np.int32), prior_type=np.zeros(P, dtype=np.int32), prior_mean=np.zeros(P),
+                   prior_var=np.zeros(P), prior_prec=np.zeros(P), post_mean=np.zeros(P), post_var=np.zeros(P),
+                   image_prior=np.zeros(P, dtype=np.uint64))
+    dst = tab if wide else {f: getattr(cfg, f) for f in ("transform", "prior_type", "prior_mean", "prior_var", "prior_prec", "post_mean",
+                                                         "post_var", "image_prior")}
     for k, p in enumerate(params):
         ov = param_overrides.get(p["name"], {})
         tr = p["transform"]
@@ -237,19 +252,25 @@ def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps
         # Prior to Fabber space (fwdmodel.cc:277, transforms.cc:10-15)
         fmean = to_fabber(tr, mean)
         fvar = to_fabber_var(tr, var)
-        cfg.transform[k] = tr
-        cfg.prior_type[k] = PRIOR_CODES[ptype]
-        cfg.prior_mean[k] = fmean
-        cfg.prior_var[k] = fvar
-        cfg.prior_prec[k] = 1.0 / fvar if fvar != 0 else math.inf
-        cfg.post_mean[k] = p["post"][0]
-        cfg.post_var[k] = p["post"][1]
+        dst["transform"][k] = tr
+        dst["prior_type"][k] = PRIOR_CODES[ptype]
+        dst["prior_mean"][k] = fmean
+        dst["prior_var"][k] = fvar
+        dst["prior_prec"][k] = 1.0 / fvar if fvar != 0 else math.inf
+        dst["post_mean"][k] = p["post"][0]
+        dst["post_var"][k] = p["post"][1]
         p.update(transform=tr, prior_type=ptype)
         if PRIOR_CODES[ptype] == PRIOR_IMAGE:
             img = np.ascontiguousarray(image_priors[p["name"]], dtype=np.float64)
             assert img.shape == (n_voxels,)
             keep["image_%d" % k] = img
-            cfg.image_prior[k] = img.ctypes.data
+            dst["image_prior"][k] = img.ctypes.data
+    if wide:
+        ext = FvbParamTable()
+        for f, a in tab.items():
+            setattr(ext, f, a.ctypes.data)
+        keep["param_table"] = (tab, ext)
+        cfg.params_ext = C.addressof(ext)
 
     # noise pattern -> phi index per timepoint (noisemodel_white.cc:166-226)
     pat = []

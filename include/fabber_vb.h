@@ -43,8 +43,9 @@ extern "C" {
 #endif
 
 #define FVB_MAX_PARAMS 32
+#define FVB_MAX_PARAMS_EXT 128 /* with fvb_config.params_ext (the wave-per-voxel kernel; what its LDS holds decides) */
 #define FVB_MAX_PHIS 8
-#define FVB_ABI_VERSION 7
+#define FVB_ABI_VERSION 8
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
@@ -107,6 +108,17 @@ enum fvb_status
     FVB_BAD_AR_ALPHA = 5     /* noisemodel_ar.cc:492-499 negative alpha variance        */
 };
 
+/* The per-parameter entries of fvb_config for a model with MORE than FVB_MAX_PARAMS parameters (the reference has no
+ * limit): [n_params] arrays in the memory space of the configuration's other pointers. The wave-per-voxel kernel takes
+ * such problems (white noise, any built-in model; up to what its LDS holds: n_times, n_params with
+ * 8 (4 T + T P + 7 P^2 + ...) bytes <= 160 KB), through fabber_vb_run_host / _device and fabber_vb_postproc_*. */
+typedef struct fvb_param_table
+{
+    const int32_t *transform, *prior_type;
+    const double *prior_mean, *prior_var, *prior_prec, *post_mean, *post_var;
+    const double *const *image_prior; /* [n_params] pointers ([n_voxels] each, or NULL) */
+} fvb_param_table;
+
 /* Problem description. Pointers inside are HOST pointers for fabber_vb_run_host and for the
  * oracle, DEVICE pointers for fabber_vb_run_device (documented per field). */
 typedef struct fvb_config
@@ -163,7 +175,14 @@ typedef struct fvb_config
     int32_t ar_cross_terms; /* option ar1-cross-terms: 0 "none" (2 alphas), 1 "same" (3), 2 "dual" (4); must be 0
                                with one echo. The noise block of the MVN is (alphas, phi means): 2 +
                                ar_cross_terms + n_phis entries (noisemodel_ar.cc:287-300) */
+
+    /* ---- more than FVB_MAX_PARAMS parameters ---- */
+    const fvb_param_table *params_ext; /* NULL: the fixed arrays above; else n_params may exceed FVB_MAX_PARAMS and every
+                                          per-parameter entry is read from this table (the fixed arrays are ignored) */
 } fvb_config;
+
+/* the per-parameter entries wherever they are (host code) */
+#define FVB_PARAM(cfg, field, k) ((cfg)->params_ext ? (cfg)->params_ext->field[k] : (cfg)->field[k])
 
 /* Result arrays; any pointer may be NULL if that output is not wanted, except mvn. */
 typedef struct fvb_outputs

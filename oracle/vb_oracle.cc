@@ -520,7 +520,7 @@ struct Model
     {
         vec tparams(P);
         for (int i = 0; i < P; i++)
-            tparams[i] = to_model(cfg->transform[i], params[i]);
+            tparams[i] = to_model(FVB_PARAM(cfg, transform, i), params[i]);
         EvaluateModel(tparams, result);
     }
 
@@ -546,11 +546,11 @@ struct Model
         Mat cov = post.GetCovariance();
         for (int p = 0; p < P; p++)
         {
-            if (cfg->prior_type[p] == FVB_PRIOR_IMAGE)
-                post.means[p] = cfg->image_prior[p][v];
+            if (FVB_PARAM(cfg, prior_type, p) == FVB_PRIOR_IMAGE)
+                post.means[p] = FVB_PARAM(cfg, image_prior, p)[v];
             else
-                post.means[p] = cfg->post_mean[p];
-            cov(p, p) = cfg->post_var[p];
+                post.means[p] = FVB_PARAM(cfg, post_mean, p);
+            cov(p, p) = FVB_PARAM(cfg, post_var, p);
         }
         post.SetCovariance(cov);
         InitVoxelPosterior(post);
@@ -558,8 +558,8 @@ struct Model
         Mat c2 = post.GetCovariance();
         for (int p = 0; p < P; p++)
         {
-            post.means[p] = to_fabber(cfg->transform[p], post.means[p]);
-            c2(p, p) = to_fabber_var(cfg->transform[p], c2(p, p));
+            post.means[p] = to_fabber(FVB_PARAM(cfg, transform, p), post.means[p]);
+            c2(p, p) = to_fabber_var(FVB_PARAM(cfg, transform, p), c2(p, p));
         }
         post.SetCovariance(c2);
     }
@@ -614,11 +614,11 @@ struct Linearized
                 if (delta < 1e-10)
                     delta = 1e-10;
                 const real c2 = centre[i] + delta, c3 = centre[i] - delta;
-                const int tr = model->cfg->transform[i];
+                const int tr = FVB_PARAM(model->cfg, transform, i);
                 const real p2 = to_model(tr, c2), p3 = to_model(tr, c3);
                 const int e = i / 2;
-                const real amp = to_model(model->cfg->transform[2 * e], centre[2 * e]);
-                const real rate = to_model(model->cfg->transform[2 * e + 1], centre[2 * e + 1]);
+                const real amp = to_model(FVB_PARAM(model->cfg, transform, 2 * e), centre[2 * e]);
+                const real rate = to_model(FVB_PARAM(model->cfg, transform, 2 * e + 1), centre[2 * e + 1]);
                 for (int t = 0; t < T; t++)
                 {
                     const real tt = real(t) * dt;
@@ -1177,21 +1177,21 @@ static Conv *make_conv(int conv, int max_its, int max_trials, real min_fchange)
 // ---------------------------------------------------------------------------------------------
 static real apply_prior(const fvb_config *cfg, int k, Mvn *prior, const Mvn &fwd_post, int v, int it)
 {
-    switch (cfg->prior_type[k])
+    switch (FVB_PARAM(cfg, prior_type, k))
     {
     case FVB_PRIOR_NORMAL: // DefaultPrior::ApplyToMVN :108-117
     {
-        prior->means[k] = cfg->prior_mean[k];
+        prior->means[k] = FVB_PARAM(cfg, prior_mean, k);
         Mat prec = prior->GetPrecisions();
-        prec(k, k) = cfg->prior_prec[k];
+        prec(k, k) = FVB_PARAM(cfg, prior_prec, k);
         prior->SetPrecisions(prec);
         return 0;
     }
     case FVB_PRIOR_IMAGE: // ImagePrior::ApplyToMVN :133-142
     {
-        prior->means[k] = cfg->image_prior[k][v];
+        prior->means[k] = FVB_PARAM(cfg, image_prior, k)[v];
         Mat prec = prior->GetPrecisions();
-        prec(k, k) = cfg->prior_prec[k];
+        prec(k, k) = FVB_PARAM(cfg, prior_prec, k);
         prior->SetPrecisions(prec);
         return 0;
     }
@@ -1203,8 +1203,8 @@ static real apply_prior(const fvb_config *cfg, int k, Mvn *prior, const Mvn &fwd
         real new_cov = post_mean * post_mean + post_cov;
         if (it == 0)
         {
-            cov(k, k) = cfg->prior_var[k];
-            prior->means[k] = cfg->prior_mean[k];
+            cov(k, k) = FVB_PARAM(cfg, prior_var, k);
+            prior->means[k] = FVB_PARAM(cfg, prior_mean, k);
         }
         else
         {
@@ -1587,8 +1587,8 @@ int32_t oracle_vb_postproc(const fvb_config *cfg, const void *data, const double
         for (int p = 0; p < P; p++)
         {
             // FwdModel::ToModel (fwdmodel.cc:326-337)
-            double mm = to_model(cfg->transform[p], means[p]);
-            double mv = to_model_var(cfg->transform[p], var[p]);
+            double mm = to_model(FVB_PARAM(cfg, transform, p), means[p]);
+            double mv = to_model_var(FVB_PARAM(cfg, transform, p), var[p]);
             double sd = std::sqrt(mv);
             if (pp->mean)
                 pp->mean[p * V + v] = mm;

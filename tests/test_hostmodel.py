@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from fabber_core_amd import fabber
+from fabber_core_amd import fabber, hiplib, vbabi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "fabber_core_amd", "csrc", "host")
@@ -315,3 +315,44 @@ def test_twenty_parameter_linear_model_through_the_c_api(tmp_path):
                                 "save-mean": True, "max-iterations": 10})
         for k in range(P):
             assert np.allclose(out["mean_Parameter_%d" % (k + 1)], want[..., k], rtol=1e-4, atol=1e-4), (method, k)
+
+
+@pytest.mark.gpu
+def test_forty_parameter_linear_model():
+    """More than FVB_MAX_PARAMS = 32 parameters (the reference has no limit): the per-parameter entries travel as a table
+    (fvb_config.params_ext) and the wave-per-voxel kernel takes the problem. A 40-column cosine design with an ARD prior
+    and an image prior among the parameters: the engine against the oracle, strict per voxel, and through fabber_dorun
+    against the closed-form least-squares solution, result images (mean, std, zstat, model fit) included."""
+    import oracle
+    import parity
+    rng = np.random.default_rng(14)
+    T, P, V = 160, 40, 300
+    tt = np.arange(T)
+    X = np.stack([np.cos(np.pi * (tt + 0.5) * k / T) for k in range(P)], axis=1)
+    theta = rng.normal(0, 3, (P, V))
+    y = (X @ theta + rng.normal(0, 0.3, (T, V))).astype(np.float32)
+    img = rng.normal(0.0, 1.0, V)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, max_iterations=6, need_f=True,
+                           param_overrides={"Parameter_38": dict(type="A"), "Parameter_5": dict(type="I", prec=0.5)},
+                           image_priors={"Parameter_5": img})
+    assert h.cfg.n_params == 40 and h.cfg.params_ext
+    assert hiplib.kernel_name(h) == "wave"
+    cpu, got = oracle.run(h, y), hiplib.run_host(h, y)
+    parity.strict(h, cpu, got, what="forty parameters", check_f=True, cpu2=oracle.run_fma(h, y))
+    # the C ABI: 5 x 4 x 3 voxels, flat priors -> the least-squares means
+    shape = (5, 4, 3)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savetxt(os.path.join(tmp, "design.mat"), X)
+        th = rng.normal(0, 3, shape + (P,))
+        data = (th @ X.T + rng.normal(0, 0.3, shape + (T,))).astype(np.float32)
+        want = np.linalg.lstsq(X, data.reshape(-1, T).T.astype(np.float64), rcond=None)[0].T.reshape(shape + (P,))
+        out = fabber.run(data, {"model": "linear", "basis": os.path.join(tmp, "design.mat"), "noise": "white", "method": "vb",
+                                "save-mean": True, "save-std": True, "save-zstat": True, "save-model-fit": True, "max-iterations": 10})
+        for k in range(P):
+            assert np.allclose(out["mean_Parameter_%d" % (k + 1)], want[..., k], rtol=1e-4, atol=1e-4), k
+            assert np.all(out["std_Parameter_%d" % (k + 1)] > 0)
+        assert np.sqrt(np.mean((out["modelfit"] - data) ** 2)) < 0.4
+        # what has no wide form says so: method=nlls, AR(1) noise
+        with pytest.raises(Exception, match="parameters"):
+            fabber.run(data, {"model": "linear", "basis": os.path.join(tmp, "design.mat"), "noise": "white", "method": "nlls", "max-iterations": 3})
