@@ -64,7 +64,8 @@ int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_no
         return fail(-3, "bad n_voxels / n_times");
     if (cfg->n_params <= 0 || cfg->n_params > (cfg->params_ext ? FVB_MAX_PARAMS_EXT : FVB_MAX_PARAMS))
         return fail(-4, cfg->params_ext ? "n_params out of range" : "n_params out of range (more than FVB_MAX_PARAMS parameters: fvb_config.params_ext)");
-    if (cfg->params_ext && (cfg->noise != FVB_NOISE_WHITE || allow_spatial))
+    // (allow_no_noise: the post-processing of a result image, which such problems have like any other)
+    if (cfg->params_ext && (cfg->noise != FVB_NOISE_WHITE || (allow_spatial && !allow_no_noise)))
         return fail(-4, "a parameter table (more than FVB_MAX_PARAMS parameters) runs voxelwise VB under white noise only");
     // (a result image without noise entries - method=nlls - can only be post-processed)
     if ((cfg->n_phis <= 0 && !(allow_no_noise && cfg->n_phis == 0)) || cfg->n_phis > FVB_MAX_PHIS)
