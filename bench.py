@@ -84,10 +84,10 @@ def pmc_profile(workload, V, kernel, args, kernel_ms):
     WRITE_SIZE in separate rocprofv3 --pmc passes of this very command, scaled by the bytes-per-count measured with
     tools/pmc_calib on the kernels' own access widths; the fp64 instruction counters and GRBM_GUI_ACTIVE in a third).
     Counters cannot be read from inside the timed run, so the figures are attached only when the committed profile
-    is of the same workload, size, kernel and default engine settings; rates use the LIVE kernel time."""
-    path = os.path.join(ROOT, "profiles", "r3_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r2_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
+    is of the same workload, size, kernel and default engine settings. Every rate and fraction here is the PROFILE's:
+    a pass's counters over the kernel's duration in that same pass (the live kernel time of this run is roofline.kernel_ms;
+    it is not mixed into them)."""
+    path = os.path.join(ROOT, "profiles", "r4_pmc_%s%s.json" % (workload, "_needf" if args.need_f else ""))
     if not os.path.exists(path) or V != WORKLOADS[workload]["voxels"] or args.variant != "auto" \
             or args.residual != "auto" or args.residual_tol is not None:
         return {"traffic": None}
@@ -106,18 +106,18 @@ def pmc_profile(workload, V, kernel, args, kernel_ms):
                                       "the tiled copy is written and read once more, plus what is left of register spills"}}
     clock = der.get("shader_clock_ghz")
     valu = ctr.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
-    if valu and clock:
+    if valu and der.get("valu_issue_utilisation"):
         # one fp64 VALU instruction of a 64-lane wave occupies its SIMD's 16-lane pipe for 4 cycles
         out["valu_issue"] = {"valu_wave_instructions": valu, "simds": N_SIMDS, "shader_clock_ghz_measured": clock,
-                             "clock_source": "GRBM_GUI_ACTIVE / 8 / kernel time of the profiled launch",
-                             "utilisation": valu * 4 / (N_SIMDS * prof["kernel_trace"]["avg_ns"] * clock),
+                             "cycles_source": "GRBM_GUI_ACTIVE / 8 of the same counter pass as SQ_INSTS_VALU",
+                             "utilisation": der["valu_issue_utilisation"],
                              "wait_any_over_wave_cycles": ctr["SQ_WAIT_ANY"]["mean_per_launch"] / ctr["SQ_WAVE_CYCLES"]["mean_per_launch"]}
     if der.get("fp64_flop_per_launch"):
-        flop = der["fp64_flop_per_launch"]
-        out["fp64_executed"] = {"flop_per_launch": flop, "achieved": flop / (kernel_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
-                                "vector_peak_at_2p4ghz": FP64_VALU_PEAK_TFLOPS,
-                                "frac": flop / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                "counted": "(2 x SQ_INSTS_VALU_FMA_F64 + ADD_F64 + MUL_F64) x 64 lanes, executed"}
+        out["fp64_executed"] = {"flop_per_launch": der["fp64_flop_per_launch"], "achieved": der["fp64_tflops"], "unit": "TFLOP/s",
+                                "vector_peak_at_2p4ghz": FP64_VALU_PEAK_TFLOPS, "frac": der["fp64_frac_of_peak"],
+                                "profiled_kernel_ms": der["fp64_pass_avg_ns"] / 1e6,
+                                "counted": "(2 x SQ_INSTS_VALU_FMA_F64 + ADD_F64 + MUL_F64) x 64 lanes, executed, over the "
+                                           "kernel's duration in the pass that counted them"}
     return out
 
 
@@ -156,14 +156,14 @@ def bench_spatial(args, world, rank, device):
                 "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dev_ms,
                 "note": "device time of one run between HIP events (all its kernels; the host builds no tables in between); "
-                        "per-kernel durations: profiles/r3_kernel_stats_c5.csv"}
-    # HBM bytes of one run from the committed counter passes of this very command (tools/r3_profiles.sh ->
+                        "per-kernel durations: profiles/r4_kernel_stats_c5.csv"}
+    # HBM bytes of one run from the committed counter passes of this very command (tools/r4_profiles.sh ->
     # tools/pmc_c5_merge.py): attached when the profile is of the same problem
-    pmc = os.path.join(ROOT, "profiles", "r3_pmc_c5.json")
+    pmc = os.path.join(ROOT, "profiles", "r4_pmc_c5.json")
     if os.path.exists(pmc) and n == w["grid"] and not args.need_f and args.prior_type == "M":
         prof = json.load(open(pmc))
         roofline["traffic"] = prof["per_run"]["traffic"]
-        roofline["traffic_detail"] = {"source": "profiles/r3_pmc_c5.json", "fetch_bytes": prof["per_run"]["fetch_bytes"],
+        roofline["traffic_detail"] = {"source": "profiles/r4_pmc_c5.json", "fetch_bytes": prof["per_run"]["fetch_bytes"],
                                       "write_bytes": prof["per_run"]["write_bytes"],
                                       "profiled_kernel_ms": prof["per_run"]["kernel_ms"],
                                       "by_kernel_gb": {k: (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_run"] / 1e9

@@ -42,7 +42,7 @@ def main():
         total["write_bytes"] += k["write_bytes_per_launch"] * k["launches_per_run"]
         total["kernel_ms"] += k["avg_ms"] * k["launches_per_run"]
     total["traffic"] = total["fetch_bytes"] + total["write_bytes"]
-    total["note"] = ("prep, ordered sweep, second sweep (both instances) and set-up kernels; the a_K sums, the numbering "
+    total["note"] = ("prep, ordered sweep, second sweep (both instances), set-up and a_K partial-sum kernels; the a_K reductions, the numbering "
                      "kernels and the copies are not counted (3 % of the run's device time)")
     json.dump({"workload": "c5", "runs_profiled": runs, "kernels": kernels, "per_run": total}, sys.stdout, indent=1)
 

@@ -11,18 +11,23 @@ import os
 import sys
 
 
-def counters(d, match):
-    """{counter: [value per dispatch]} for kernels whose name contains `match`."""
+def counters(d, match, durations=None):
+    """{counter: [value per dispatch]} for kernels whose name contains `match`; `durations` (a list) receives the
+    duration in ns of every such dispatch IN THIS PASS (the counter rows carry the dispatch's own timestamps)."""
     out = {}
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
-        per = {}
+        per, span = {}, {}
         for row in csv.DictReader(open(f)):
             if match not in row["Kernel_Name"]:
                 continue
             key = (row["Dispatch_Id"], row["Counter_Name"])
             per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            if row.get("End_Timestamp"):
+                span[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         for (disp, name), val in per.items():
             out.setdefault(name, []).append(val)
+        if durations is not None:
+            durations.extend(span.values())
     return out
 
 
@@ -71,26 +76,37 @@ def main():
                     if (ctr == "FETCH_SIZE") == base.startswith("read"):
                         calib[pat + " " + ctr] = dict(counter=mean(vals), true_bytes=nbytes, bytes_per_count=nbytes / mean(vals))
     out["calibration"] = calib
-    res = {}
+    res, pass_ns = {}, {}
     for which in ("fetch", "write", "sq", "fp64", "mem"):
-        for name, vals in counters(os.path.join(root, which), match).items():
-            res[name] = dict(mean_per_launch=mean(vals), launches=len(vals))
+        dur = []
+        for name, vals in counters(os.path.join(root, which), match, dur).items():
+            res[name if name not in res else name + "@" + which] = dict(mean_per_launch=mean(vals), launches=len(vals), counter_pass=which)
+        if dur:
+            pass_ns[which] = dict(avg_ns=mean(dur), launches=len(dur))
     out["counters"] = res
+    out["pass_durations"] = pass_ns  # the kernel's duration inside each counter pass (counters slow a kernel down a little)
     # derived: shader clock held during the kernel, executed fp64 FLOP/s, VALU issue utilisation at that clock
     kt = out["kernel_trace"]
     g = lambda n: res.get(n, {}).get("mean_per_launch")
-    if kt and g("GRBM_GUI_ACTIVE"):
-        # (the profiled pass's own duration would be the right divisor; the trace pass's is within ~3 %)
-        clock_ghz = g("GRBM_GUI_ACTIVE") / 8 / kt["avg_ns"]
-        d = {"shader_clock_ghz": clock_ghz}
+    gui = [k for k in res if k.startswith("GRBM_GUI_ACTIVE") and res[k]["counter_pass"] == "fp64"]
+    if kt and gui and "fp64" in pass_ns:
+        # Every derived figure divides a pass's counters by the kernel's duration IN THAT SAME PASS (round-3 verdict:
+        # a fraction built from one run's counters and another run's clock is not a measurement of either).
+        t_fp64 = pass_ns["fp64"]["avg_ns"]
+        clock_ghz = res[gui[0]]["mean_per_launch"] / 8 / t_fp64
+        d = {"shader_clock_ghz": clock_ghz, "fp64_pass_avg_ns": t_fp64, "trace_pass_avg_ns": kt["avg_ns"]}
         if g("SQ_INSTS_VALU_FMA_F64") is not None:
             flop = (2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")) * 64
             d["fp64_flop_per_launch"] = flop
-            d["fp64_tflops"] = flop / kt["avg_ns"] / 1e3
+            d["fp64_tflops"] = flop / t_fp64 / 1e3
             d["fp64_vector_peak_tflops_at_2p4ghz"] = 78.6
             d["fp64_frac_of_peak"] = d["fp64_tflops"] / 78.6
-        if g("SQ_INSTS_VALU"):
-            d["valu_issue_utilisation"] = g("SQ_INSTS_VALU") * 4 / (1024 * kt["avg_ns"] * clock_ghz)
+        gui_sq = [k for k in res if k.startswith("GRBM_GUI_ACTIVE") and res[k]["counter_pass"] == "sq"]
+        if g("SQ_INSTS_VALU") and gui_sq:
+            # cycles of the sq pass itself: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            d["valu_issue_utilisation"] = g("SQ_INSTS_VALU") * 4 / (1024 * res[gui_sq[0]]["mean_per_launch"] / 8)
+        elif g("SQ_INSTS_VALU") and "sq" in pass_ns:
+            d["valu_issue_utilisation"] = g("SQ_INSTS_VALU") * 4 / (1024 * pass_ns["sq"]["avg_ns"] * clock_ghz)
         out["derived"] = d
     print(json.dumps(out, indent=1))
 
