@@ -194,7 +194,7 @@ def bench_spatial(args, world, rank, device):
     result = {"metric": "voxels/sec to VB convergence", "value": V * args.steps / elapsed, "unit": "voxels/s", "n_gpus": 1,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-              "config": {"workload": w["desc"], "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
+              "config": {"workload": w["desc"].replace("(type M)", "(type %s)" % args.prior_type), "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
                          "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32", "spatial_prior_type": args.prior_type,
                          "bad_voxels": int(np.count_nonzero(got["status"])), "ms_per_iteration": dev_ms / w["its"]},
               "roofline": roofline, "cpu_baseline": cpu}
@@ -248,7 +248,7 @@ def bench_spatial_multi(args, world, rank, device):
     result = {"metric": "voxels/sec to VB convergence", "value": V * args.steps / elapsed, "unit": "voxels/s", "n_gpus": world,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-              "config": {"workload": w["desc"], "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
+              "config": {"workload": w["desc"].replace("(type M)", "(type %s)" % args.prior_type), "grid": [n, n, n], "total_voxels": V, "timepoints": T, "params": P,
                          "iterations": w["its"], "need_f": bool(args.need_f), "input_dtype": "f32", "spatial_prior_type": args.prior_type,
                          "slabs": n_slabs, "route": route, "bad_voxels": int(np.count_nonzero(got["status"])),
                          "parallelism": "%d z-slab(s) on %s, driven by rank 0 through fabber_vb_spatial_multi_* (series resident per device; "

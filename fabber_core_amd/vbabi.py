@@ -14,7 +14,8 @@ import numpy as np
 
 FVB_MAX_PARAMS = 32
 FVB_MAX_PHIS = 8
-FVB_ABI_VERSION = 8
+FVB_MAX_ALPHAS = 4
+FVB_ABI_VERSION = 9
 
 MODEL_POLY, MODEL_LINEAR, MODEL_EXP, MODEL_HOSTJAC = 0, 1, 2, 100
 TRANSFORM_IDENTITY, TRANSFORM_LOG, TRANSFORM_SOFTPLUS, TRANSFORM_FRACTIONAL, TRANSFORM_ABS = range(5)
@@ -70,6 +71,11 @@ class FvbConfig(C.Structure):
         ("f_history_rows", C.c_int32),
         ("data_f64", C.c_int32),
         ("ar_cross_terms", C.c_int32),
+        ("ar_alpha_given", C.c_int32),
+        ("ar_alpha_prior_mean", C.c_double * FVB_MAX_ALPHAS),
+        ("ar_alpha_prior_prec", (C.c_double * FVB_MAX_ALPHAS) * FVB_MAX_ALPHAS),
+        ("ar_alpha_post_mean", C.c_double * FVB_MAX_ALPHAS),
+        ("ar_alpha_post_cov", (C.c_double * FVB_MAX_ALPHAS) * FVB_MAX_ALPHAS),
         ("params_ext", C.c_void_p),
     ]
 
@@ -194,7 +200,8 @@ def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps
                  convergence="maxits", max_iterations=10, min_fchange=0.01, max_trials=10,
                  need_f=None, f_history_rows=0, noise_pattern="1", masked_timepoints=(),
                  prior_noise_stddev=-1.0, locked_noise_stdev=-1.0, param_overrides=None,
-                 image_priors=None, init_mvn=None, noise=NOISE_WHITE, num_echoes=1, ar_cross_terms="none"):
+                 image_priors=None, init_mvn=None, noise=NOISE_WHITE, num_echoes=1, ar_cross_terms="none",
+                 ar_alpha_prior=None, ar_alpha_post=None):
     """Resolve options into an fvb_config whose pointer members are HOST numpy arrays.
 
     param_overrides: {name: dict(type=, mean=, prec=, transform=)} == PSP_byname options
@@ -307,6 +314,19 @@ def build_config(model, n_voxels, n_times, *, degree=None, design=None, num_exps
     if noise == NOISE_AR1:  # noisemodel_ar.cc:322-403
         cfg.n_phis = num_echoes
         cfg.ar_cross_terms = {"none": 0, "same": 1, "dual": 2}[ar_cross_terms]
+        # noise-initial-prior / -posterior for the AR(1) coefficients: (mean, precision matrix) and (mean, covariance)
+        nA = 2 + cfg.ar_cross_terms
+        for bit, given, mean_f, mat_f in ((1, ar_alpha_prior, cfg.ar_alpha_prior_mean, cfg.ar_alpha_prior_prec),
+                                          (2, ar_alpha_post, cfg.ar_alpha_post_mean, cfg.ar_alpha_post_cov)):
+            if given is None:
+                continue
+            mean, mat = np.asarray(given[0], dtype=np.float64), np.asarray(given[1], dtype=np.float64)
+            assert mean.shape == (nA,) and mat.shape == (nA, nA) and np.array_equal(mat, mat.T)
+            cfg.ar_alpha_given |= bit
+            for i in range(nA):
+                mean_f[i] = mean[i]
+                for j in range(nA):
+                    mat_f[i][j] = mat[i, j]
         for i in range(num_echoes):
             cfg.noise_prior_b[i], cfg.noise_prior_c[i] = 1e6, 1e-6
             cfg.noise_post_b[i], cfg.noise_post_c[i] = 1e-8, 1e-6

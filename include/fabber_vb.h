@@ -45,7 +45,8 @@ extern "C" {
 #define FVB_MAX_PARAMS 32
 #define FVB_MAX_PARAMS_EXT 128 /* with fvb_config.params_ext (the wave-per-voxel kernel; what its LDS holds decides) */
 #define FVB_MAX_PHIS 8
-#define FVB_ABI_VERSION 8
+#define FVB_MAX_ALPHAS 4 /* AR(1) coefficients: 2 + ar_cross_terms (noisemodel_ar.cc:360-377) */
+#define FVB_ABI_VERSION 9
 
 /* Forward models with a device body (fwdmodel_poly.cc:62, fwdmodel_linear.cc:92,
  * examples/fwdmodel_exp.cc:65). FVB_MODEL_HOSTJAC = model only exists as a host plugin;
@@ -175,6 +176,17 @@ typedef struct fvb_config
     int32_t ar_cross_terms; /* option ar1-cross-terms: 0 "none" (2 alphas), 1 "same" (3), 2 "dual" (4); must be 0
                                with one echo. The noise block of the MVN is (alphas, phi means): 2 +
                                ar_cross_terms + n_phis entries (noisemodel_ar.cc:287-300) */
+
+    /* ---- AR(1): the alpha distributions of noise-initial-prior / noise-initial-posterior
+     * (Vb::InitializeNoiseFromParam, inference_vb.cc:132-142 -> Ar1cParams::InputFromMVN, noisemodel_ar.cc:302-316).
+     * The Gamma part of those files arrives through noise_prior_b/c and noise_post_b/c like under white noise. ---- */
+    int32_t ar_alpha_given;                    /* bit 0: ar_alpha_prior_* hold the prior; bit 1: ar_alpha_post_* the initial
+                                                  posterior; a clear bit: HardcodedInitialDists (noisemodel_ar.cc:391-394:
+                                                  zero mean, precision 1e-4 I) */
+    double ar_alpha_prior_mean[FVB_MAX_ALPHAS];
+    double ar_alpha_prior_prec[FVB_MAX_ALPHAS][FVB_MAX_ALPHAS]; /* symmetric; GetPrecisions() of the file's covariance block */
+    double ar_alpha_post_mean[FVB_MAX_ALPHAS];
+    double ar_alpha_post_cov[FVB_MAX_ALPHAS][FVB_MAX_ALPHAS];   /* symmetric */
 
     /* ---- more than FVB_MAX_PARAMS parameters ---- */
     const fvb_param_table *params_ext; /* NULL: the fixed arrays above; else n_params may exceed FVB_MAX_PARAMS and every
