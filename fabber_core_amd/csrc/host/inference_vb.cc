@@ -344,27 +344,65 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
         const string filename = rundata.GetStringDefault(key, "modeldefault");
         if (filename == "modeldefault")
             continue;
-        if (cfg.noise != FVB_NOISE_WHITE)
-            throw InvalidOptionValue(key, filename, "Loading the AR(1) noise distributions from file is not supported by the MI355X engine");
         LOG << "VbInferenceTechnique::Loading " << key << " distribution from " << filename << endl;
         MVNDist dist(filename, m_log);
-        if (dist.GetSize() != cfg.n_phis)
+        // AR(1): the alphas first, then the precisions (Ar1cParams::InputFromMVN, noisemodel_ar.cc:302-316)
+        const int nAlpha = (cfg.noise == FVB_NOISE_AR1) ? 2 + cfg.ar_cross_terms : 0;
+        if (dist.GetSize() != nAlpha + cfg.n_phis)
             throw InvalidOptionValue(key, filename, "The distribution has " + stringify(dist.GetSize()) + " entries, the noise model "
-                    + stringify(cfg.n_phis) + " precisions");
+                    + stringify(nAlpha + cfg.n_phis));
         const NEWMAT::SymmetricMatrix &cov = dist.GetCovariance();
         const bool prior = string(key) == "noise-initial-prior";
-        for (int i = 1; i <= cfg.n_phis; i++) // WhiteParams::InputFromMVN, noisemodel_white.cc:70-79
-            for (int j = i + 1; j <= cfg.n_phis; j++)
+        if (nAlpha)
+        {
+            // alpha.CopyFromSubmatrix(mvn, 1, nAlpha, true): the block must be independent of the rest (dist_mvn.cc:157-165)
+            for (int i = 1; i <= nAlpha; i++)
+                for (int j = nAlpha + 1; j <= nAlpha + cfg.n_phis; j++)
+                    if (cov(i, j) != 0)
+                        throw FabberRunDataError("Covariance found in part of MVN that should be independent from the rest!");
+            NEWMAT::SymmetricMatrix block(cov.SymSubMatrix(1, nAlpha));
+            // a distribution over the alphas has a positive definite covariance (the reference would carry its inverse
+            // - whatever it is - into UpdateAlpha and the free energy)
+            NEWMAT::SymmetricMatrix inverse;
+            bool usable = true;
+            try
+            {
+                inverse = block.i();
+            }
+            catch (...)
+            {
+                usable = false;
+            }
+            for (int i = 1; usable && i <= nAlpha; i++)
+                usable = block(i, i) > 0 && inverse(i, i) > 0 && inverse(i, i) - inverse(i, i) == 0;
+            if (!usable)
+                throw InvalidOptionValue(key, filename, "The covariance of the AR(1) coefficients needs to be positive definite");
+            cfg.ar_alpha_given |= prior ? 1 : 2;
+            for (int i = 0; i < nAlpha; i++)
+            {
+                (prior ? cfg.ar_alpha_prior_mean : cfg.ar_alpha_post_mean)[i] = dist.means(i + 1);
+                for (int j = 0; j < nAlpha; j++)
+                {
+                    if (prior)
+                        cfg.ar_alpha_prior_prec[i][j] = inverse(i + 1, j + 1); // MVNDist::GetPrecisions
+                    else
+                        cfg.ar_alpha_post_cov[i][j] = block(i + 1, j + 1);
+                }
+            }
+        }
+        for (int i = nAlpha + 1; i <= nAlpha + cfg.n_phis; i++) // WhiteParams::InputFromMVN, noisemodel_white.cc:70-79; noisemodel_ar.cc:311-315
+            for (int j = i + 1; j <= nAlpha + cfg.n_phis; j++)
                 if (cov(i, j) != 0)
                     throw FabberRunDataError("Phis should have zero covariance!");
         for (int i = 0; i < cfg.n_phis; i++)
         {
             // a Gamma distribution has a positive mean and a positive variance (the reference would carry a
             // negative scale or a division by zero into its first update)
-            if (!(dist.means(i + 1) > 0) || !(cov(i + 1, i + 1) > 0))
+            const int q = nAlpha + i + 1;
+            if (!(dist.means(q) > 0) || !(cov(q, q) > 0))
                 throw InvalidOptionValue(key, filename, "Noise precision " + stringify(i + 1) + " needs a positive mean and a positive variance");
-            const double b = cov(i + 1, i + 1) / dist.means(i + 1); // GammaDist::SetMeanVariance
-            const double c = dist.means(i + 1) / b;
+            const double b = cov(q, q) / dist.means(q); // GammaDist::SetMeanVariance
+            const double c = dist.means(q) / b;
             (prior ? cfg.noise_prior_b : cfg.noise_post_b)[i] = b;
             (prior ? cfg.noise_prior_c : cfg.noise_post_c)[i] = c;
         }
@@ -445,10 +483,17 @@ void Vb::BuildInitialMvn(FabberRunData &rundata, fvb_config &cfg)
                 img.at0(i * (i + 1) / 2 + j, v) = cov(i + 1, j + 1);
             img.at0(nCov + i, v) = post.means(i + 1);
         }
-        for (int a = 0; a < NA; a++) // Ar1cNoiseModel's initial alpha posterior: N(0, 1e4 I) (noisemodel_ar.cc:379-403)
-        {
+        for (int a = 0; a < NA; a++) // Ar1cNoiseModel's initial alpha posterior: N(0, 1e4 I) (noisemodel_ar.cc:379-403),
+        {                            // or the one of noise-initial-posterior
             const int q = P + a;
-            img.at0(q * (q + 1) / 2 + q, v) = 1e4;
+            if (cfg.ar_alpha_given & 2)
+            {
+                for (int a2 = 0; a2 <= a; a2++)
+                    img.at0(q * (q + 1) / 2 + P + a2, v) = cfg.ar_alpha_post_cov[a][a2];
+                img.at0(nCov + q, v) = cfg.ar_alpha_post_mean[a];
+            }
+            else
+                img.at0(q * (q + 1) / 2 + q, v) = 1e4;
         }
         for (int k = 0; k < N; k++)
         {

@@ -122,6 +122,10 @@ LaneKernelInfo select_lane(const fvb_config *cfg)
 {
     if (g_variant == 2 || (cfg->n_phis != 1 && cfg->noise == FVB_NOISE_WHITE && cfg->n_phis > 4))
         return LaneKernelInfo{ nullptr, 0, nullptr };
+    // alpha distributions from noise-initial-prior / -posterior: the lane kernels carry the hard-coded prior's diagonal
+    // form (vb_lane_ar_kernel.h); the wave-per-voxel kernel takes any
+    if (cfg->noise == FVB_NOISE_AR1 && cfg->ar_alpha_given)
+        return LaneKernelInfo{ nullptr, 0, nullptr };
     if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 2) // two echoes: the two-pass kernel of vb_lane_arn_kernel.h
     {
         if (cfg->n_times % 2 != 0 || cfg->n_times < 8 || (g_variant == 0 && cfg->n_voxels < WAVE_KERNEL_BELOW_VOXELS))

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void vb_wave_ar_step_kernel(const HmArgs ha)
         }
         ar_residual(cx);
         ar_j_sigma(cx);
-        status = ar_update_alpha<NPHI, NA>(cx, st);
+        status = ar_update_alpha<NPHI, NA>(ka, cx, st);
         if (status != FVB_OK)
         {
             done = true;

@@ -403,7 +403,7 @@ __device__ __forceinline__ bool ar_update_theta(WaveCtx &cx, const ArState<NPHI,
 
 // Ar1cNoiseModel::UpdateAlpha (noisemodel_ar.cc:447-528). Needs L.k and L.JS. Returns a status.
 template <int NPHI, int NA>
-__device__ __forceinline__ int ar_update_alpha(WaveCtx &cx, ArState<NPHI, NA> &st)
+__device__ __forceinline__ int ar_update_alpha(const KernelArgs &ka, WaveCtx &cx, ArState<NPHI, NA> &st)
 {
     const WaveLayout &L = cx.L;
     const double *sh = cx.sh;
@@ -412,13 +412,19 @@ __device__ __forceinline__ int ar_update_alpha(WaveCtx &cx, ArState<NPHI, NA> &s
     for (int i = 0; i < NPHI; i++)
         sc[i] = sh[L.b + i] * sh[L.c + i];
     double prec[NA][NA], tmp[NA];
+    const bool prior_given = (ka.cfg.ar_alpha_given & 1) != 0; // noise-initial-prior (InputFromMVN, :302-316)
 #pragma unroll
     for (int i = 0; i < NA; i++)
     {
+        tmp[i] = 0; // prior precisions * prior means (:501-502)
 #pragma unroll
         for (int j = 0; j < NA; j++)
-            prec[i][j] = (i == j) ? 1e-4 : 0.0; // prior: zero mean, precision 1e-4 I (:391-394)
-        tmp[i] = 0;                            // prior precisions * prior means
+        {
+            // hard-coded prior: zero mean, precision 1e-4 I (:391-394)
+            prec[i][j] = prior_given ? ka.cfg.ar_alpha_prior_prec[i][j] : ((i == j) ? 1e-4 : 0.0);
+            if (prior_given)
+                tmp[i] += ka.cfg.ar_alpha_prior_prec[i][j] * ka.cfg.ar_alpha_prior_mean[j];
+        }
     }
 #pragma unroll
     for (int i = 1; i <= NPHI; i++)
@@ -557,13 +563,36 @@ __device__ __forceinline__ bool ar_free_energy(const KernelArgs &ka, WaveCtx &cx
     parts += 0.5 * logdetPrior;
     parts += -0.5 * quad;
     parts += -0.5 * trSL0;
-    parts += 0.5 * NA * log(1e-4); // log det of the alpha prior precision 1e-4 I
     double qa = 0, tra = 0;
-#pragma unroll
-    for (int i = 0; i < NA; i++)
+    if (ka.cfg.ar_alpha_given & 1) // the prior of noise-initial-prior: parts [6] - [8] with its mean and precision matrix (:720-729)
     {
-        qa += st.am[i] * 1e-4 * st.am[i];
-        tra += st.acov[i][i] * 1e-4;
+        double p0m[NA][NA], p0i[NA][NA], lp;
+        int sp;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+#pragma unroll
+            for (int j = 0; j < NA; j++)
+                p0m[i][j] = ka.cfg.ar_alpha_prior_prec[i][j];
+        small_sym_inverse<NA>(p0m, p0i, lp, sp);
+        parts += 0.5 * lp;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+#pragma unroll
+            for (int j = 0; j < NA; j++)
+            {
+                qa += (st.am[i] - ka.cfg.ar_alpha_prior_mean[i]) * p0m[i][j] * (st.am[j] - ka.cfg.ar_alpha_prior_mean[j]);
+                tra += st.acov[i][j] * p0m[j][i];
+            }
+    }
+    else
+    {
+        parts += 0.5 * NA * log(1e-4); // log det of the alpha prior precision 1e-4 I
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+        {
+            qa += st.am[i] * 1e-4 * st.am[i];
+            tra += st.acov[i][i] * 1e-4;
+        }
     }
     parts += -0.5 * qa;
     parts += -0.5 * tra;
@@ -708,6 +737,20 @@ __global__ __launch_bounds__(64) void vb_wave_ar_kernel(const KernelArgs ka, con
             st.acov[i][j] = (i == j) ? 1e4 : 0.0;
         }
     }
+    if (ka.cfg.ar_alpha_given & 2) // noise-initial-posterior (inference_vb.cc:205; continue-from-mvn below overrides it, :214)
+    {
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+        {
+            st.am[i] = ka.cfg.ar_alpha_post_mean[i];
+#pragma unroll
+            for (int j = 0; j < NA; j++)
+                st.acov[i][j] = ka.cfg.ar_alpha_post_cov[i][j];
+        }
+        double la0;
+        int sg0;
+        small_sym_inverse<NA>(st.acov, st.aprec, la0, sg0);
+    }
     if (ka.cfg.init_mvn)
     {
         // MVNDist::Load + Ar1cParams::InputFromMVN (dist_mvn.cc:347-374; noisemodel_ar.cc:302-316)
@@ -842,7 +885,7 @@ __global__ __launch_bounds__(64) void vb_wave_ar_kernel(const KernelArgs ka, con
             }
             ar_residual(cx);
             ar_j_sigma(cx);
-            status = ar_update_alpha<NPHI, NA>(cx, st);
+            status = ar_update_alpha<NPHI, NA>(ka, cx, st);
             if (status != FVB_OK)
                 break;
             ar_update_phi<NPHI, NA>(ka, cx, st);

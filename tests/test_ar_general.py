@@ -34,7 +34,7 @@ def alpha_matrix(n, a12, a34, n_phis, n_times):
     return m
 
 
-def dense_ar_vb(X, y, n_phis, n_alphas, iterations):
+def dense_ar_vb(X, y, n_phis, n_alphas, iterations, alpha_prior=None, alpha_post=None):
     """Vb::DoCalculationsVoxelwise with Ar1cNoiseModel for one voxel of a linear model with the
     default priors (precision 1e-12 on theta): UpdateTheta, UpdateAlpha, UpdatePhi per iteration."""
     T, P = X.shape
@@ -42,8 +42,12 @@ def dense_ar_vb(X, y, n_phis, n_alphas, iterations):
     M = lambda n, a, b: alpha_matrix(n, a, b, n_phis, nT)
     L0, m0 = np.eye(P) * 1e-12, np.zeros(P)
     theta = np.zeros(P)
-    A0 = np.eye(n_alphas) * 1e-4
+    A0, a0 = np.eye(n_alphas) * 1e-4, np.zeros(n_alphas)
     a_mean, a_prec = np.zeros(n_alphas), A0.copy()
+    if alpha_prior is not None:                         # noise-initial-prior: InputFromMVN, :302-316
+        a0, A0 = np.array(alpha_prior[0], dtype=float), np.array(alpha_prior[1], dtype=float)
+    if alpha_post is not None:                          # noise-initial-posterior
+        a_mean, a_prec = np.array(alpha_post[0], dtype=float), np.linalg.inv(alpha_post[1])
     b0, c0 = 1e6, 1e-6
     b = np.full(n_phis, 1e-8)
     c = np.full(n_phis, c0 + (nT - 1) * 0.5)          # Precalculate, :765-768
@@ -78,7 +82,7 @@ def dense_ar_vb(X, y, n_phis, n_alphas, iterations):
             prec[Tn - 1, 1] += 0.5 * sc[1] * op(M(2, 1, 1)); prec[1, Tn - 1] = prec[Tn - 1, 1]
             prec[2, 2] += sc[0] * op(M(1, 0, 2))
             prec[Tn - 1, Tn - 1] += sc[1] * op(M(2, 0, 2))
-        tmp = A0 @ np.zeros(n_alphas)
+        tmp = A0 @ a0                                  # :501-502
         for i in range(1, n_phis + 1):
             tmp[i - 1] += -0.5 * sc[i - 1] * op(M(i, 1, 0))
         if Tn > 2:
@@ -148,6 +152,53 @@ def test_two_echoes_against_the_dense_transcription(cross, n_alphas):
         assert np.allclose(means[4 + n_alphas:], phi, rtol=1e-6)
 
 
+def alpha_distributions(n_alphas, seed):
+    """A prior and an initial posterior over the AR(1) coefficients with off-diagonal terms, as a noise-initial-prior /
+    noise-initial-posterior file would give them: (mean, PRECISION matrix), (mean, COVARIANCE matrix)."""
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(n_alphas, n_alphas))
+    prec = 0.5 * (a @ a.T) + 3.0 * np.eye(n_alphas)     # an informative prior: its mean must show in the posterior
+    b = rng.normal(size=(n_alphas, n_alphas))
+    cov = 0.01 * (b @ b.T) + 0.05 * np.eye(n_alphas)
+    return (rng.uniform(-0.3, 0.3, n_alphas), prec), (rng.uniform(-0.2, 0.2, n_alphas), cov)
+
+
+@pytest.mark.parametrize("cross,n_alphas", [("none", 2), ("same", 3), ("dual", 4)])
+def test_alpha_distributions_from_file_against_the_dense_transcription(cross, n_alphas):
+    """Ar1cParams::InputFromMVN (noisemodel_ar.cc:302-316): the prior's mean and precision matrix enter UpdateAlpha
+    (:468, :501-502) and the free energy, the initial posterior the first marginals"""
+    prior, post = alpha_distributions(n_alphas, seed=n_alphas)
+    h, y, X = two_echo_problem(5, 40, seed=8, cross=cross, max_iterations=4, ar_alpha_prior=prior, ar_alpha_post=post)
+    res = oracle.run(h, y.astype(np.float64))
+    plain = oracle.run(two_echo_problem(5, 40, seed=8, cross=cross, max_iterations=4)[0], y.astype(np.float64))
+    assert np.all(res["status"] == 0)
+    n = 4 + n_alphas + 2
+    off = n * (n + 1) // 2
+    assert np.abs(res["mvn"][off + 4:off + 4 + n_alphas] - plain["mvn"][off + 4:off + 4 + n_alphas]).max() > 1e-3
+    for v in range(5):
+        theta, cov, a_mean, a_cov, phi = dense_ar_vb(X, y[:, v], 2, n_alphas, 4, alpha_prior=prior, alpha_post=post)
+        means, full = unpack(res, h, v)
+        assert np.allclose(means[:4], theta, rtol=1e-6, atol=1e-8), (cross, v)
+        assert np.allclose(means[4:4 + n_alphas], a_mean, rtol=1e-6, atol=1e-9)
+        assert np.allclose(full[4:4 + n_alphas, 4:4 + n_alphas], a_cov, rtol=1e-5, atol=1e-12)
+        assert np.allclose(means[4 + n_alphas:], phi, rtol=1e-6)
+
+
+def test_one_echo_alpha_distributions_in_both_restatements(monkeypatch):
+    prior, post = alpha_distributions(2, seed=11)
+    # (three iterations: the two restatements agree to 1e-14 after one and drift apart by a factor of ~50 per iteration
+    # on this design, with the hard-coded distributions as well)
+    h, y = cases.linear_problem(20, 50, seed=3, max_iterations=3, noise=AR, need_f=True, ar_alpha_prior=prior, ar_alpha_post=post)
+    a = oracle.run(h, y)
+    monkeypatch.setenv("ORACLE_AR_GENERAL", "1")
+    b = oracle.run(h, y)
+    assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
+    assert np.allclose(a["mvn"], b["mvn"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(a["free_energy"], b["free_energy"], rtol=1e-9)
+    hp, _ = cases.linear_problem(20, 50, seed=3, max_iterations=3, noise=AR, need_f=True)
+    assert not np.allclose(oracle.run(hp, y)["free_energy"], a["free_energy"], rtol=1e-6)
+
+
 def test_two_echoes_recover_the_two_noise_levels():
     h, y, _ = two_echo_problem(40, 200, seed=6, cross="none", max_iterations=10)
     res = oracle.run(h, y.astype(np.float32))
@@ -192,6 +243,26 @@ def assert_close_to_oracle(h, y, ref=None, rtol=1e-6):
     if h.cfg.need_f:
         assert np.allclose(got["free_energy"][ok], ref["free_energy"][ok], rtol=1e-7, atol=1e-6)
     return ref, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("echoes,cross", [(1, "none"), (2, "none"), (2, "same"), (2, "dual")])
+def test_alpha_distributions_from_file_on_the_gpu(echoes, cross):
+    """noise-initial-prior / -posterior under AR(1) noise: at any size the run takes the wave-per-voxel kernel"""
+    n_alphas = 2 + {"none": 0, "same": 1, "dual": 2}[cross]
+    prior, post = alpha_distributions(n_alphas, seed=20 + n_alphas)
+    for V, only in ((300, "both"), (5000, "prior"), (64, "post")):
+        opts = dict(max_iterations=5, need_f=True)
+        if only in ("both", "prior"):
+            opts["ar_alpha_prior"] = prior
+        if only in ("both", "post"):
+            opts["ar_alpha_post"] = post
+        if echoes == 2:
+            h, y, _ = two_echo_problem(V, 40, seed=9, cross=cross, **opts)
+        else:
+            h, y = cases.linear_problem(V, 50, seed=4, noise=AR, **opts)
+        assert_close_to_oracle(h, y.astype(np.float32))
+        assert "wave" in hiplib.kernel_name(h), hiplib.kernel_name(h)
 
 
 @pytest.mark.gpu

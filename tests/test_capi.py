@@ -414,3 +414,76 @@ def test_noise_distributions_from_matrix_files(tmp_path):
         f.write_text(text)
         with pytest.raises(fabber.FabberError, match="positive mean and a positive variance"):
             fabber.run(data, dict(opts, **{"noise-initial-prior": str(f)}))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("echoes,cross", [(1, "none"), (2, "dual")])
+def test_ar_noise_distributions_from_matrix_files(tmp_path, echoes, cross):
+    """noise-initial-prior / noise-initial-posterior under AR(1) noise (Ar1cParams::InputFromMVN, noisemodel_ar.cc:302-316):
+    the file holds the alphas' MVN block first, then one Gamma per echo by mean and variance. (1) The hard-coded
+    distributions (noisemodel_ar.cc:391-401) written to files give the default run; (2) an informative prior with
+    covariance between the alphas gives what the oracle computes from the same distributions; (3) what InputFromMVN
+    rejects is rejected."""
+    import oracle
+    rng = np.random.default_rng(12)
+    shape, T = (4, 3, 3), 40
+    t = np.arange(1, T + 1)
+    data = (2.0 + 0.3 * t + rng.normal(0, 0.5, shape + (T,))).astype(np.float32)
+    nA = 2 + {"none": 0, "same": 1, "dual": 2}[cross]
+    n = nA + echoes
+    opts = {"model": "poly", "degree": 1, "noise": "ar", "method": "vb", "max-iterations": 5, "save-mean": True, "save-mvn": True,
+            "num-echoes": echoes, "ar1-cross-terms": cross}
+
+    def write(path, mean, cov):
+        m = np.zeros((n + 1, n + 1))
+        m[:n, :n], m[:n, n], m[n, :n], m[n, n] = cov, mean, mean, 1
+        path.write_text("\n".join(" ".join("%.17g" % x for x in row) for row in m) + "\n")
+
+    default = fabber.run(data, opts)
+    prior_f, post_f = tmp_path / "prior.mat", tmp_path / "post.mat"
+    # Gamma(b, c): mean bc, variance b^2 c; prior b = 1e6, c = 1e-6, posterior b = 1e-8, c = 1e-6
+    write(prior_f, [0] * nA + [1.0] * echoes, np.diag([1e4] * nA + [1e6] * echoes))
+    write(post_f, [0] * nA + [1e-14] * echoes, np.diag([1e4] * nA + [1e-22] * echoes))
+    same = fabber.run(data, dict(opts, **{"noise-initial-prior": str(prior_f), "noise-initial-posterior": str(post_f)}))
+    assert "Loading noise-initial-prior distribution" in same["log"]
+    assert np.allclose(same["finalMVN"], default["finalMVN"], rtol=2e-5, atol=1e-9)
+
+    a = rng.normal(size=(nA, nA))
+    cov_alpha = 0.02 * (a @ a.T) + 0.1 * np.eye(nA)
+    mean_alpha = rng.uniform(-0.3, 0.3, nA)
+    cov = np.zeros((n, n))
+    cov[:nA, :nA] = cov_alpha
+    cov[nA:, nA:] = np.diag([2.0] * echoes)                   # Gamma with mean 4, variance 2: b = 0.5, c = 8
+    write(prior_f, list(mean_alpha) + [4.0] * echoes, cov)
+    out = fabber.run(data, dict(opts, **{"noise-initial-prior": str(prior_f)}))
+    assert np.abs(out["finalMVN"] - default["finalMVN"]).max() > 1e-3
+    V = int(np.prod(shape))
+    y = data.transpose(3, 2, 1, 0).reshape(T, -1).astype(np.float64)
+    h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=5, noise=vbabi.NOISE_AR1, num_echoes=echoes,
+                           ar_cross_terms=cross, ar_alpha_prior=(mean_alpha, np.linalg.inv(cov_alpha)))
+    for e in range(echoes):
+        h.cfg.noise_prior_b[e], h.cfg.noise_prior_c[e] = 0.5, 8.0
+    ref = oracle.run(h, y)
+    rows = vbabi.mvn_rows(2 + n)
+    got = out["finalMVN"].transpose(3, 2, 1, 0).reshape(rows, -1)
+    assert np.all(ref["status"] == 0)
+    assert np.allclose(got, ref["mvn"], rtol=2e-5, atol=1e-7)
+
+    cov[0, nA] = cov[nA, 0] = 0.01                              # alpha block not independent of the precisions (dist_mvn.cc:157-165)
+    write(prior_f, list(mean_alpha) + [4.0] * echoes, cov)
+    with pytest.raises(fabber.FabberError, match="independent"):
+        fabber.run(data, dict(opts, **{"noise-initial-prior": str(prior_f)}))
+    if echoes == 2:
+        cov[0, nA] = cov[nA, 0] = 0
+        cov[nA, nA + 1] = cov[nA + 1, nA] = 0.5
+        write(prior_f, list(mean_alpha) + [4.0] * echoes, cov)
+        with pytest.raises(fabber.FabberError, match="zero covariance"):
+            fabber.run(data, dict(opts, **{"noise-initial-prior": str(prior_f)}))
+    short = tmp_path / "short.mat"
+    short.write_text("32 4\n4 1\n")                              # one entry: the white noise model's file
+    with pytest.raises(fabber.FabberError, match="entries"):
+        fabber.run(data, dict(opts, **{"noise-initial-prior": str(short)}))
+    # spatial VB does not take the alphas from a file (the engine's message reaches the caller)
+    write(prior_f, [0] * nA + [1.0] * echoes, np.diag([1e4] * nA + [1e6] * echoes))
+    with pytest.raises(fabber.FabberError):
+        fabber.run(data, dict(opts, method="spatialvb", **{"param-spatial-priors": "MN", "noise-initial-prior": str(prior_f)}))
