@@ -10,6 +10,7 @@ of the tree.
 import argparse
 import concurrent.futures
 import hashlib
+import re
 import os
 import shutil
 import subprocess
@@ -46,13 +47,45 @@ def _headers():
     return hs
 
 
+_INCLUDE = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
+
+
+def _closure(src, _seen=None):
+    """src and the project headers it includes, transitively (every project header is included with quotes, relative
+    to the including file, csrc/ or include/): a change to one kernel header rebuilds the sources that see it, not all
+    fifty (a full build is ~25 minutes on 8 cores)."""
+    seen = _seen if _seen is not None else {}
+    if src in seen:
+        return seen
+    seen[src] = True
+    with open(src, "r", errors="replace") as fh:
+        text = fh.read()
+    for inc in _INCLUDE.findall(text):
+        for d in (os.path.dirname(src), CSRC, os.path.join(os.path.dirname(HERE), "include")):
+            cand = os.path.normpath(os.path.join(d, inc))
+            if os.path.exists(cand):
+                _closure(cand, seen)
+                break
+    return seen
+
+
 def _stamp(src, flags):
     h = hashlib.sha256()
     h.update(" ".join(flags).encode())
-    for f in [src] + _headers():
+    for f in sorted(_closure(src)):
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def restamp():
+    """Write the stamps of the objects that exist as if they had just been built (after changing how stamps are formed)."""
+    flags = HIP_FLAGS + os.environ.get("FVB_EXTRA_HIPCC_FLAGS", "").split()
+    for s in HIP_SOURCES:
+        obj = os.path.join(OBJDIR, s + ".o")
+        if os.path.exists(obj):
+            with open(obj + ".stamp", "w") as fh:
+                fh.write(_stamp(os.path.join(CSRC, s), flags))
 
 
 def _compile_one(args):

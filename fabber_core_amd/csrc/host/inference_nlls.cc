@@ -25,6 +25,11 @@ struct NLLSInferenceTechnique::EngineStorage
     vector<unsigned char> phi_index;
     vector<Parameter> params;
     bool host_model = false;
+    // more than FVB_MAX_PARAMS parameters: the per-parameter entries as a table (fvb_config.params_ext)
+    vector<int32_t> wide_transform, wide_type;
+    vector<double> wide_zero, wide_post_mean;
+    vector<const double *> wide_images;
+    fvb_param_table wide;
 };
 
 static OptionSpec NLLS_OPTIONS[] = {
@@ -117,9 +122,10 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
     st.params.clear();
     m_model->GetParameters(rundata, st.params);
     const int P = (int)st.params.size();
-    if (P > FVB_MAX_PARAMS)
-        throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters are not supported by the MI355X engine");
+    if (P > FVB_MAX_PARAMS_EXT)
+        throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS_EXT) + " parameters are not supported by the MI355X engine");
     cfg.n_params = P;
+    const bool wide = P > FVB_MAX_PARAMS; // the per-parameter entries as a table (the wave-per-voxel minimiser reads it)
     DeviceModelSpec spec;
     // A model without a device body (any model library written for the reference), or any model when host-model is
     // set, is evaluated on the host - the minimiser's iterations stay on the GPU (fabber_nlls_run_hostmodel_host).
@@ -144,10 +150,29 @@ void NLLSInferenceTechnique::DoCalculations(FabberRunData &rundata)
         st.design = spec.design;
         cfg.design = st.design.Store();
     }
+    if (wide)
+    {
+        st.wide_transform.assign(P, 0);
+        st.wide_type.assign(P, 0);
+        st.wide_zero.assign(P, 0.0);
+        st.wide_post_mean.assign(P, 0.0);
+        st.wide_images.assign(P, (const double *)NULL);
+    }
     for (int k = 0; k < P; k++)
     {
-        cfg.transform[k] = st.params[k].transform->DeviceCode();
-        cfg.post_mean[k] = initialFwdPosterior->means(k + 1); // Fabber space, as it is (inference_nlls.cc:131)
+        (wide ? st.wide_transform[k] : cfg.transform[k]) = st.params[k].transform->DeviceCode();
+        (wide ? st.wide_post_mean[k] : cfg.post_mean[k]) = initialFwdPosterior->means(k + 1); // Fabber space, as it is (inference_nlls.cc:131)
+    }
+    if (wide)
+    {
+        st.wide.transform = st.wide_transform.data();
+        st.wide.prior_type = st.wide_type.data();
+        st.wide.prior_mean = st.wide.prior_var = st.wide.prior_prec = st.wide.post_var = st.wide_zero.data(); // (unused by the minimiser)
+        st.wide.post_mean = st.wide_post_mean.data();
+        st.wide.image_prior = st.wide_images.data();
+        cfg.params_ext = &st.wide;
+        if (!device_model)
+            throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS) + " parameters that are evaluated on the host are not supported under method=nlls by the MI355X engine");
     }
     st.phi_index.clear();
     if (!m_masked_tpoints.empty()) // MaskRows (inference_nlls.cc:110,152,216-234)

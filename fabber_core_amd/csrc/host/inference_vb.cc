@@ -257,8 +257,8 @@ void Vb::BuildEngineConfig(FabberRunData &rundata, fvb_config &cfg)
     if (P > FVB_MAX_PARAMS_EXT)
         throw FabberInternalError("Models with more than " + stringify(FVB_MAX_PARAMS_EXT) + " parameters are not supported by the MI355X engine");
     cfg.n_params = P;
-    // beyond FVB_MAX_PARAMS the per-parameter entries travel as a table (the wave-per-voxel kernel takes such problems:
-    // voxelwise VB, white noise, a built-in model - the engine says so where that is not the case)
+    // beyond FVB_MAX_PARAMS the per-parameter entries travel as a table (the wave-per-voxel kernels take such problems:
+    // voxelwise VB, white or AR(1) noise, a built-in model - the engine says so where that is not the case)
     const bool wide = P > FVB_MAX_PARAMS;
     if (wide)
     {

@@ -65,8 +65,8 @@ int validate(const fvb_config *cfg, bool allow_spatial = false, bool allow_no_no
     if (cfg->n_params <= 0 || cfg->n_params > (cfg->params_ext ? FVB_MAX_PARAMS_EXT : FVB_MAX_PARAMS))
         return fail(-4, cfg->params_ext ? "n_params out of range" : "n_params out of range (more than FVB_MAX_PARAMS parameters: fvb_config.params_ext)");
     // (allow_no_noise: the post-processing of a result image, which such problems have like any other)
-    if (cfg->params_ext && (cfg->noise != FVB_NOISE_WHITE || (allow_spatial && !allow_no_noise)))
-        return fail(-4, "a parameter table (more than FVB_MAX_PARAMS parameters) runs voxelwise VB under white noise only");
+    if (cfg->params_ext && allow_spatial && !allow_no_noise)
+        return fail(-4, "a parameter table (more than FVB_MAX_PARAMS parameters) runs voxelwise VB and method=nlls only");
     // (a result image without noise entries - method=nlls - can only be post-processed)
     if ((cfg->n_phis <= 0 && !(allow_no_noise && cfg->n_phis == 0)) || cfg->n_phis > FVB_MAX_PHIS)
         return fail(-5, "n_phis out of range");
@@ -121,10 +121,6 @@ constexpr int WAVE_KERNEL_BELOW_VOXELS = 4096;
 LaneKernelInfo select_lane(const fvb_config *cfg)
 {
     if (g_variant == 2 || (cfg->n_phis != 1 && cfg->noise == FVB_NOISE_WHITE && cfg->n_phis > 4))
-        return LaneKernelInfo{ nullptr, 0, nullptr };
-    // alpha distributions from noise-initial-prior / -posterior: the lane kernels carry the hard-coded prior's diagonal
-    // form (vb_lane_ar_kernel.h); the wave-per-voxel kernel takes any
-    if (cfg->noise == FVB_NOISE_AR1 && cfg->ar_alpha_given)
         return LaneKernelInfo{ nullptr, 0, nullptr };
     if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 2) // two echoes: the two-pass kernel of vb_lane_arn_kernel.h
     {

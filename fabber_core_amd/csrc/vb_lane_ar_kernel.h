@@ -47,6 +47,25 @@ struct ArAlpha
     double a1, a2;
 };
 
+// Ar1cNoiseModel::HardcodedInitialDists (noisemodel_ar.cc:379-403), or the posterior of noise-initial-posterior
+__device__ __forceinline__ void ar_initial_alpha(const KernelArgs &ka, ArAlpha &al)
+{
+    if (ka.cfg.ar_alpha_given & 2)
+    {
+        al.mean[0] = ka.cfg.ar_alpha_post_mean[0];
+        al.mean[1] = ka.cfg.ar_alpha_post_mean[1];
+        al.c11 = ka.cfg.ar_alpha_post_cov[0][0];
+        al.c12 = ka.cfg.ar_alpha_post_cov[0][1];
+        al.c22 = ka.cfg.ar_alpha_post_cov[1][1];
+    }
+    else
+    {
+        al.mean[0] = al.mean[1] = 0;
+        al.c11 = al.c22 = 1.0 / AR_ALPHA_PRIOR_PREC;
+        al.c12 = 0;
+    }
+}
+
 template <int P>
 constexpr int lane_ar_save_rows()
 {
@@ -394,18 +413,45 @@ template <int P>
 __device__ __forceinline__ int update_noise_ar(const KernelArgs &ka, VoxelState<P> &st, ArAlpha &al, const ArForms &f)
 {
     const double phibar = st.b * st.c;
-    const double prec11 = AR_ALPHA_PRIOR_PREC + phibar * (f.kk[2] + f.tr[2]); // OpKLJ(M20)
-    if (!is_finite(prec11))
-        return FVB_BAD_AR_ALPHA;
-    const double var11 = 1.0 / prec11, var22 = 1.0 / AR_ALPHA_PRIOR_PREC;
-    if (var11 < 0)
-        return FVB_BAD_AR_ALPHA;
-    const double tmp1 = -0.5 * phibar * (f.kk[1] + f.tr[1]); // prior means are zero
-    al.c11 = var11;
-    al.c12 = 0;
-    al.c22 = var22;
-    al.mean[0] = var11 * tmp1;
-    al.mean[1] = 0;
+    double var11;
+    if (ka.cfg.ar_alpha_given & 1) // (uniform) noise-initial-prior: a full 2 x 2 prior (InputFromMVN, :302-316)
+    {
+        const double p11 = ka.cfg.ar_alpha_prior_prec[0][0], p12 = ka.cfg.ar_alpha_prior_prec[0][1], p22 = ka.cfg.ar_alpha_prior_prec[1][1];
+        const double m01 = ka.cfg.ar_alpha_prior_mean[0], m02 = ka.cfg.ar_alpha_prior_mean[1];
+        const double a = p11 + phibar * (f.kk[2] + f.tr[2]); // OpKLJ(M20)
+        if (!is_finite(a))
+            return FVB_BAD_AR_ALPHA;
+        const double det = a * p22 - p12 * p12;
+        if (det == 0 || !is_finite(det))
+            return FVB_BAD_RESULT;
+        const double rdet = 1.0 / det;
+        var11 = p22 * rdet;
+        al.c11 = var11;
+        al.c12 = -p12 * rdet;
+        al.c22 = a * rdet;
+        if (al.c11 < 0 || al.c22 < 0)
+            return FVB_BAD_AR_ALPHA;
+        const double t1 = (p11 * m01 + p12 * m02) + -0.5 * phibar * (f.kk[1] + f.tr[1]); // :501-505
+        const double t2 = p12 * m01 + p22 * m02;
+        al.mean[0] = al.c11 * t1 + al.c12 * t2;
+        al.mean[1] = al.c12 * t1 + al.c22 * t2;
+    }
+    else
+    {
+        const double prec11 = AR_ALPHA_PRIOR_PREC + phibar * (f.kk[2] + f.tr[2]); // OpKLJ(M20)
+        if (!is_finite(prec11))
+            return FVB_BAD_AR_ALPHA;
+        var11 = 1.0 / prec11;
+        const double var22 = 1.0 / AR_ALPHA_PRIOR_PREC;
+        if (var11 < 0)
+            return FVB_BAD_AR_ALPHA;
+        const double tmp1 = -0.5 * phibar * (f.kk[1] + f.tr[1]); // prior means are zero
+        al.c11 = var11;
+        al.c12 = 0;
+        al.c22 = var22;
+        al.mean[0] = var11 * tmp1;
+        al.mean[1] = 0;
+    }
     al.a1 = al.mean[0];
     al.a2 = var11 + al.mean[0] * al.mean[0];
     // UpdatePhi with the new marginal
@@ -448,9 +494,20 @@ __device__ __forceinline__ bool calc_free_energy_ar(const KernelArgs &ka, VoxelS
     parts += 0.5 * logdetPrior;                                                      // [3]
     parts += -0.5 * quad;                                                            // [4]
     parts += -0.5 * trSL0;                                                           // [5]
-    parts += 0.5 * 2 * log(AR_ALPHA_PRIOR_PREC);                                     // [6]
-    parts += -0.5 * AR_ALPHA_PRIOR_PREC * (al.mean[0] * al.mean[0] + al.mean[1] * al.mean[1]); // [7]
-    parts += -0.5 * AR_ALPHA_PRIOR_PREC * (al.c11 + al.c22);                         // [8]
+    if (ka.cfg.ar_alpha_given & 1) // (uniform) the prior of noise-initial-prior (:720-729)
+    {
+        const double p11 = ka.cfg.ar_alpha_prior_prec[0][0], p12 = ka.cfg.ar_alpha_prior_prec[0][1], p22 = ka.cfg.ar_alpha_prior_prec[1][1];
+        const double d1 = al.mean[0] - ka.cfg.ar_alpha_prior_mean[0], d2 = al.mean[1] - ka.cfg.ar_alpha_prior_mean[1];
+        parts += 0.5 * log(fabs(p11 * p22 - p12 * p12));                                   // [6]
+        parts += -0.5 * (d1 * p11 * d1 + 2 * d1 * p12 * d2 + d2 * p22 * d2);               // [7]
+        parts += -0.5 * (al.c11 * p11 + 2 * al.c12 * p12 + al.c22 * p22);                  // [8]
+    }
+    else
+    {
+        parts += 0.5 * 2 * log(AR_ALPHA_PRIOR_PREC);                                     // [6]
+        parts += -0.5 * AR_ALPHA_PRIOR_PREC * (al.mean[0] * al.mean[0] + al.mean[1] * al.mean[1]); // [7]
+        parts += -0.5 * AR_ALPHA_PRIOR_PREC * (al.c11 + al.c22);                         // [8]
+    }
     F = -expectedLogAlphaDist - expectedLogThetaDist - expectedLogPhiDist + parts;
     finite = is_finite(F);
     F += Fprior;
@@ -562,9 +619,7 @@ __global__ __launch_bounds__(64, lane_waves<P>()) void vb_lane_ar_kernel(const K
             st.Sig[tri(i, i)] = to_fabber_var(tr, st.Sig[tri(i, i)]);
         }
         // Ar1cNoiseModel::HardcodedInitialDists (noisemodel_ar.cc:379-403)
-        al.mean[0] = al.mean[1] = 0;
-        al.c11 = al.c22 = 1.0 / AR_ALPHA_PRIOR_PREC;
-        al.c12 = 0;
+        ar_initial_alpha(ka, al);
         st.b = ka.cfg.noise_post_b[0];
         st.c = ka.cfg.noise_post_c[0];
     }

@@ -313,6 +313,38 @@ __device__ __forceinline__ bool update_theta_arn(VoxelState<P> &st, const ArnMom
     return true;
 }
 
+// Ar1cNoiseModel::HardcodedInitialDists (noisemodel_ar.cc:379-403), or the posterior of noise-initial-posterior
+template <int NA>
+__device__ __forceinline__ void arn_initial_alpha(const KernelArgs &ka, ArnAlpha<NA> &al)
+{
+    if (ka.cfg.ar_alpha_given & 2)
+    {
+        constexpr int NT = NA * (NA + 1) / 2;
+        double inv[NT], la;
+        int sg;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+        {
+            al.mean[i] = ka.cfg.ar_alpha_post_mean[i];
+#pragma unroll
+            for (int j = 0; j <= i; j++)
+                al.cov[tri(i, j)] = ka.cfg.ar_alpha_post_cov[i][j];
+        }
+        ldl_inverse<NA>(al.cov, inv, la, sg);
+        al.logdetPrec = -la;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; i++)
+    {
+        al.mean[i] = 0;
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            al.cov[tri(i, j)] = (i == j) ? 1.0 / AR_ALPHA_PRIOR_PREC : 0.0;
+    }
+    al.logdetPrec = NA * log(AR_ALPHA_PRIOR_PREC);
+}
+
 // Ar1cNoiseModel::UpdateAlpha + UpdatePhi (noisemodel_ar.cc:447-556) from the line scalars
 template <int NA>
 __device__ __forceinline__ int update_noise_arn(const KernelArgs &ka, ArnAlpha<NA> &al, double (&pb)[2], double (&pc)[2],
@@ -322,11 +354,12 @@ __device__ __forceinline__ int update_noise_arn(const KernelArgs &ka, ArnAlpha<N
     const double nT = (double)(ka.cfg.n_times / 2);
     const double sc[2] = { pb[0] * pc[0], pb[1] * pc[1] };
     double prec[NT];
+    const bool prior_given = (ka.cfg.ar_alpha_given & 1) != 0; // (uniform) noise-initial-prior (InputFromMVN, :302-316)
 #pragma unroll
     for (int i = 0; i < NA; i++)
 #pragma unroll
         for (int j = 0; j <= i; j++)
-            prec[tri(i, j)] = (i == j) ? AR_ALPHA_PRIOR_PREC : 0.0;
+            prec[tri(i, j)] = prior_given ? ka.cfg.ar_alpha_prior_prec[i][j] : ((i == j) ? AR_ALPHA_PRIOR_PREC : 0.0);
     prec[tri(0, 0)] += sc[0] * S[0][ARN_20];
     prec[tri(1, 1)] += sc[1] * S[1][ARN_20];
     if (NA >= 3)
@@ -354,7 +387,13 @@ __device__ __forceinline__ int update_noise_arn(const KernelArgs &ka, ArnAlpha<N
     double tmp[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++)
-        tmp[i] = 0; // (the prior means are zero)
+    {
+        tmp[i] = 0; // (the hard-coded prior's means are zero); else prior precisions x prior means (:501-502)
+        if (prior_given)
+#pragma unroll
+            for (int j = 0; j < NA; j++)
+                tmp[i] += ka.cfg.ar_alpha_prior_prec[i][j] * ka.cfg.ar_alpha_prior_mean[j];
+    }
     tmp[0] += -0.5 * sc[0] * S[0][ARN_10];
     tmp[1] += -0.5 * sc[1] * S[1][ARN_10];
     if (NA >= 3)
@@ -428,16 +467,44 @@ __device__ __forceinline__ bool calc_free_energy_arn(const KernelArgs &ka, Voxel
     parts += 0.5 * logdetPrior; // [3]
     parts += -0.5 * quad;       // [4]
     parts += -0.5 * trSL0;      // [5]
-    double mm = 0, trc = 0;
-#pragma unroll
-    for (int i = 0; i < NA; i++)
+    if (ka.cfg.ar_alpha_given & 1) // (uniform) the prior of noise-initial-prior: its log-determinant, quadratic form, trace (:720-729)
     {
-        mm += al.mean[i] * al.mean[i];
-        trc += al.cov[tri(i, i)];
+        constexpr int NT = NA * (NA + 1) / 2;
+        double p0[NT], p0i[NT], lp;
+        int sp;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++)
+                p0[tri(i, j)] = ka.cfg.ar_alpha_prior_prec[i][j];
+        ldl_inverse<NA>(p0, p0i, lp, sp);
+        double qa = 0, tra = 0;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+#pragma unroll
+            for (int j = 0; j < NA; j++)
+            {
+                const double pij = p0[tri(i > j ? i : j, i > j ? j : i)];
+                qa += (al.mean[i] - ka.cfg.ar_alpha_prior_mean[i]) * pij * (al.mean[j] - ka.cfg.ar_alpha_prior_mean[j]);
+                tra += al.cov[tri(i > j ? i : j, i > j ? j : i)] * pij;
+            }
+        parts += 0.5 * lp;   // [6]
+        parts += -0.5 * qa;  // [7]
+        parts += -0.5 * tra; // [8]
     }
-    parts += 0.5 * NA * log(AR_ALPHA_PRIOR_PREC); // [6]
-    parts += -0.5 * AR_ALPHA_PRIOR_PREC * mm;     // [7]
-    parts += -0.5 * AR_ALPHA_PRIOR_PREC * trc;    // [8]
+    else
+    {
+        double mm = 0, trc = 0;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+        {
+            mm += al.mean[i] * al.mean[i];
+            trc += al.cov[tri(i, i)];
+        }
+        parts += 0.5 * NA * log(AR_ALPHA_PRIOR_PREC); // [6]
+        parts += -0.5 * AR_ALPHA_PRIOR_PREC * mm;     // [7]
+        parts += -0.5 * AR_ALPHA_PRIOR_PREC * trc;    // [8]
+    }
     F = -expectedLogAlphaDist - expectedLogThetaDist - expectedLogPhiDist + parts;
     finite = is_finite(F);
     F += Fprior;
@@ -587,16 +654,7 @@ __global__ __launch_bounds__(64, (NA == 2 && !NEEDF) ? 2 : 1) void vb_lane_arn_k
             st.m[i] = to_fabber(tr, st.m[i]);
             st.Sig[tri(i, i)] = to_fabber_var(tr, st.Sig[tri(i, i)]);
         }
-        // Ar1cNoiseModel::HardcodedInitialDists (noisemodel_ar.cc:379-403)
-#pragma unroll
-        for (int i = 0; i < NA; i++)
-        {
-            al.mean[i] = 0;
-#pragma unroll
-            for (int j = 0; j <= i; j++)
-                al.cov[tri(i, j)] = (i == j) ? 1.0 / AR_ALPHA_PRIOR_PREC : 0.0;
-        }
-        al.logdetPrec = NA * log(AR_ALPHA_PRIOR_PREC);
+        arn_initial_alpha<NA>(ka, al);
 #pragma unroll
         for (int e = 0; e < 2; e++)
         {

@@ -94,8 +94,8 @@ int validate_nlls(const fvb_config *cfg, const fvb_nlls *nl)
         return api_fail(-2, "fvb_config.abi_version mismatch");
     if (cfg->n_voxels < 0 || cfg->n_times <= 0)
         return api_fail(-3, "bad n_voxels / n_times");
-    if (cfg->n_params <= 0 || cfg->n_params > FVB_MAX_PARAMS)
-        return api_fail(-4, "n_params out of range");
+    if (cfg->n_params <= 0 || cfg->n_params > (cfg->params_ext ? FVB_MAX_PARAMS_EXT : FVB_MAX_PARAMS))
+        return api_fail(-4, "n_params out of range (more than FVB_MAX_PARAMS parameters: fvb_config.params_ext)");
     if (cfg->model == FVB_MODEL_LINEAR && !cfg->design)
         return api_fail(-10, "linear model needs a design matrix");
     if (cfg->model == FVB_MODEL_EXP && (cfg->n_params != 2 * cfg->model_iopt[0]))
@@ -203,6 +203,35 @@ int32_t fabber_nlls_run_host(const fvb_config *cfg, const fvb_nlls *nl, const vo
         FVB_HIP_CHECK(b_phi.alloc(T));
         FVB_HIP_CHECK(hipMemcpy(b_phi.p, cfg->phi_index, T, hipMemcpyHostToDevice));
         d.phi_index = (const uint8_t *)b_phi.p;
+    }
+    DevMem b_table;
+    if (cfg->params_ext) // more than FVB_MAX_PARAMS parameters: the table on the device (the minimiser reads the transforms
+    {                    // and the starting estimate; the prior entries are carried for the post-processing kernel)
+        const fvb_param_table *h = cfg->params_ext;
+        const size_t off_i = sizeof(fvb_param_table), off_d = off_i + 2 * (size_t)P * sizeof(int32_t) + (2 * (size_t)P * sizeof(int32_t)) % 8;
+        const size_t off_p = off_d + 5 * (size_t)P * sizeof(double), bytes = off_p + (size_t)P * sizeof(double *);
+        std::vector<char> host(bytes, 0);
+        FVB_HIP_CHECK(b_table.alloc(bytes));
+        char *dev = (char *)b_table.p;
+        fvb_param_table t;
+        t.transform = (const int32_t *)(dev + off_i);
+        t.prior_type = t.transform + P;
+        t.prior_mean = (const double *)(dev + off_d);
+        t.prior_var = t.prior_mean + P;
+        t.prior_prec = t.prior_var + P;
+        t.post_mean = t.prior_prec + P;
+        t.post_var = t.post_mean + P;
+        t.image_prior = (const double *const *)(dev + off_p); // (all NULL: the minimiser has no priors)
+        memcpy(host.data(), &t, sizeof(t));
+        memcpy(host.data() + off_i, h->transform, (size_t)P * sizeof(int32_t));
+        if (h->prior_type)
+            memcpy(host.data() + off_i + (size_t)P * sizeof(int32_t), h->prior_type, (size_t)P * sizeof(int32_t));
+        const double *src[5] = { h->prior_mean, h->prior_var, h->prior_prec, h->post_mean, h->post_var };
+        for (int a = 0; a < 5; a++)
+            if (src[a])
+                memcpy(host.data() + off_d + (size_t)a * P * sizeof(double), src[a], (size_t)P * sizeof(double));
+        FVB_HIP_CHECK(hipMemcpy(b_table.p, host.data(), bytes, hipMemcpyHostToDevice));
+        d.params_ext = (const fvb_param_table *)b_table.p;
     }
     fvb_outputs dout;
     memset(&dout, 0, sizeof(dout));

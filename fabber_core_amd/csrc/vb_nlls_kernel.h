@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64) void nlls_wave_kernel(const NllsArgs na, const 
 
     nlls_wave_stage(ka, cx);
     FVB_WAVE_FOR(i, L.P)
-    sh[L.m + i] = ka.cfg.post_mean[i]; // starting estimate, Fabber space
+    sh[L.m + i] = FVB_KPARAM(ka, post_mean, i); // starting estimate, Fabber space
     wave_sync();
 
     NllsWaveState s;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64) void nlls_wave_step_kernel(const NllsHmArgs ha)
         sh[L.b + e] = 0;
         wave_sync();
         FVB_WAVE_FOR(i, L.P)
-        sh[L.m + i] = ka.cfg.post_mean[i];
+        sh[L.m + i] = FVB_KPARAM(ka, post_mean, i);
     }
     else
     {

@@ -419,8 +419,6 @@ int build_neighbours_device(const int32_t *h_coords, int V, int dims, int32_t *d
 // Which statistics a configuration's state image carries (vb_spatial_noise.h), or -1: no spatial kernels for it
 static int spatial_noise_kind(const fvb_config *cfg)
 {
-    if (cfg->noise == FVB_NOISE_AR1 && cfg->ar_alpha_given) // alpha distributions from file: the voxelwise engine only
-        return -1;
     if (cfg->noise == FVB_NOISE_WHITE)
         return cfg->n_phis == 1 ? FVB_SPNZ_WHITE : (cfg->n_phis == 2 ? FVB_SPNZ_PATTERN2 : (cfg->n_phis <= 4 ? FVB_SPNZ_PATTERN4 : (cfg->n_phis <= 8 ? FVB_SPNZ_PATTERN8 : -1)));
     if (cfg->noise == FVB_NOISE_AR1 && cfg->n_phis == 1 && cfg->ar_cross_terms == 0)
@@ -430,8 +428,7 @@ static int spatial_noise_kind(const fvb_config *cfg)
     return -1;
 }
 static const char *const spatial_noise_refusal
-    = "spatial VB runs white noise with up to 8 noise precisions and AR(1) noise with one or two echoes (the AR(1) "
-      "coefficients' hard-coded initial distributions)";
+    = "spatial VB runs white noise with up to 8 noise precisions and AR(1) noise with one or two echoes";
 // the kernel table of a configuration (setup == NULL: none was built for this model / parameter count / noise model)
 static SpatialKernels spatial_kernels_for(const fvb_config *cfg)
 {

@@ -355,9 +355,7 @@ struct SpAr1
         }
         else
         {
-            f.al.mean[0] = f.al.mean[1] = 0;
-            f.al.c11 = f.al.c22 = 1.0 / AR_ALPHA_PRIOR_PREC;
-            f.al.c12 = 0;
+            ar_initial_alpha(ka, f.al);
             st.b = ka.cfg.noise_post_b[0];
             st.c = ka.cfg.noise_post_c[0];
         }
@@ -579,15 +577,7 @@ struct SpArN
         }
         else
         {
-#pragma unroll
-            for (int i = 0; i < NA; i++)
-            {
-                f.al.mean[i] = 0;
-#pragma unroll
-                for (int j = 0; j <= i; j++)
-                    f.al.cov[tri(i, j)] = (i == j) ? 1.0 / AR_ALPHA_PRIOR_PREC : 0.0;
-            }
-            f.al.logdetPrec = NA * log(AR_ALPHA_PRIOR_PREC);
+            arn_initial_alpha<NA>(ka, f.al);
 #pragma unroll
             for (int e = 0; e < 2; e++)
                 f.pb[e] = ka.cfg.noise_post_b[e];

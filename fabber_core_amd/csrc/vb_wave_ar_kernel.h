@@ -790,12 +790,12 @@ __global__ __launch_bounds__(64) void vb_wave_ar_kernel(const KernelArgs ka, con
         }
         FVB_WAVE_FOR(i, P)
         {
-            double mean = (ka.cfg.prior_type[i] == FVB_PRIOR_IMAGE) ? ka.cfg.image_prior[i][v] : ka.cfg.post_mean[i];
+            double mean = (FVB_KPARAM(ka, prior_type, i) == FVB_PRIOR_IMAGE) ? FVB_KPARAM(ka, image_prior, i)[v] : FVB_KPARAM(ka, post_mean, i);
             if (ka.cfg.model == FVB_MODEL_EXP && (i % 2) == 0)
                 mean = data_max / (P / 2 + i / 2);
-            const int tr = ka.cfg.transform[i];
+            const int tr = FVB_KPARAM(ka, transform, i);
             sh[L.m + i] = to_fabber(tr, mean);
-            sh[L.Sig + i * P + i] = to_fabber_var(tr, ka.cfg.post_var[i]);
+            sh[L.Sig + i * P + i] = to_fabber_var(tr, FVB_KPARAM(ka, post_var, i));
         }
         FVB_WAVE_FOR(i, NPHI)
         {

@@ -168,8 +168,7 @@ def nlls_run_host(holder, data, lm=False, start=None, settings=None, device=0):
     cfg = holder.cfg
     data = _prepare_data(holder, data)
     V, P = cfg.n_voxels, cfg.n_params
-    for p in range(P):
-        cfg.post_mean[p] = 0.0 if start is None else float(start[p])
+    holder.set_post_mean([0.0] * P if start is None else start)
     nl = settings or vbabi.FvbNlls.defaults(lm)
     arrs = dict(mvn=np.full((vbabi.mvn_rows(P), V), np.nan), status=np.full(V, -1, dtype=np.int32),
                 iterations=np.full(V, -1, dtype=np.int32), free_energy=np.full(V, np.nan))
@@ -214,8 +213,7 @@ def nlls_run_hostmodel_host(holder, data, model, lm=False, start=None, settings=
     cfg = holder.cfg
     data = _prepare_data(holder, data)
     V, P, T = cfg.n_voxels, cfg.n_params, cfg.n_times
-    for p in range(P):
-        cfg.post_mean[p] = 0.0 if start is None else float(start[p])
+    holder.set_post_mean([0.0] * P if start is None else start)
     nl = settings or vbabi.FvbNlls.defaults(lm)
     arrs = dict(mvn=np.full((vbabi.mvn_rows(P), V), np.nan), status=np.full(V, -1, dtype=np.int32),
                 iterations=np.full(V, -1, dtype=np.int32), free_energy=np.full(V, np.nan))

@@ -187,6 +187,13 @@ class ConfigHolder:
         self.params = params
         self.keep = keep
 
+    def set_post_mean(self, values):
+        """The initial posterior means (method=nlls: the Fabber-space starting estimate), wherever the per-parameter
+        entries live - the fixed arrays or the table of cfg.params_ext."""
+        dst = self.keep["param_table"][0]["post_mean"] if self.cfg.params_ext else self.cfg.post_mean
+        for k in range(self.cfg.n_params):
+            dst[k] = float(values[k])
+
     @property
     def n_mvn_rows(self):
         return mvn_rows(self.cfg.n_params + self.n_noise_outputs)

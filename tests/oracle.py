@@ -25,8 +25,7 @@ def lib():
     if _LIB is None:
         path = os.path.join(_ROOT, "oracle", "liboracle.so")
         src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle.so"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle.so"])  # (make knows the dependencies: the source, the .inc files, include/fabber_vb.h)
         L = C.CDLL(path)
         L.oracle_vb_run.restype = C.c_int32
         L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
@@ -59,8 +58,7 @@ def lib_fma():
     if _LIB_FMA is None:
         path = os.path.join(_ROOT, "oracle", "liboracle_fma.so")
         src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_fma.so"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_fma.so"])  # (make knows the dependencies: the source, the .inc files, include/fabber_vb.h)
         L = C.CDLL(path)
         L.oracle_vb_run.restype = C.c_int32
         L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
@@ -78,8 +76,7 @@ def lib_exp1ulp():
     if _LIB_EXP1ULP is None:
         path = os.path.join(_ROOT, "oracle", "liboracle_exp1ulp.so")
         src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_exp1ulp.so"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_exp1ulp.so"])  # (make knows the dependencies: the source, the .inc files, include/fabber_vb.h)
         L = C.CDLL(path)
         L.oracle_vb_run.restype = C.c_int32
         L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
@@ -95,8 +92,7 @@ def lib_quad():
     if _LIB_QUAD is None:
         path = os.path.join(_ROOT, "oracle", "liboracle_quad.so")
         src = os.path.join(_ROOT, "oracle", "vb_oracle.cc")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_quad.so"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "liboracle_quad.so"])  # (make knows the dependencies: the source, the .inc files, include/fabber_vb.h)
         L = C.CDLL(path)
         L.oracle_vb_run.restype = C.c_int32
         L.oracle_vb_run.argtypes = [C.POINTER(vbabi.FvbConfig), C.c_void_p, C.POINTER(vbabi.FvbOutputs),
@@ -179,8 +175,7 @@ def run_nlls(holder, data, lm=False, start=None, settings=None, halt_bad_voxel=F
     cfg = holder.cfg
     data = prepare_data(holder, data)
     V, P = cfg.n_voxels, cfg.n_params
-    for p in range(P):
-        cfg.post_mean[p] = 0.0 if start is None else float(start[p])
+    holder.set_post_mean([0.0] * P if start is None else start)
     nl = settings or vbabi.FvbNlls.defaults(lm)
     arrs = dict(mvn=np.full((vbabi.mvn_rows(P), V), np.nan), status=np.full(V, -1, dtype=np.int32),
                 iterations=np.full(V, -1, dtype=np.int32), free_energy=np.full(V, np.nan))

@@ -248,7 +248,8 @@ def assert_close_to_oracle(h, y, ref=None, rtol=1e-6):
 @pytest.mark.gpu
 @pytest.mark.parametrize("echoes,cross", [(1, "none"), (2, "none"), (2, "same"), (2, "dual")])
 def test_alpha_distributions_from_file_on_the_gpu(echoes, cross):
-    """noise-initial-prior / -posterior under AR(1) noise: at any size the run takes the wave-per-voxel kernel"""
+    """noise-initial-prior / -posterior under AR(1) noise: the lane kernels from 4096 voxels (a full 2 x 2 prior in
+    lane_ar1, the general precision matrix in lane_ar2), the wave-per-voxel kernel below"""
     n_alphas = 2 + {"none": 0, "same": 1, "dual": 2}[cross]
     prior, post = alpha_distributions(n_alphas, seed=20 + n_alphas)
     for V, only in ((300, "both"), (5000, "prior"), (64, "post")):
@@ -262,7 +263,15 @@ def test_alpha_distributions_from_file_on_the_gpu(echoes, cross):
         else:
             h, y = cases.linear_problem(V, 50, seed=4, noise=AR, **opts)
         assert_close_to_oracle(h, y.astype(np.float32))
-        assert "wave" in hiplib.kernel_name(h), hiplib.kernel_name(h)
+        # (one echo: lane_ar1 at every size; two echoes: lane_ar2 from 4096 voxels, the wave-per-voxel kernel below)
+        assert ("lane_ar" if V >= 4096 or echoes == 1 else "wave") in hiplib.kernel_name(h), hiplib.kernel_name(h)
+        if echoes == 1 and V == 300:
+            hiplib.set_variant("wave")
+            try:
+                assert "wave" in hiplib.kernel_name(h)
+                assert_close_to_oracle(h, y.astype(np.float32))
+            finally:
+                hiplib.set_variant("auto")
 
 
 @pytest.mark.gpu

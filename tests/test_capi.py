@@ -459,8 +459,10 @@ def test_ar_noise_distributions_from_matrix_files(tmp_path, echoes, cross):
     assert np.abs(out["finalMVN"] - default["finalMVN"]).max() > 1e-3
     V = int(np.prod(shape))
     y = data.transpose(3, 2, 1, 0).reshape(T, -1).astype(np.float64)
+    prec_alpha = np.linalg.inv(cov_alpha)
+    prec_alpha = 0.5 * (prec_alpha + prec_alpha.T)
     h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=5, noise=vbabi.NOISE_AR1, num_echoes=echoes,
-                           ar_cross_terms=cross, ar_alpha_prior=(mean_alpha, np.linalg.inv(cov_alpha)))
+                           ar_cross_terms=cross, ar_alpha_prior=(mean_alpha, prec_alpha))
     for e in range(echoes):
         h.cfg.noise_prior_b[e], h.cfg.noise_prior_c[e] = 0.5, 8.0
     ref = oracle.run(h, y)
@@ -483,7 +485,9 @@ def test_ar_noise_distributions_from_matrix_files(tmp_path, echoes, cross):
     short.write_text("32 4\n4 1\n")                              # one entry: the white noise model's file
     with pytest.raises(fabber.FabberError, match="entries"):
         fabber.run(data, dict(opts, **{"noise-initial-prior": str(short)}))
-    # spatial VB does not take the alphas from a file (the engine's message reaches the caller)
+    # under spatial VB too: the hard-coded distributions from files give the default spatial run
     write(prior_f, [0] * nA + [1.0] * echoes, np.diag([1e4] * nA + [1e6] * echoes))
-    with pytest.raises(fabber.FabberError):
-        fabber.run(data, dict(opts, method="spatialvb", **{"param-spatial-priors": "MN", "noise-initial-prior": str(prior_f)}))
+    sp_opts = dict(opts, method="spatialvb", **{"param-spatial-priors": "MN"})
+    sp_default = fabber.run(data, sp_opts)
+    sp_file = fabber.run(data, dict(sp_opts, **{"noise-initial-prior": str(prior_f), "noise-initial-posterior": str(post_f)}))
+    assert np.allclose(sp_file["finalMVN"], sp_default["finalMVN"], rtol=2e-5, atol=1e-9)

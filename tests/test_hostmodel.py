@@ -353,6 +353,50 @@ def test_forty_parameter_linear_model():
             assert np.allclose(out["mean_Parameter_%d" % (k + 1)], want[..., k], rtol=1e-4, atol=1e-4), k
             assert np.all(out["std_Parameter_%d" % (k + 1)] > 0)
         assert np.sqrt(np.mean((out["modelfit"] - data) ** 2)) < 0.4
-        # what has no wide form says so: method=nlls, AR(1) noise
+        # method=nlls with the same 40 columns: the least-squares solution again (the wave-per-voxel minimiser reads the table)
+        out = fabber.run(data, {"model": "linear", "basis": os.path.join(tmp, "design.mat"), "noise": "white", "method": "nlls",
+                                "save-mean": True, "save-std": True, "max-iterations": 10})
+        for k in range(P):
+            assert np.allclose(out["mean_Parameter_%d" % (k + 1)], want[..., k], rtol=1e-4, atol=1e-4), k
+        # what has no wide form says so: spatial VB
         with pytest.raises(Exception, match="parameters"):
-            fabber.run(data, {"model": "linear", "basis": os.path.join(tmp, "design.mat"), "noise": "white", "method": "nlls", "max-iterations": 3})
+            fabber.run(data, {"model": "linear", "basis": os.path.join(tmp, "design.mat"), "noise": "white", "method": "spatialvb",
+                              "param-spatial-priors": "M+", "max-iterations": 3})
+
+
+@pytest.mark.gpu
+def test_more_than_32_parameters_under_ar_noise_and_nlls():
+    """The parameter table (fvb_config.params_ext) is read by the wave-per-voxel AR(1) kernel and by the wave-per-voxel
+    minimiser of method=nlls as well: 36 cosine regressors over 60 timepoints (what the AR kernel's three [T][P] work
+    areas leave room for in 160 KB of LDS), one and two echoes; 40 regressors over 100 timepoints for NLLS."""
+    import oracle
+    import parity
+    rng = np.random.default_rng(15)
+    T, P, V = 60, 36, 200
+    tt = np.arange(T)
+    X = np.stack([np.cos(np.pi * (tt + 0.5) * k / T) for k in range(P)], axis=1)
+    theta = rng.normal(0, 3, (P, V))
+    e = rng.normal(0, 0.3, (T, V))
+    for t in range(1, T):
+        e[t] += 0.3 * e[t - 1]
+    y = (X @ theta + e).astype(np.float32)
+    for kw in (dict(), dict(num_echoes=2, ar_cross_terms="dual")):
+        h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X, max_iterations=5, need_f=True, noise=vbabi.NOISE_AR1,
+                               param_overrides={"Parameter_30": dict(type="A")}, **kw)
+        assert h.cfg.n_params == 36 and h.cfg.params_ext and "wave" in hiplib.kernel_name(h)
+        cpu, got = oracle.run(h, y), hiplib.run_host(h, y)
+        parity.strict(h, cpu, got, what="36 parameters, AR(1) %s" % (kw or "one echo"), check_f=True, cpu2=oracle.run_fma(h, y), allow_floor=True)
+    T, P = 100, 40
+    tt = np.arange(T)
+    X = np.stack([np.cos(np.pi * (tt + 0.5) * k / T) for k in range(P)], axis=1)
+    y = (X @ rng.normal(0, 3, (P, V)) + rng.normal(0, 0.3, (T, V))).astype(np.float32)
+    h = vbabi.build_config(vbabi.MODEL_LINEAR, V, T, design=X)
+    ref, got = oracle.run_nlls(h, y), hiplib.nlls_run_host(h, y)
+    assert np.array_equal(ref["status"], got["status"]) and np.all(ref["status"] == 0)
+    rows = vbabi.mvn_rows(P)
+    off = P * (P + 1) // 2
+    want = np.linalg.lstsq(X, y.astype(np.float64), rcond=None)[0]
+    assert np.allclose(got["mvn"][off:off + P], want, rtol=1e-6, atol=1e-8)
+    assert np.allclose(got["mvn"][off:off + P], ref["mvn"][off:off + P], rtol=1e-7, atol=1e-9)
+    assert np.allclose(got["mvn"][:off], ref["mvn"][:off], rtol=1e-5, atol=1e-12)
+    assert got["mvn"].shape[0] == rows

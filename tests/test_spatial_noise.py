@@ -151,6 +151,27 @@ def test_spatial_priors_under_other_noise_models(typ, noise):
 
 
 @gpu
+@pytest.mark.parametrize("noise", ["ar", "ar2none", "ar2same", "ar2dual"])
+def test_alpha_distributions_from_file_under_spatial_vb(noise):
+    """noise-initial-prior / -posterior for the AR(1) coefficients (Ar1cParams::InputFromMVN, noisemodel_ar.cc:302-316)
+    inside the spatial loop: an informative prior with covariance between the alphas and a given initial posterior,
+    with F (the prior's log-determinant, quadratic form and trace are terms of it)"""
+    from test_ar_general import alpha_distributions
+    n_alphas = 2 + {"none": 0, "same": 1, "dual": 2}[NOISES[noise].get("ar_cross_terms", "none")]
+    prior, post = alpha_distributions(n_alphas, seed=40 + n_alphas)
+    _, coords = masked_volume((9, 8, 6), seed=21)
+    V, T = coords.shape[1], 40
+    _, y = smooth_line_data(coords, T, seed=22, rho=0.3)
+    for typ, kw in (("M", dict(ar_alpha_prior=prior, ar_alpha_post=post)), ("P", dict(ar_alpha_prior=prior)), ("m", dict(ar_alpha_post=post))):
+        h = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=6, need_f=True, param_overrides={"c0": dict(type=typ)},
+                               **NOISES[noise], **kw)
+        plain = vbabi.build_config(vbabi.MODEL_POLY, V, T, degree=1, max_iterations=6, need_f=True, param_overrides={"c0": dict(type=typ)},
+                                   **NOISES[noise])
+        _, got = spatial_check(h, vbabi.SpatialHolder(coords), y, "alpha from file %s %s" % (typ, noise), check_f=True)
+        assert np.abs(got["free_energy"] - hiplib.run_spatial_host(plain, vbabi.SpatialHolder(coords), y)["free_energy"]).max() > 1e-3
+
+
+@gpu
 @pytest.mark.parametrize("noise", ["ar", "pattern12", "ar2dual", "ar2none"])
 def test_nonlinear_model_with_free_energy_ard_and_two_spatial_parameters(noise):
     _, coords = masked_volume((10, 8, 6), seed=5)
