@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 #define FVB_MAX_PARAMS 32
-#define FVB_MAX_PARAMS_EXT 128 /* with fvb_config.params_ext (the wave-per-voxel kernel; what its LDS holds decides) */
+#define FVB_MAX_PARAMS_EXT 128 /* with fvb_config.params_ext (the wave-per-voxel kernels; what their LDS holds decides) */
 #define FVB_MAX_PHIS 8
 #define FVB_MAX_ALPHAS 4 /* AR(1) coefficients: 2 + ar_cross_terms (noisemodel_ar.cc:360-377) */
 #define FVB_ABI_VERSION 9
@@ -110,9 +110,10 @@ enum fvb_status
 };
 
 /* The per-parameter entries of fvb_config for a model with MORE than FVB_MAX_PARAMS parameters (the reference has no
- * limit): [n_params] arrays in the memory space of the configuration's other pointers. The wave-per-voxel kernel takes
- * such problems (white noise, any built-in model; up to what its LDS holds: n_times, n_params with
- * 8 (4 T + T P + 7 P^2 + ...) bytes <= 160 KB), through fabber_vb_run_host / _device and fabber_vb_postproc_*. */
+ * limit): [n_params] arrays in the memory space of the configuration's other pointers. The wave-per-voxel kernels take
+ * such problems (voxelwise VB under white or AR(1) noise and method=nlls, any built-in model; up to what their LDS holds:
+ * n_times, n_params with 8 (4 T + T P + 7 P^2 + ...) bytes <= 160 KB, AR(1): 3 T P), through fabber_vb_run_host / _device,
+ * fabber_nlls_run_host / _device and fabber_vb_postproc_*. */
 typedef struct fvb_param_table
 {
     const int32_t *transform, *prior_type;
