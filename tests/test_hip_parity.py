@@ -550,4 +550,6 @@ def test_math_building_blocks_as_the_device_compiles_them():
         assert np.max(np.abs(full - ref)) <= 1e-13 * cond * np.max(np.abs(ref)) + 1e-300
         assert abs(ld - np.linalg.slogdet(a)[1]) <= 1e-12 * max(1.0, abs(ld))
         tw_inv, tw_ld, _, ok = hiplib.ldl_inverse(a)
-        assert ok and abs(tw_ld - ld) <= 1e-14 * max(1.0, abs(ld))  # (the device's log against glibc's: a few ulp)
+        # (the device's log against glibc's: a few ulp - and the pivots themselves, which the device forms with fused
+        # multiply-adds and the host twin without: their relative difference grows with the condition number)
+        assert ok and abs(tw_ld - ld) <= 1e-14 * max(1.0, abs(ld)) + 2e-16 * cond, (tw_ld, ld, cond)

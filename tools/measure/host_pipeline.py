@@ -25,12 +25,21 @@ def main():
     ap.add_argument("--calls", type=int, default=5)
     ap.add_argument("--voxels", type=int, default=1_000_000)
     ap.add_argument("--once", type=int, default=None)
+    ap.add_argument("--pinned", action="store_true", help="pin the caller's buffers first (fabber_vb_pin_host_buffer)")
     ap.add_argument("--schedules", default="", help="semicolon-separated FVB_HOST_BLOCK_SCHEDULE values to try after the block sizes")
     a = ap.parse_args()
     import cases
     from fabber_core_amd import hiplib
     h, y = cases.exp_problem(a.voxels, 100, 2, 0.02, seed=20260103, max_iterations=50)
     res = hiplib.run_host(h, y)
+    if a.pinned:
+        import ctypes as C
+        L = hiplib.lib()
+        L.fabber_vb_pin_host_buffer.restype = C.c_int32
+        L.fabber_vb_pin_host_buffer.argtypes = [C.c_void_p, C.c_size_t]
+        y = np.ascontiguousarray(y)
+        for arr in [y] + [v for v in res.values() if isinstance(v, np.ndarray)]:
+            print("pin", arr.nbytes, L.fabber_vb_pin_host_buffer(arr.ctypes.data, arr.nbytes))
     blocks = [a.once] if a.once is not None else [int(b) for b in a.blocks.split(",")]
     out = {}
     for b in blocks:
