@@ -481,6 +481,11 @@ __global__ __launch_bounds__(64) void device_math_kernel(int what, int n, const 
     }
 }
 
+namespace
+{
+void destroy_idle_pipe_streams();
+}
+
 extern "C" {
 
 int32_t fabber_vb_mvn_rows(int32_t n)
@@ -508,6 +513,7 @@ const char *fabber_vb_last_error(void)
 
 void fabber_vb_release_cached_memory(void)
 {
+    destroy_idle_pipe_streams();
     fvb::api_release_pools(0);
 }
 
@@ -680,7 +686,10 @@ struct HostBlock
     int v0 = 0, v1 = 0, kernel_voxels = 0, rows = 0;
     fvb_config d;
     fvb_outputs dout;
-    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_f, b_hist, b_hlen, b_status, b_it;
+    DevBuf b_data, b_design, b_phi, b_init, b_img[FVB_MAX_PARAMS], b_mvn, b_small, b_hist;
+    // F (8 bytes), history length, status, iterations (4 each) of a voxel: one device buffer, [F][hlen][status][it]
+    static constexpr size_t SMALL_BYTES_PER_VOXEL = 8 + 4 + 4 + 4;
+    size_t small_bytes = 0;
     DeviceParamTable ptable;
     hipEvent_t up_done = nullptr, fit_done = nullptr;
     ~HostBlock()
@@ -739,31 +748,37 @@ struct HostBlock
         memset(&dout, 0, sizeof(dout));
         FVB_HIP_CHECK(b_mvn.alloc(sizeof(double) * rows * Vb, stream));
         dout.mvn = (double *)b_mvn.p;
-        if (out->free_energy)
         {
-            FVB_HIP_CHECK(b_f.alloc(sizeof(double) * Vb, stream));
-            dout.free_energy = (double *)b_f.p;
+            // (sections the caller does not want are left out; every section starts on a multiple of 8 bytes because F
+            // comes first and Vb is even for every block but possibly the last, whose int sections are padded)
+            const size_t ints = (Vb + 1) / 2 * 2 * sizeof(int32_t);
+            small_bytes = (out->free_energy ? sizeof(double) * Vb : 0) + (out->f_history_len ? ints : 0) + (out->status ? ints : 0)
+                + (out->iterations ? ints : 0);
+            FVB_HIP_CHECK(b_small.alloc(small_bytes, stream));
+            char *q = (char *)b_small.p;
+            if (out->free_energy)
+            {
+                dout.free_energy = (double *)q;
+                q += sizeof(double) * Vb;
+            }
+            if (out->f_history_len)
+            {
+                dout.f_history_len = (int32_t *)q;
+                q += ints;
+            }
+            if (out->status)
+            {
+                dout.status = (int32_t *)q;
+                q += ints;
+            }
+            if (out->iterations)
+                dout.iterations = (int32_t *)q;
         }
         if (out->f_history && cfg->f_history_rows > 0)
         {
             FVB_HIP_CHECK(b_hist.alloc(sizeof(double) * cfg->f_history_rows * Vb, stream));
             FVB_HIP_CHECK(hipMemsetAsync(b_hist.p, 0xff, sizeof(double) * cfg->f_history_rows * Vb, stream)); // NaN fill
             dout.f_history = (double *)b_hist.p;
-        }
-        if (out->f_history_len)
-        {
-            FVB_HIP_CHECK(b_hlen.alloc(sizeof(int32_t) * Vb, stream));
-            dout.f_history_len = (int32_t *)b_hlen.p;
-        }
-        if (out->status)
-        {
-            FVB_HIP_CHECK(b_status.alloc(sizeof(int32_t) * Vb, stream));
-            dout.status = (int32_t *)b_status.p;
-        }
-        if (out->iterations)
-        {
-            FVB_HIP_CHECK(b_it.alloc(sizeof(int32_t) * Vb, stream));
-            dout.iterations = (int32_t *)b_it.p;
         }
         FVB_HIP_CHECK(hipEventCreateWithFlags(&up_done, hipEventDisableTiming));
         FVB_HIP_CHECK(hipEventRecord(up_done, stream));
@@ -779,8 +794,9 @@ struct HostBlock
         FVB_HIP_CHECK(hipEventRecord(fit_done, stream));
         return 0;
     }
-    // returns after the block's results are in the caller's arrays
-    int stage_out(hipStream_t stream)
+    // returns after the block's results are in the caller's arrays. bounce: pinned host memory of at least small_bytes
+    // (the small arrays come down in one copy and are handed out from there), or NULL: one copy per array
+    int stage_out(hipStream_t stream, void *bounce = nullptr)
     {
         const size_t V = (size_t)cfg->n_voxels, Vb = (size_t)(v1 - v0);
         auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
@@ -788,18 +804,38 @@ struct HostBlock
                 hipMemcpyDeviceToHost, stream);
         };
         FVB_HIP_CHECK(hipStreamWaitEvent(stream, fit_done, 0));
+        if (bounce && small_bytes)
+            FVB_HIP_CHECK(hipMemcpyAsync(bounce, b_small.p, small_bytes, hipMemcpyDeviceToHost, stream)); // (ahead of the big one)
         FVB_HIP_CHECK(download(out->mvn, dout.mvn, sizeof(double), rows));
-        if (dout.free_energy)
-            FVB_HIP_CHECK(download(out->free_energy, dout.free_energy, sizeof(double), 1));
         if (dout.f_history)
             FVB_HIP_CHECK(download(out->f_history, dout.f_history, sizeof(double), cfg->f_history_rows));
-        if (dout.f_history_len)
-            FVB_HIP_CHECK(download(out->f_history_len, dout.f_history_len, sizeof(int32_t), 1));
-        if (dout.status)
-            FVB_HIP_CHECK(download(out->status, dout.status, sizeof(int32_t), 1));
-        if (dout.iterations)
-            FVB_HIP_CHECK(download(out->iterations, dout.iterations, sizeof(int32_t), 1));
+        if (!bounce)
+        {
+            if (dout.free_energy)
+                FVB_HIP_CHECK(download(out->free_energy, dout.free_energy, sizeof(double), 1));
+            if (dout.f_history_len)
+                FVB_HIP_CHECK(download(out->f_history_len, dout.f_history_len, sizeof(int32_t), 1));
+            if (dout.status)
+                FVB_HIP_CHECK(download(out->status, dout.status, sizeof(int32_t), 1));
+            if (dout.iterations)
+                FVB_HIP_CHECK(download(out->iterations, dout.iterations, sizeof(int32_t), 1));
+        }
         FVB_HIP_CHECK(hipStreamSynchronize(stream));
+        if (bounce && small_bytes)
+        {
+            const char *base = (const char *)b_small.p;
+            auto hand_out = [&](void *dst, const void *dev, size_t elem) {
+                memcpy((char *)dst + (size_t)v0 * elem, (const char *)bounce + ((const char *)dev - base), Vb * elem);
+            };
+            if (dout.free_energy)
+                hand_out(out->free_energy, dout.free_energy, sizeof(double));
+            if (dout.f_history_len)
+                hand_out(out->f_history_len, dout.f_history_len, sizeof(int32_t));
+            if (dout.status)
+                hand_out(out->status, dout.status, sizeof(int32_t));
+            if (dout.iterations)
+                hand_out(out->iterations, dout.iterations, sizeof(int32_t));
+        }
         return 0;
     }
 };
@@ -839,6 +875,98 @@ int run_host_block(const fvb_config *cfg, const void *data, const fvb_outputs *o
 // dropped: gathering the rows into pinned slots with 12 host threads and one DMA per slot - the host's own memcpy
 // (~20 GB/s) is then on the critical path: 32 - 37 ms. A caller that keeps its buffers can take the copies off the
 // host altogether: fabber_vb_pin_host_buffer (below) - the same calls then are asynchronous rectangle DMAs.
+// The four streams of a pipelined call (and a pinned bounce buffer for the blocks' small result arrays) are kept between
+// calls: creating and destroying them was 4 - 5 ms of a 23 ms call (hipStreamCreateWithFlags 0.45 - 0.6 ms each,
+// hipStreamDestroy 0.5 - 1.2 ms each: rocprofv3 --hip-runtime-trace, tools/measure/host_timeline.sh). A call takes a
+// set of its device from the cache or makes one; fabber_vb_release_cached_memory destroys the idle ones.
+struct PipeStreams
+{
+    int device = -1;
+    hipStream_t up = nullptr, fit[2] = { nullptr, nullptr }, down = nullptr;
+    void *bounce = nullptr; // pinned host memory
+    size_t bounce_bytes = 0;
+    int create(int dev)
+    {
+        device = dev;
+        FVB_HIP_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+        FVB_HIP_CHECK(hipStreamCreateWithFlags(&fit[0], hipStreamNonBlocking));
+        FVB_HIP_CHECK(hipStreamCreateWithFlags(&fit[1], hipStreamNonBlocking));
+        FVB_HIP_CHECK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+        return 0;
+    }
+    int need_bounce(size_t bytes)
+    {
+        if (bytes <= bounce_bytes)
+            return 0;
+        if (bounce)
+            (void)hipHostFree(bounce);
+        bounce = nullptr;
+        bounce_bytes = 0;
+        FVB_HIP_CHECK(hipHostMalloc(&bounce, bytes, hipHostMallocDefault));
+        bounce_bytes = bytes;
+        return 0;
+    }
+    void destroy()
+    {
+        for (hipStream_t s : { up, fit[0], fit[1], down })
+            if (s)
+                (void)hipStreamDestroy(s);
+        if (bounce)
+            (void)hipHostFree(bounce);
+        up = fit[0] = fit[1] = down = nullptr;
+        bounce = nullptr;
+        bounce_bytes = 0;
+    }
+};
+struct PipeStreamCache
+{
+    std::mutex lock;
+    std::vector<PipeStreams> idle;
+};
+static PipeStreamCache &pipe_stream_cache()
+{
+    static PipeStreamCache c;
+    return c;
+}
+static int acquire_pipe_streams(int device, PipeStreams &ps)
+{
+    {
+        PipeStreamCache &c = pipe_stream_cache();
+        std::lock_guard<std::mutex> hold(c.lock);
+        for (size_t i = 0; i < c.idle.size(); i++)
+            if (c.idle[i].device == device)
+            {
+                ps = c.idle[i];
+                c.idle.erase(c.idle.begin() + (long)i);
+                return 0;
+            }
+    }
+    const int rc = ps.create(device);
+    if (rc)
+        ps.destroy();
+    return rc;
+}
+static void release_pipe_streams(const PipeStreams &ps)
+{
+    PipeStreamCache &c = pipe_stream_cache();
+    std::lock_guard<std::mutex> hold(c.lock);
+    c.idle.push_back(ps);
+}
+void destroy_idle_pipe_streams()
+{
+    PipeStreamCache &c = pipe_stream_cache();
+    std::lock_guard<std::mutex> hold(c.lock);
+    int now = 0;
+    (void)hipGetDevice(&now);
+    for (PipeStreams &ps : c.idle)
+    {
+        if (hipSetDevice(ps.device) == hipSuccess)
+            ps.destroy();
+    }
+    c.idle.clear();
+    (void)hipSetDevice(now);
+}
+
 int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_outputs *out, int device, int block_voxels)
 {
     FVB_HIP_CHECK(hipSetDevice(device));
@@ -884,12 +1012,31 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     const int n_unmasked = count_unmasked(cfg, cfg->phi_index);
     // (two streams take the blocks' kernels in turn: the first wavefronts of block b + 1 move into the SIMDs the last
     // stragglers of block b have left, instead of every block paying for its own tail)
-    hipStream_t s_up = nullptr, s_fit[2] = { nullptr, nullptr }, s_down = nullptr;
-    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit[0], hipStreamNonBlocking));
-    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_fit[1], hipStreamNonBlocking));
-    FVB_HIP_CHECK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    PipeStreams ps;
+    {
+        const int rc_streams = acquire_pipe_streams(device, ps);
+        if (rc_streams)
+            return rc_streams;
+    }
+    hipStream_t s_up = ps.up, s_fit[2] = { ps.fit[0], ps.fit[1] }, s_down = ps.down;
+    {
+        // the small result arrays of a block (F, history length, status, iterations) come down as ONE copy into pinned
+        // memory and are handed out from there: four pageable copies of ~1 MB cost the download thread 0.15 - 0.3 ms each
+        int widest = 0;
+        for (int b = 0; b < n_blocks; b++)
+            widest = std::max(widest, bounds[(size_t)b + 1] - bounds[(size_t)b]);
+        const int rc_bounce = ps.need_bounce((size_t)widest * HostBlock::SMALL_BYTES_PER_VOXEL + 64);
+        if (rc_bounce)
+        {
+            ps.destroy();
+            return rc_bounce;
+        }
+    }
     std::vector<std::unique_ptr<HostBlock> > blocks((size_t)n_blocks);
+    // blocks whose results are down: their buffers go back to the pool on a thread of their own (hipFreeAsync of a
+    // block's buffers took 0.4 - 1.0 ms of the download thread per block)
+    std::vector<std::unique_ptr<HostBlock> > finished;
+    bool no_more_finished = false;
     std::mutex lock;
     std::condition_variable cv;
     int launched = 0;       // blocks whose fit has been enqueued
@@ -914,15 +1061,33 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
                 if (launched <= b)
                     return;
             }
-            const int rc = blocks[(size_t)b]->stage_out(s_down);
+            const int rc = blocks[(size_t)b]->stage_out(s_down, ps.bounce);
             std::unique_lock<std::mutex> hold(lock);
             if (rc && rc_down == 0)
             {
                 rc_down = rc;
                 err_down = g_last_error; // thread-local: carry it to the caller's thread
             }
-            blocks[(size_t)b].reset(); // (its buffers go back to the pool: at most three blocks are resident)
-            released = b + 1;
+            finished.push_back(std::move(blocks[(size_t)b])); // (to the reaper: at most three blocks are resident)
+            cv.notify_all();
+        }
+    });
+    std::thread reaper([&] {
+        (void)hipSetDevice(device);
+        for (;;)
+        {
+            std::unique_ptr<HostBlock> blk;
+            {
+                std::unique_lock<std::mutex> hold(lock);
+                cv.wait(hold, [&] { return !finished.empty() || no_more_finished; });
+                if (finished.empty())
+                    return;
+                blk = std::move(finished.front());
+                finished.erase(finished.begin());
+            }
+            blk.reset(); // its buffers go back to the pool
+            std::unique_lock<std::mutex> hold(lock);
+            released++;
             cv.notify_all();
         }
     });
@@ -963,11 +1128,14 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     (void)hipStreamSynchronize(s_fit[0]);
     (void)hipStreamSynchronize(s_fit[1]);
     (void)hipStreamSynchronize(s_down);
+    {
+        std::unique_lock<std::mutex> hold(lock);
+        no_more_finished = true;
+        cv.notify_all();
+    }
+    reaper.join();
     blocks.clear();
-    (void)hipStreamDestroy(s_up);
-    (void)hipStreamDestroy(s_fit[0]);
-    (void)hipStreamDestroy(s_fit[1]);
-    (void)hipStreamDestroy(s_down);
+    release_pipe_streams(ps);
     if (rc)
         return rc;
     if (rc_down)
