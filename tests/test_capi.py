@@ -148,6 +148,66 @@ def test_run_without_gpu_fails_loudly():
         assert "no HIP device" in e.value.message and "no CPU fallback" in e.value.message
 
 
+def test_noise_distribution_files_are_checked_before_the_engine_runs(tmp_path):
+    """noise-initial-prior / -posterior: what Ar1cParams / WhiteParams::InputFromMVN reject (noisemodel_ar.cc:302-316,
+    noisemodel_white.cc:70-79, dist_mvn.cc:157-165) is rejected while the configuration is built - no device needed"""
+    data = volume((2, 2, 2), [VAL + 0.1 * i for i in range(20)])
+
+    def write(path, mean, cov):
+        n = len(mean)
+        m = np.zeros((n + 1, n + 1))
+        m[:n, :n], m[:n, n], m[n, :n], m[n, n] = cov, mean, mean, 1
+        path.write_text("\n".join(" ".join("%.17g" % x for x in row) for row in m) + "\n")
+
+    def run(noise_opts, f):
+        with fabber.Fabber() as fab:
+            fab.set_extent((2, 2, 2))
+            fab.set_options(dict({"model": "poly", "degree": 1, "method": "vb", "noise-initial-prior": str(f)}, **noise_opts))
+            fab.set_data("data", data)
+            fab.run()
+
+    f = tmp_path / "dist.mat"
+    ar2 = {"noise": "ar", "num-echoes": 2, "ar1-cross-terms": "same"}       # 3 alphas + 2 precisions
+    cov = np.diag([0.1, 0.1, 0.1, 2.0, 2.0])
+    mean = [0.1, -0.1, 0.0, 4.0, 4.0]
+    cov[0, 3] = cov[3, 0] = 0.01
+    write(f, mean, cov)
+    with pytest.raises(fabber.FabberError, match="independent"):
+        run(ar2, f)
+    cov[0, 3] = cov[3, 0] = 0
+    cov[3, 4] = cov[4, 3] = 0.5
+    write(f, mean, cov)
+    with pytest.raises(fabber.FabberError, match="zero covariance"):
+        run(ar2, f)
+    cov[3, 4] = cov[4, 3] = 0
+    write(f, mean[:4], cov[:4, :4])
+    with pytest.raises(fabber.FabberError, match="entries"):
+        run(ar2, f)
+    cov[1, 1] = -0.1
+    write(f, mean, cov)
+    with pytest.raises(fabber.FabberError, match="positive definite"):
+        run(ar2, f)
+    cov[1, 1] = 0.1
+    write(f, mean[:3] + [-4.0, 4.0], cov)
+    with pytest.raises(fabber.FabberError, match="positive mean and a positive variance"):
+        run(ar2, f)
+    write(f, [4.0, 4.0], np.array([[2.0, 0.3], [0.3, 2.0]]))
+    with pytest.raises(fabber.FabberError, match="zero covariance"):
+        run({"noise": "white", "noise-pattern": "12"}, f)
+    # a well-formed file gets as far as the engine
+    write(f, mean, cov)
+    if not hiplib_has_device():
+        with pytest.raises(fabber.FabberError, match="no HIP device"):
+            run(ar2, f)
+
+
+def hiplib_has_device():
+    from fabber_core_amd import hiplib
+    L = hiplib.lib()
+    L.fabber_vb_device_count.restype = C.c_int32
+    return L.fabber_vb_device_count() > 0
+
+
 # ---------------------------------------------------------------------------------------------
 # GPU: the reference's known-answer tests through the C ABI
 # ---------------------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
+"""The reference's C ABI on C3 (fabber_new .. fabber_destroy, bench.py's e2e leg) with FVB_HOST_TIMING=1: the host side's stage timers on stderr."""
 import os, sys, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["FVB_HOST_TIMING"] = "1"
 import bench, cases
 w = bench.WORKLOADS["c3"]

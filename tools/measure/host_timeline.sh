@@ -6,7 +6,12 @@ OUT=$ROOT/gpurun_out/host_timeline
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT -- python3 $ROOT/tools/measure/host_pipeline.py --once ${1:-262144} ${PIN:+--pinned} > $OUT.log 2>&1 < /dev/null
+# PROG=e2e: the reference's C ABI (fabber_new .. fabber_destroy, tools/measure/e2e_timing.py) instead of the bare engine call
+if [ "$PROG" = e2e ]; then
+    timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT -- python3 $ROOT/tools/measure/e2e_timing.py > $OUT.log 2>&1 < /dev/null
+else
+    timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT -- python3 $ROOT/tools/measure/host_pipeline.py --once ${1:-262144} ${PIN:+--pinned} > $OUT.log 2>&1 < /dev/null
+fi
 tail -3 $OUT.log
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
@@ -28,7 +33,7 @@ ev.sort()
 if not ev:
     sys.exit("no events")
 t_end = max(e for _, e, _, _ in ev)
-sel = [x for x in ev if x[0] > t_end - 45e6]
+sel = [x for x in ev if x[0] > t_end - float(__import__('os').environ.get('WINDOW_MS', '45')) * 1e6]
 t0 = sel[0][0]
 for s, e, k, name in sel:
     print("%8.3f %8.3f %7.3f %s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, k, name))
