@@ -13,6 +13,11 @@
 #include "noisemodel_white.h"
 #include "noisemodel_ar.h"
 
+#include "armawrap/newmat.h"
+#include "../../../include/fabber_vb.h"
+
+#include <cstdlib>
+
 void FabberSetup::SetupDefaultInferenceTechniques()
 {
     InferenceTechniqueFactory *f = InferenceTechniqueFactory::GetInstance();
@@ -42,8 +47,26 @@ void FabberSetup::SetupDefaultConvergenceDetectors()
     f->Add("trialmode", &ConvergenceDetector::NewTrialMode);
     f->Add("lm", &ConvergenceDetector::NewLM);
 }
+// The volumes of a run (blocks of 8 MB and more: newmat.h) are page-locked when they are created and unlocked before they
+// are freed, by the library that owns the GPU (BigBlockHooks). FVB_HOST_NO_PINNED_IMAGES=1 leaves them pageable.
+static void pin_block(void *p, std::size_t bytes)
+{
+    if (fabber_vb_device_count() > 0)
+        (void)fabber_vb_pin_host_buffer(p, (uint64_t)bytes);
+}
+static void unpin_block(void *p, std::size_t)
+{
+    if (fabber_vb_device_count() > 0)
+        (void)fabber_vb_unpin_host_buffer(p);
+}
+
 void FabberSetup::SetupDefaults()
 {
+    if (!getenv("FVB_HOST_NO_PINNED_IMAGES"))
+    {
+        NEWMAT::BigBlockHooks::created() = &pin_block;
+        NEWMAT::BigBlockHooks::dying() = &unpin_block;
+    }
     SetupDefaultInferenceTechniques();
     SetupDefaultNoiseModels();
     SetupDefaultFwdModels();

@@ -418,6 +418,13 @@ hipMemPool_t api_pool()
     {
         uint64_t never = UINT64_MAX;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
+        if (getenv("FVB_POOL_CONSERVATIVE")) // (experiment switch: no reuse of a freed block across streams)
+        {
+            int off = 0;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowOpportunistic, &off);
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowInternalDependencies, &off);
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseFollowEventDependencies, &off);
+        }
     }
     else
     {
@@ -675,6 +682,38 @@ namespace
 // Voxels [v0, v1) of a host-resident problem on one device: the block's columns of every [row][voxel]
 // image go up and down as 2-D copies (row pitch = the caller's n_voxels), the kernels see a problem of
 // v1 - v0 voxels. Runs on `stream`; returns after the block's results are in the caller's arrays.
+// Rows of a [row][voxel] host image to or from a block's device buffer. Page-locked host memory (the caller's own, or the
+// C ABI library's volumes, which it pins when it creates them) moves row by row as plain 1-D DMA transfers; pageable
+// memory as ONE 2-D copy, which the runtime stages. Why not 2-D for both: with ROCm 7.2's runtime a 2-D asynchronous copy
+// between registered host memory and the device delivered wrong data for the block that ends at the end of the
+// registration (tools/measure/runtime_check.py with PIN=1: the last 131 072 voxels of C3 every time; ROCm 7.0's runtime,
+// the one PyTorch bundles, copies them right) - a row-wise 1-D transfer is the form nothing can get wrong.
+static bool is_locked_host_memory(const void *p)
+{
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess)
+    {
+        (void)hipGetLastError(); // (an ordinary pointer: not an error)
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+static hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipMemcpyKind kind,
+    hipStream_t stream, bool row_by_row)
+{
+    if (!row_by_row || rows <= 1 || (dpitch == width && spitch == width))
+        return (dpitch == width && spitch == width) ? hipMemcpyAsync(dst, src, width * rows, kind, stream)
+                                                    : hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, stream);
+    for (size_t r = 0; r < rows; r++)
+    {
+        const hipError_t e = hipMemcpyAsync((char *)dst + r * dpitch, (const char *)src + r * spitch, width, kind, stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
 // The three stages of a block: in (allocate, upload), fit (the kernels), out (download). They may run on three
 // different streams - the pipelined host entry point below uploads block b + 1 and downloads block b - 1 while block
 // b is being fitted - ordered by the events up_done and fit_done.
@@ -706,8 +745,8 @@ struct HostBlock
         rows = fabber_vb_mvn_rows(P + noise_outputs(cfg));
         const size_t esz = cfg->data_f64 ? 8 : 4;
         auto upload = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-            return hipMemcpy2DAsync(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows,
-                hipMemcpyHostToDevice, stream);
+            return copy_rows(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows, hipMemcpyHostToDevice,
+                stream, is_locked_host_memory(src));
         };
         d = *cfg;
         d.n_voxels = (int32_t)Vb;
@@ -800,8 +839,8 @@ struct HostBlock
     {
         const size_t V = (size_t)cfg->n_voxels, Vb = (size_t)(v1 - v0);
         auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-            return hipMemcpy2DAsync((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows,
-                hipMemcpyDeviceToHost, stream);
+            return copy_rows((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows, hipMemcpyDeviceToHost, stream,
+                is_locked_host_memory(dst));
         };
         FVB_HIP_CHECK(hipStreamWaitEvent(stream, fit_done, 0));
         if (bounce && small_bytes)
@@ -948,6 +987,12 @@ static int acquire_pipe_streams(int device, PipeStreams &ps)
 }
 static void release_pipe_streams(const PipeStreams &ps)
 {
+    if (getenv("FVB_NO_STREAM_CACHE")) // (experiment switch: the streams of a call die with it, as before round 4)
+    {
+        PipeStreams gone = ps;
+        gone.destroy();
+        return;
+    }
     PipeStreamCache &c = pipe_stream_cache();
     std::lock_guard<std::mutex> hold(c.lock);
     c.idle.push_back(ps);
@@ -1108,8 +1153,12 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
         blk->v1 = bounds[(size_t)b + 1];
         blk->kernel_voxels = V;
         rc = blk->stage_in(s_up);
+        if (rc == 0 && getenv("FVB_SYNC_UPLOAD")) // (experiment switch)
+            (void)hipStreamSynchronize(s_up);
         if (rc == 0)
             rc = blk->fit(s_fit[b & 1], n_unmasked);
+        if (rc == 0 && getenv("FVB_SYNC_FIT")) // (experiment switch)
+            (void)hipStreamSynchronize(s_fit[b & 1]);
         std::unique_lock<std::mutex> hold(lock);
         if (rc == 0)
         {
