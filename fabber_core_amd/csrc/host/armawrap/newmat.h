@@ -169,12 +169,9 @@ private:
 // next one of the same size: a run through the C ABI allocates ~1 GB of images between fabber_new and fabber_destroy, and
 // mapping, first-touching and unmapping them was a third of a million-voxel run (35 ms in fabber_destroy alone). The
 // cache is bounded (FVB_HOST_CACHE_BYTES, default 3 GiB; 0 = off), process-wide, and emptied by trim().
-// What the library that owns the GPU does with a big block when it is created and before it is freed: the C ABI layer
-// registers the engine's fabber_vb_pin_host_buffer / fabber_vb_unpin_host_buffer here, so that the volumes of a run
-// (series, result images) are page-locked ONCE and every copy to or from the device is a plain DMA transfer. Beside the
-// speed, this takes the blocks out of the HIP runtime's pageable-copy path, which pins user memory on the fly and keeps
-// those pins by address: with ROCm 7.2's runtime, blocks handed out again by the cache below came back with wrong
-// contents from the pipelined engine call (tools/measure/runtime_check_capi.py; ROCm 7.0's runtime did not show it).
+// What the library that owns the GPU does with a big block when it is created and before it is freed: with
+// FVB_HOST_PINNED_IMAGES=1 the C ABI layer registers the engine's fabber_vb_pin_host_buffer / fabber_vb_unpin_host_buffer
+// here, so that the volumes of a run (series, result images) are page-locked once (setup.cc). Off by default.
 struct BigBlockHooks
 {
     typedef void (*Fn)(void *, std::size_t);

@@ -47,8 +47,9 @@ void FabberSetup::SetupDefaultConvergenceDetectors()
     f->Add("trialmode", &ConvergenceDetector::NewTrialMode);
     f->Add("lm", &ConvergenceDetector::NewLM);
 }
-// The volumes of a run (blocks of 8 MB and more: newmat.h) are page-locked when they are created and unlocked before they
-// are freed, by the library that owns the GPU (BigBlockHooks). FVB_HOST_NO_PINNED_IMAGES=1 leaves them pageable.
+// FVB_HOST_PINNED_IMAGES=1: the volumes of a run (blocks of 8 MB and more: newmat.h) are page-locked when they are created and
+// unlocked before they are freed, by the library that owns the GPU (BigBlockHooks). Off by default: the copies of the
+// pipelined engine call run at the same rate from pageable memory (bench.py: 16.6 ms either way on C3).
 static void pin_block(void *p, std::size_t bytes)
 {
     if (fabber_vb_device_count() > 0)
@@ -62,7 +63,7 @@ static void unpin_block(void *p, std::size_t)
 
 void FabberSetup::SetupDefaults()
 {
-    if (!getenv("FVB_HOST_NO_PINNED_IMAGES"))
+    if (getenv("FVB_HOST_PINNED_IMAGES"))
     {
         NEWMAT::BigBlockHooks::created() = &pin_block;
         NEWMAT::BigBlockHooks::dying() = &unpin_block;

@@ -6,6 +6,7 @@
  * negative code and fabber_vb_last_error() says why.
  */
 #include "vb_dispatch.h"
+#include "vb_host_copy.h"
 #include "vb_wave_kernel.h"
 
 #include <hip/hip_runtime.h>
@@ -276,24 +277,76 @@ namespace fvb
 {
 void api_keep_pool_memory();
 hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream);
+hipError_t api_pool_free(void *p, hipStream_t stream);
 }
 namespace
 {
 // RAII device buffer used only by the *_host entry points: from the device's stream-ordered pool, which keeps the
 // memory between calls (hipMalloc + hipFree of the series-sized buffers were ~20 of the 50 ms a call on 1e6 voxels
 // of the bi-exponential configuration took through host pointers)
+// Device memory of ONE block of the pipelined host entry point: plain hipMalloc'd buffers that stay with the call's cached
+// streams (PipeStreams) and are handed out again - to the block that takes the slot three blocks later, and to the next
+// call. No stream-ordered pool here: upload, fit and download streams and two host threads work on a call, and with ROCm
+// 7.2's runtime buffers taken from ONE pool by several streams came out overlapping - wrong results from the pipelined
+// call, right ones with hipMalloc (tools/measure/runtime_check.py, runtime_check_capi.py: FVB_NO_POOL=1); ROCm 7.0's
+// runtime did not show it. A slot's buffers are reused only after the block that had them has been SEEN to finish.
+struct BlockSlot
+{
+    struct Buf
+    {
+        void *p;
+        size_t cap;
+        bool used;
+    };
+    std::vector<Buf> bufs;
+    hipError_t take(void **out, size_t bytes)
+    {
+        int best = -1;
+        for (size_t i = 0; i < bufs.size(); i++)
+            if (!bufs[i].used && bufs[i].cap >= bytes && (best < 0 || bufs[i].cap < bufs[(size_t)best].cap))
+                best = (int)i;
+        if (best < 0)
+        {
+            const size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+            void *p = nullptr;
+            const hipError_t e = hipMalloc(&p, cap);
+            if (e != hipSuccess)
+                return e;
+            bufs.push_back(Buf{ p, cap, false });
+            best = (int)bufs.size() - 1;
+        }
+        bufs[(size_t)best].used = true;
+        *out = bufs[(size_t)best].p;
+        return hipSuccess;
+    }
+    void reset()
+    {
+        for (Buf &b : bufs)
+            b.used = false;
+    }
+    void destroy()
+    {
+        for (Buf &b : bufs)
+            (void)hipFree(b.p);
+        bufs.clear();
+    }
+};
+
 struct DevBuf
 {
     void *p = nullptr;
     hipStream_t stream = nullptr;
+    BlockSlot *slot = nullptr; // the memory is the slot's (nothing to free here)
     ~DevBuf()
     {
-        if (p)
-            (void)hipFreeAsync(p, stream);
+        if (p && !slot)
+            (void)fvb::api_pool_free(p, stream);
     }
     hipError_t alloc(size_t bytes, hipStream_t s = nullptr)
     {
         stream = s;
+        if (slot)
+            return slot->take(&p, bytes ? bytes : 8);
         return fvb::api_pool_alloc(&p, bytes ? bytes : 8, s);
     }
 };
@@ -434,8 +487,30 @@ hipMemPool_t api_pool()
     t.pools.push_back(std::make_pair(dev, pool));
     return pool;
 }
+static const bool g_no_pool = getenv("FVB_NO_POOL") != nullptr; // (experiment switch: plain hipMalloc / hipFree, everything waited for)
+hipError_t api_pool_free(void *p, hipStream_t stream)
+{
+    if (!g_no_pool)
+        return hipFreeAsync(p, stream);
+    // (no synchronisation here - that would hide what the experiment is after: the memory is freed when the call ends)
+    static std::mutex lock;
+    static std::vector<void *> later;
+    std::lock_guard<std::mutex> hold(lock);
+    if (p)
+        later.push_back(p);
+    else
+    {
+        (void)hipDeviceSynchronize();
+        for (void *q : later)
+            (void)hipFree(q);
+        later.clear();
+    }
+    return hipSuccess;
+}
 hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream)
 {
+    if (g_no_pool)
+        return hipMalloc(p, bytes);
     hipMemPool_t pool = api_pool();
     return pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
 }
@@ -573,7 +648,7 @@ const char *fabber_vb_kernel_name(const fvb_config *cfg)
 namespace
 {
 int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *out, hipStream_t stream, int n_unmasked,
-    int kernel_voxels);
+    int kernel_voxels, BlockSlot *slot = nullptr);
 }
 
 int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const fvb_outputs *out, void *stream_,
@@ -585,9 +660,11 @@ int32_t fabber_vb_run_device_ex(const fvb_config *cfg, const void *data, const f
 namespace
 {
 // kernel_voxels: the voxel count the kernel choice (lane / wave) is made for - the whole problem's when
-// cfg describes one block of it (fabber_vb_run_host_multi), so that every block runs the same code
+// cfg describes one block of it (fabber_vb_run_host_multi), so that every block runs the same code.
+// slot: the kernels' work buffers (tiled series, saved state) come from the block's slot (pipelined host entry point)
+// instead of the stream-ordered pool.
 int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *out, hipStream_t stream, int n_unmasked,
-    int kernel_voxels)
+    int kernel_voxels, BlockSlot *slot)
 {
     int rc = validate(cfg);
     if (rc)
@@ -619,10 +696,11 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
     fvb_config choice = *cfg;
     choice.n_voxels = kernel_voxels;
     LaneKernelInfo lk = select_lane(&choice);
+    auto work_alloc = [&](void **p, size_t bytes) { return slot ? slot->take(p, bytes) : api_pool_alloc(p, bytes, stream); };
     if (lk.fn || lk.fn_tiles_f32)
     {
         if (needs_save(cfg))
-            FVB_HIP_CHECK(api_pool_alloc((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels, stream));
+            FVB_HIP_CHECK(work_alloc((void **)&ka.save, sizeof(double) * (size_t)lk.save_rows * cfg->n_voxels));
         const unsigned grid = (unsigned)((cfg->n_voxels + 63) / 64);
         LaneKernelFn fn = lk.fn;
         void *tiles = nullptr;
@@ -635,13 +713,13 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
             const unsigned rgrid = (unsigned)((V + 255) / 256);
             if (cfg->data_f64)
             {
-                FVB_HIP_CHECK(api_pool_alloc(&tiles, Tile<double>::bytes(V, T), stream));
+                FVB_HIP_CHECK(work_alloc(&tiles, Tile<double>::bytes(V, T)));
                 hipLaunchKernelGGL(retile_series<double>, dim3(rgrid), dim3(256), 0, stream, (const double *)data, (double *)tiles, V, T);
                 fn = (cfg->convergence == FVB_CONV_MAXITS && lk.fn_tiles_f64_counting) ? lk.fn_tiles_f64_counting : lk.fn_tiles_f64;
             }
             else
             {
-                FVB_HIP_CHECK(api_pool_alloc(&tiles, Tile<float>::bytes(V, T), stream));
+                FVB_HIP_CHECK(work_alloc(&tiles, Tile<float>::bytes(V, T)));
                 hipLaunchKernelGGL(retile_series<float>, dim3(rgrid), dim3(256), 0, stream, (const float *)data, (float *)tiles, V, T);
                 fn = (cfg->convergence == FVB_CONV_MAXITS && lk.fn_tiles_f32_counting) ? lk.fn_tiles_f32_counting : lk.fn_tiles_f32;
             }
@@ -652,10 +730,9 @@ int run_device_as(const fvb_config *cfg, const void *data, const fvb_outputs *ou
         const size_t lds = (cfg->noise == FVB_NOISE_WHITE && cfg->n_phis > 1) ? (size_t)((cfg->n_times + 15) & ~15) : 0;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, ka);
         FVB_HIP_CHECK(hipGetLastError());
-        if (tiles)
-            FVB_HIP_CHECK(hipFreeAsync(tiles, stream));
-        if (ka.save)
-            FVB_HIP_CHECK(hipFreeAsync(ka.save, stream));
+        for (void *work : { tiles, (void *)ka.save })
+            if (work && !slot)
+                FVB_HIP_CHECK(api_pool_free(work, stream));
         return 0;
     }
     return launch_wave_kernel(ka, stream, g_last_error);
@@ -682,38 +759,6 @@ namespace
 // Voxels [v0, v1) of a host-resident problem on one device: the block's columns of every [row][voxel]
 // image go up and down as 2-D copies (row pitch = the caller's n_voxels), the kernels see a problem of
 // v1 - v0 voxels. Runs on `stream`; returns after the block's results are in the caller's arrays.
-// Rows of a [row][voxel] host image to or from a block's device buffer. Page-locked host memory (the caller's own, or the
-// C ABI library's volumes, which it pins when it creates them) moves row by row as plain 1-D DMA transfers; pageable
-// memory as ONE 2-D copy, which the runtime stages. Why not 2-D for both: with ROCm 7.2's runtime a 2-D asynchronous copy
-// between registered host memory and the device delivered wrong data for the block that ends at the end of the
-// registration (tools/measure/runtime_check.py with PIN=1: the last 131 072 voxels of C3 every time; ROCm 7.0's runtime,
-// the one PyTorch bundles, copies them right) - a row-wise 1-D transfer is the form nothing can get wrong.
-static bool is_locked_host_memory(const void *p)
-{
-    hipPointerAttribute_t attr;
-    memset(&attr, 0, sizeof(attr));
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess)
-    {
-        (void)hipGetLastError(); // (an ordinary pointer: not an error)
-        return false;
-    }
-    return attr.type == hipMemoryTypeHost;
-}
-static hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipMemcpyKind kind,
-    hipStream_t stream, bool row_by_row)
-{
-    if (!row_by_row || rows <= 1 || (dpitch == width && spitch == width))
-        return (dpitch == width && spitch == width) ? hipMemcpyAsync(dst, src, width * rows, kind, stream)
-                                                    : hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, stream);
-    for (size_t r = 0; r < rows; r++)
-    {
-        const hipError_t e = hipMemcpyAsync((char *)dst + r * dpitch, (const char *)src + r * spitch, width, kind, stream);
-        if (e != hipSuccess)
-            return e;
-    }
-    return hipSuccess;
-}
-
 // The three stages of a block: in (allocate, upload), fit (the kernels), out (download). They may run on three
 // different streams - the pipelined host entry point below uploads block b + 1 and downloads block b - 1 while block
 // b is being fitted - ordered by the events up_done and fit_done.
@@ -731,8 +776,11 @@ struct HostBlock
     size_t small_bytes = 0;
     DeviceParamTable ptable;
     hipEvent_t up_done = nullptr, fit_done = nullptr;
+    BlockSlot *slot = nullptr; // pipelined entry point: where every device buffer of the block comes from
     ~HostBlock()
     {
+        if (slot)
+            slot->reset(); // (the owner destroys a block only after its work has been seen to finish)
         if (up_done)
             (void)hipEventDestroy(up_done);
         if (fit_done)
@@ -750,6 +798,13 @@ struct HostBlock
         };
         d = *cfg;
         d.n_voxels = (int32_t)Vb;
+        if (slot)
+        {
+            for (DevBuf *b : { &b_data, &b_design, &b_phi, &b_init, &b_mvn, &b_small, &b_hist })
+                b->slot = slot;
+            for (DevBuf &b : b_img)
+                b.slot = slot;
+        }
         FVB_HIP_CHECK(b_data.alloc(T * Vb * esz, stream));
         FVB_HIP_CHECK(upload(b_data.p, data, esz, T));
         if (cfg->design)
@@ -826,7 +881,7 @@ struct HostBlock
     int fit(hipStream_t stream, int n_unmasked)
     {
         FVB_HIP_CHECK(hipStreamWaitEvent(stream, up_done, 0));
-        int rc = run_device_as(&d, b_data.p, &dout, stream, n_unmasked, kernel_voxels);
+        int rc = run_device_as(&d, b_data.p, &dout, stream, n_unmasked, kernel_voxels, slot);
         if (rc)
             return rc;
         FVB_HIP_CHECK(hipEventCreateWithFlags(&fit_done, hipEventDisableTiming));
@@ -924,6 +979,7 @@ struct PipeStreams
     hipStream_t up = nullptr, fit[2] = { nullptr, nullptr }, down = nullptr;
     void *bounce = nullptr; // pinned host memory
     size_t bounce_bytes = 0;
+    BlockSlot slots[3];     // device memory of the (at most three) blocks in flight
     int create(int dev)
     {
         device = dev;
@@ -952,6 +1008,8 @@ struct PipeStreams
                 (void)hipStreamDestroy(s);
         if (bounce)
             (void)hipHostFree(bounce);
+        for (BlockSlot &sl : slots)
+            sl.destroy();
         up = fit[0] = fit[1] = down = nullptr;
         bounce = nullptr;
         bounce_bytes = 0;
@@ -1152,6 +1210,7 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
         blk->v0 = bounds[(size_t)b];
         blk->v1 = bounds[(size_t)b + 1];
         blk->kernel_voxels = V;
+        blk->slot = &ps.slots[b % 3]; // (free: block b - 3 has been reaped, see the wait above)
         rc = blk->stage_in(s_up);
         if (rc == 0 && getenv("FVB_SYNC_UPLOAD")) // (experiment switch)
             (void)hipStreamSynchronize(s_up);
@@ -1184,6 +1243,8 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     }
     reaper.join();
     blocks.clear();
+    if (g_no_pool)
+        (void)fvb::api_pool_free(nullptr, nullptr); // (experiment switch: now the deferred frees)
     release_pipe_streams(ps);
     if (rc)
         return rc;
