@@ -14,7 +14,7 @@ from fabber_core_amd import fabber, hiplib  # noqa: E402
 
 what, V = sys.argv[1], int(sys.argv[2])
 h, y = cases.exp_problem(V, 100, 2, 0.02, seed=20260103, max_iterations=50)
-out = {"runtime": sorted({l.split()[-1] for l in open("/proc/self/maps") if "amdhip64" in l}), "torch_loaded": "torch" in sys.modules}
+out = {}
 if what == "engine":
     os.environ["FVB_HOST_BLOCK_VOXELS"] = "0"
     one = hiplib.run_host(h, y)
@@ -51,4 +51,5 @@ else:
     rows = eng["mvn"].shape[0]
     got = first.transpose(3, 2, 1, 0).reshape(rows, -1)
     out.update(identical=same, matches_engine=bool(np.allclose(got, eng["mvn"].astype(np.float32), rtol=1e-6, atol=0, equal_nan=True)))
+out.update(runtime=sorted({l.split()[-1] for l in open("/proc/self/maps") if "amdhip64" in l}), torch_loaded="torch" in sys.modules)
 print(json.dumps(out))
