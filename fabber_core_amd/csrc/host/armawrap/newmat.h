@@ -169,30 +169,6 @@ private:
 // next one of the same size: a run through the C ABI allocates ~1 GB of images between fabber_new and fabber_destroy, and
 // mapping, first-touching and unmapping them was a third of a million-voxel run (35 ms in fabber_destroy alone). The
 // cache is bounded (FVB_HOST_CACHE_BYTES, default 3 GiB; 0 = off), process-wide, and emptied by trim().
-// What the library that owns the GPU does with a big block when it is created and before it is freed: with
-// FVB_HOST_PINNED_IMAGES=1 the C ABI layer registers the engine's fabber_vb_pin_host_buffer / fabber_vb_unpin_host_buffer
-// here, so that the volumes of a run (series, result images) are page-locked once (setup.cc). Off by default.
-struct BigBlockHooks
-{
-    typedef void (*Fn)(void *, std::size_t);
-    static Fn &created()
-    {
-        static Fn f = nullptr;
-        return f;
-    }
-    static Fn &dying()
-    {
-        static Fn f = nullptr;
-        return f;
-    }
-    static void release(void *p, std::size_t bytes)
-    {
-        if (dying())
-            dying()(p, bytes);
-        free(p);
-    }
-};
-
 class BigBlockCache
 {
 public:
@@ -234,7 +210,7 @@ public:
             for (std::size_t i = 1; i < m_free.size(); i++)
                 if (m_free[i].second > m_free[big].second)
                     big = i;
-            BigBlockHooks::release(m_free[big].first, m_free[big].second);
+            free(m_free[big].first);
             m_held -= m_free[big].second;
             m_free[big] = m_free.back();
             m_free.pop_back();
@@ -256,7 +232,6 @@ private:
     }
     ~BigBlockCache()
     {
-        // (process exit: the GPU runtime may be gone already - the blocks are freed without the hook)
         for (std::size_t i = 0; i < m_free.size(); i++)
             free(m_free[i].first);
     }
@@ -296,11 +271,8 @@ struct DefaultInitAllocator : std::allocator<T>
         if (posix_memalign(&p, HUGE_PAGE, rounded) != 0)
             throw std::bad_alloc();
 #ifdef MADV_HUGEPAGE
-        if (!getenv("FVB_HOST_NO_THP")) // (experiment switch)
-            (void)madvise(p, rounded, MADV_HUGEPAGE);
+        (void)madvise(p, rounded, MADV_HUGEPAGE);
 #endif
-        if (BigBlockHooks::created())
-            BigBlockHooks::created()(p, rounded);
         return static_cast<T *>(p);
     }
     void deallocate(T *p, std::size_t n)
@@ -311,7 +283,7 @@ struct DefaultInitAllocator : std::allocator<T>
         {
             const std::size_t rounded = (n * sizeof(T) + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
             if (!BigBlockCache::instance().give(p, rounded))
-                BigBlockHooks::release(p, rounded);
+                free(p);
         }
     }
     template <class U>

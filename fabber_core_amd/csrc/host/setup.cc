@@ -13,10 +13,6 @@
 #include "noisemodel_white.h"
 #include "noisemodel_ar.h"
 
-#include "armawrap/newmat.h"
-#include "../../../include/fabber_vb.h"
-
-#include <cstdlib>
 
 void FabberSetup::SetupDefaultInferenceTechniques()
 {
@@ -47,27 +43,8 @@ void FabberSetup::SetupDefaultConvergenceDetectors()
     f->Add("trialmode", &ConvergenceDetector::NewTrialMode);
     f->Add("lm", &ConvergenceDetector::NewLM);
 }
-// FVB_HOST_PINNED_IMAGES=1: the volumes of a run (blocks of 8 MB and more: newmat.h) are page-locked when they are created and
-// unlocked before they are freed, by the library that owns the GPU (BigBlockHooks). Off by default: the copies of the
-// pipelined engine call run at the same rate from pageable memory (bench.py: 16.6 ms either way on C3).
-static void pin_block(void *p, std::size_t bytes)
-{
-    if (fabber_vb_device_count() > 0)
-        (void)fabber_vb_pin_host_buffer(p, (uint64_t)bytes);
-}
-static void unpin_block(void *p, std::size_t)
-{
-    if (fabber_vb_device_count() > 0)
-        (void)fabber_vb_unpin_host_buffer(p);
-}
-
 void FabberSetup::SetupDefaults()
 {
-    if (getenv("FVB_HOST_PINNED_IMAGES"))
-    {
-        NEWMAT::BigBlockHooks::created() = &pin_block;
-        NEWMAT::BigBlockHooks::dying() = &unpin_block;
-    }
     SetupDefaultInferenceTechniques();
     SetupDefaultNoiseModels();
     SetupDefaultFwdModels();

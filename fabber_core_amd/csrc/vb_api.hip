@@ -288,7 +288,7 @@ namespace
 // streams (PipeStreams) and are handed out again - to the block that takes the slot three blocks later, and to the next
 // call. No stream-ordered pool here: upload, fit and download streams and two host threads work on a call, and with ROCm
 // 7.2's runtime buffers taken from ONE pool by several streams came out overlapping - wrong results from the pipelined
-// call, right ones with hipMalloc (tools/measure/runtime_check.py, runtime_check_capi.py: FVB_NO_POOL=1); ROCm 7.0's
+// call, right ones with plain hipMalloc in the same code (tools/measure/runtime_check.py, runtime_check_capi.py); ROCm 7.0's
 // runtime did not show it. A slot's buffers are reused only after the block that had them has been SEEN to finish.
 struct BlockSlot
 {
@@ -471,13 +471,6 @@ hipMemPool_t api_pool()
     {
         uint64_t never = UINT64_MAX;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
-        if (getenv("FVB_POOL_CONSERVATIVE")) // (experiment switch: no reuse of a freed block across streams)
-        {
-            int off = 0;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowOpportunistic, &off);
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowInternalDependencies, &off);
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseFollowEventDependencies, &off);
-        }
     }
     else
     {
@@ -487,30 +480,12 @@ hipMemPool_t api_pool()
     t.pools.push_back(std::make_pair(dev, pool));
     return pool;
 }
-static const bool g_no_pool = getenv("FVB_NO_POOL") != nullptr; // (experiment switch: plain hipMalloc / hipFree, everything waited for)
 hipError_t api_pool_free(void *p, hipStream_t stream)
 {
-    if (!g_no_pool)
-        return hipFreeAsync(p, stream);
-    // (no synchronisation here - that would hide what the experiment is after: the memory is freed when the call ends)
-    static std::mutex lock;
-    static std::vector<void *> later;
-    std::lock_guard<std::mutex> hold(lock);
-    if (p)
-        later.push_back(p);
-    else
-    {
-        (void)hipDeviceSynchronize();
-        for (void *q : later)
-            (void)hipFree(q);
-        later.clear();
-    }
-    return hipSuccess;
+    return hipFreeAsync(p, stream);
 }
 hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream)
 {
-    if (g_no_pool)
-        return hipMalloc(p, bytes);
     hipMemPool_t pool = api_pool();
     return pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
 }
@@ -794,7 +769,7 @@ struct HostBlock
         const size_t esz = cfg->data_f64 ? 8 : 4;
         auto upload = [&](void *dst, const void *src, size_t elem, size_t nrows) {
             return copy_rows(dst, Vb * elem, (const char *)src + (size_t)v0 * elem, V * elem, Vb * elem, nrows, hipMemcpyHostToDevice,
-                stream, is_locked_host_memory(src));
+                stream);
         };
         d = *cfg;
         d.n_voxels = (int32_t)Vb;
@@ -894,8 +869,7 @@ struct HostBlock
     {
         const size_t V = (size_t)cfg->n_voxels, Vb = (size_t)(v1 - v0);
         auto download = [&](void *dst, const void *src, size_t elem, size_t nrows) {
-            return copy_rows((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows, hipMemcpyDeviceToHost, stream,
-                is_locked_host_memory(dst));
+            return copy_rows((char *)dst + (size_t)v0 * elem, V * elem, src, Vb * elem, Vb * elem, nrows, hipMemcpyDeviceToHost, stream);
         };
         FVB_HIP_CHECK(hipStreamWaitEvent(stream, fit_done, 0));
         if (bounce && small_bytes)
@@ -1045,12 +1019,6 @@ static int acquire_pipe_streams(int device, PipeStreams &ps)
 }
 static void release_pipe_streams(const PipeStreams &ps)
 {
-    if (getenv("FVB_NO_STREAM_CACHE")) // (experiment switch: the streams of a call die with it, as before round 4)
-    {
-        PipeStreams gone = ps;
-        gone.destroy();
-        return;
-    }
     PipeStreamCache &c = pipe_stream_cache();
     std::lock_guard<std::mutex> hold(c.lock);
     c.idle.push_back(ps);
@@ -1212,12 +1180,8 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
         blk->kernel_voxels = V;
         blk->slot = &ps.slots[b % 3]; // (free: block b - 3 has been reaped, see the wait above)
         rc = blk->stage_in(s_up);
-        if (rc == 0 && getenv("FVB_SYNC_UPLOAD")) // (experiment switch)
-            (void)hipStreamSynchronize(s_up);
         if (rc == 0)
             rc = blk->fit(s_fit[b & 1], n_unmasked);
-        if (rc == 0 && getenv("FVB_SYNC_FIT")) // (experiment switch)
-            (void)hipStreamSynchronize(s_fit[b & 1]);
         std::unique_lock<std::mutex> hold(lock);
         if (rc == 0)
         {
@@ -1243,8 +1207,6 @@ int run_host_pipelined(const fvb_config *cfg, const void *data, const fvb_output
     }
     reaper.join();
     blocks.clear();
-    if (g_no_pool)
-        (void)fvb::api_pool_free(nullptr, nullptr); // (experiment switch: now the deferred frees)
     release_pipe_streams(ps);
     if (rc)
         return rc;

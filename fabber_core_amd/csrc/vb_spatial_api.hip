@@ -1228,12 +1228,10 @@ int fvb_spatial_run::copy_means(int v_begin, int v_count, double *host_means, in
     const size_t width = sizeof(double) * (size_t)v_count;
     if (host_means)
     {
-        // (row by row where the other side is page-locked host memory: vb_host_copy.h says why)
-        const bool rows_apart = is_locked_host_memory(host_means);
         if (to_device)
-            FVB_HIP_CHECK(copy_rows(dev, sizeof(double) * (size_t)V, host_means, width, width, P, hipMemcpyDefault, stream, rows_apart));
+            FVB_HIP_CHECK(copy_rows(dev, sizeof(double) * (size_t)V, host_means, width, width, P, hipMemcpyDefault, stream));
         else
-            FVB_HIP_CHECK(copy_rows(host_means, width, dev, sizeof(double) * (size_t)V, width, P, hipMemcpyDefault, stream, rows_apart));
+            FVB_HIP_CHECK(copy_rows(host_means, width, dev, sizeof(double) * (size_t)V, width, P, hipMemcpyDefault, stream));
     }
     if (host_status)
     {
@@ -1923,7 +1921,7 @@ int fvb_spatial_multi::upload(const void *data, const fvb_outputs *out)
         hipStream_t st = sl.stream;
         auto upload_rows = [&](void *dst, const void *src, size_t elem, size_t nrows) {
             return copy_rows(dst, Vl * elem, (const char *)src + (size_t)sl.g0 * elem, (size_t)V * elem, Vl * elem, nrows,
-                hipMemcpyHostToDevice, st, is_locked_host_memory(src));
+                hipMemcpyHostToDevice, st);
         };
         sl.d = cfg;
         sl.d.n_voxels = (int32_t)Vl;
@@ -2270,7 +2268,7 @@ int fvb_spatial_multi::download(const fvb_outputs *out)
         const size_t Vl = (size_t)(sl.g1 - sl.g0), own = (size_t)(sl.e - sl.b), skip = (size_t)(sl.b - sl.g0);
         auto download_rows = [&](void *dst, const void *src, size_t elem, size_t nrows) {
             return copy_rows((char *)dst + (size_t)sl.b * elem, (size_t)V * elem, (const char *)src + skip * elem, Vl * elem, own * elem, nrows,
-                hipMemcpyDeviceToHost, sl.stream, is_locked_host_memory(dst));
+                hipMemcpyDeviceToHost, sl.stream);
         };
         FVB_HIP_CHECK(download_rows(out->mvn, sl.dout.mvn, sizeof(double), (size_t)rows));
         if (sl.dout.free_energy && out->free_energy)
