@@ -504,10 +504,16 @@ void api_release_pools(uint64_t keep_bytes)
     {
         if (hipSetDevice(e.first) != hipSuccess)
             continue;
-        (void)hipDeviceSynchronize();
         hipMemPool_t pool = e.second;
-        if (pool || hipDeviceGetDefaultMemPool(&pool, e.first) == hipSuccess)
-            (void)hipMemPoolTrimTo(pool, (size_t)keep_bytes);
+        if (!pool && hipDeviceGetDefaultMemPool(&pool, e.first) != hipSuccess)
+            continue;
+        // (nothing to give back: no need to wait for the device - fabber_destroy calls this when the last handle goes)
+        uint64_t reserved = UINT64_MAX;
+        if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &reserved) == hipSuccess && reserved <= keep_bytes)
+            continue;
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        (void)hipMemPoolTrimTo(pool, (size_t)keep_bytes);
     }
     (void)hipSetDevice(before);
 }
