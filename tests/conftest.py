@@ -17,7 +17,14 @@ def pytest_terminal_summary(terminalreporter):
     """Which strict() comparisons ran at a tolerance raised to the measured CPU-vs-CPU floor
     (tests/parity.py); also written to gpurun_out/parity_raised.json when that directory exists."""
     import json
+    import sys
     import parity
+    try:  # which HIP runtime this process ended up with (PyTorch's bundled copy, or the system's with FVB_NO_TORCH=1)
+        libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+        if libs:
+            terminalreporter.write_line("HIP runtime of this process: %s (torch imported: %s)" % (", ".join(libs), "torch" in sys.modules))
+    except OSError:
+        pass
     if not parity.RAISED:
         return
     terminalreporter.write_line("parity.strict ran at a raised tolerance in %d comparison(s):" % len(parity.RAISED))
