@@ -493,6 +493,59 @@ void api_keep_pool_memory()
 {
     (void)api_pool();
 }
+// A non-blocking stream beside the caller's (the spatial run's set-up kernel runs on one while the geometry is worked out):
+// kept between runs, because creating and destroying a stream costs 0.5 - 1.2 ms each (tools/measure/host_timeline.sh) -
+// of a 20 ms spatial run. Per device; fabber_vb_release_cached_memory destroys the idle ones.
+struct SideStreams
+{
+    std::mutex lock;
+    std::vector<std::pair<int, hipStream_t> > idle;
+};
+static SideStreams &side_streams()
+{
+    static SideStreams s;
+    return s;
+}
+hipError_t api_take_side_stream(hipStream_t *out, int *device)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    *device = dev;
+    {
+        SideStreams &c = side_streams();
+        std::lock_guard<std::mutex> hold(c.lock);
+        for (size_t i = 0; i < c.idle.size(); i++)
+            if (c.idle[i].first == dev)
+            {
+                *out = c.idle[i].second;
+                c.idle.erase(c.idle.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+// (the stream must be idle: the caller has synchronised it)
+void api_return_side_stream(hipStream_t s, int dev)
+{
+    SideStreams &c = side_streams();
+    std::lock_guard<std::mutex> hold(c.lock);
+    c.idle.push_back(std::make_pair(dev, s));
+}
+void destroy_side_streams()
+{
+    SideStreams &c = side_streams();
+    std::lock_guard<std::mutex> hold(c.lock);
+    int now = 0;
+    (void)hipGetDevice(&now);
+    for (auto &e : c.idle)
+        if (hipSetDevice(e.first) == hipSuccess)
+            (void)hipStreamDestroy(e.second);
+    c.idle.clear();
+    (void)hipSetDevice(now);
+}
+
 // keep_bytes: what every pool may keep for the next run (0 = give everything back)
 void api_release_pools(uint64_t keep_bytes)
 {
@@ -577,6 +630,7 @@ const char *fabber_vb_last_error(void)
 void fabber_vb_release_cached_memory(void)
 {
     destroy_idle_pipe_streams();
+    fvb::destroy_side_streams();
     fvb::api_release_pools(0);
 }
 

@@ -33,6 +33,8 @@ int api_precise_passes();
 double api_residual_tol();
 void api_keep_pool_memory();
 hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream);
+hipError_t api_take_side_stream(hipStream_t *out, int *device);
+void api_return_side_stream(hipStream_t s, int device);
 }
 
 namespace
@@ -509,13 +511,14 @@ struct fvb_spatial_run
     // host-evaluated models: the linearisations the set-up re-centre reads (see HostLin below)
     const double *lin_cur = nullptr, *lin_next = nullptr;
     hipStream_t setup_stream = nullptr;
+    int setup_device = 0;
     hipEvent_t setup_done = nullptr;
     ~fvb_spatial_run()
     {
         if (setup_stream)
         {
             (void)hipStreamSynchronize(setup_stream); // (before the buffers its kernel writes are given back)
-            (void)hipStreamDestroy(setup_stream);
+            fvb::api_return_side_stream(setup_stream, setup_device); // (kept for the next run on this device)
         }
         if (setup_done)
             (void)hipEventDestroy(setup_done);
@@ -597,7 +600,7 @@ int fvb_spatial_run::open(const fvb_config *cfg_, const fvb_spatial *sp_, const 
             early.nz_count[i] = nz_count[i];
         early.locked_centres = sp.locked_centres;
         early.locked_linear = sp.locked_centres != nullptr;
-        FVB_HIP_CHECK(hipStreamCreateWithFlags(&setup_stream, hipStreamNonBlocking));
+        FVB_HIP_CHECK(fvb::api_take_side_stream(&setup_stream, &setup_device));
         FVB_HIP_CHECK(hipEventCreateWithFlags(&setup_done, hipEventDisableTiming));
         // (the two buffers were allocated in `stream`'s order; the series is the caller's, complete in `stream`'s order too)
         FVB_HIP_CHECK(hipEventRecord(setup_done, stream));
