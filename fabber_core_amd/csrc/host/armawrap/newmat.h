@@ -258,7 +258,7 @@ struct DefaultInitAllocator : std::allocator<T>
     // Large blocks come 2 MB-aligned with a request for transparent huge pages: a freshly allocated volume is
     // faulted in - and given back at the end of the run - in 2 MB steps instead of 4 KB ones (first touch and
     // munmap of ~1 GB of images were a quarter of a second of a million-voxel run through the C ABI).
-    static constexpr std::size_t BIG = std::size_t(8) << 20, HUGE_PAGE = std::size_t(2) << 20;
+    static constexpr std::size_t BIG = std::size_t(1) << 20, HUGE_PAGE = std::size_t(2) << 20;
     T *allocate(std::size_t n)
     {
         const std::size_t bytes = n * sizeof(T);
