@@ -20,6 +20,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   cpu_baseline - the CPU oracle (port of the reference algorithm, single thread) timed on this
                  host on a bounded voxel sample, plus the max relative difference of the
                  posterior means between GPU and CPU on that sample.
+  e2e          - (N = 1) the boundary itself with PCIe and host work included - fabber_vb_run_host through host pointers and
+                 the reference's C ABI stage by stage - measured in a CHILD process without PyTorch (--e2e-child): the
+                 system's HIP runtime, as a caller of the C ABI has it. Never the headline `value`.
 """
 import argparse
 import json
@@ -296,7 +299,7 @@ def bench_boundary(w, V, holder, y, need_f, steps=3):
         os.environ.pop("FVB_HOST_BLOCK_VOXELS", None)
         best, mean = timed(lambda: hiplib.run_host(holder, y, into=res))
         out["fabber_vb_run_host_ms"] = {"min": best, "mean": mean, "voxels_per_s": V / (mean * 1e-3),
-                                        "how": "blocks of 262144 voxels: upload / fit / download overlap on three streams"}
+                                        "how": "blocks of 262144 voxels (half-size at both ends): upload, fit (two streams) and download overlap; streams and block buffers kept between calls"}
         os.environ["FVB_HOST_BLOCK_VOXELS"] = "0"
         best, mean = timed(lambda: hiplib.run_host(holder, y, into=res))
         out["fabber_vb_run_host_one_block_ms"] = {"min": best, "mean": mean}
