@@ -653,14 +653,23 @@ void Vb::DoCalculations(FabberRunData &rundata)
     // (a model evaluated on the host takes its data as NEWMAT columns: the matrix then, for the engine too)
     int series_rows = 0, series_cols = 0;
     const void *series = engine_series(rundata, !m_store->has_device_model, cfg.data_f64, series_rows, series_cols);
-    vector<int> iterations(m_nvoxels, 0), hist_len(m_nvoxels, 0);
-    m_free_energy.assign(m_nvoxels, 9999);
+    // (per-voxel arrays the engine writes in full are sized without being filled, and come from the block cache; the free
+    // energy - 9999 where the reference stores none, inference_vb.cc:165 - is asked for only when somebody reads it)
+    std::vector<int, NEWMAT::DefaultInitAllocator<int> > iterations((size_t)m_nvoxels);
+    vector<int> hist_len;
+    if (m_needF)
+        m_free_energy.assign(m_nvoxels, 9999);
+    else
+        m_free_energy.clear();
     if (cfg.f_history_rows > 0)
+    {
         m_f_history.ReSize(cfg.f_history_rows, m_nvoxels);
+        hist_len.assign(m_nvoxels, 0);
+    }
     fvb_outputs out;
     memset(&out, 0, sizeof(out));
     out.mvn = m_result_image.Store();
-    out.free_energy = m_free_energy.data();
+    out.free_energy = m_needF ? m_free_energy.data() : NULL;
     out.status = m_status.data();
     out.iterations = iterations.data();
     if (cfg.f_history_rows > 0)
