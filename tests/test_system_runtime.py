@@ -38,3 +38,13 @@ def test_c_abi_handle_after_handle_under_the_system_runtime():
     finalMVN every time, and the one the engine's own entry point gives"""
     out = child("capi", 600_000)
     assert out["identical"] == [True] * 4 and out["matches_engine"], out
+
+
+def test_the_e2e_child_of_the_bench_leaves_pytorch_alone():
+    """bench.py --e2e-child stands for a C caller: it must not import torch (the system's HIP runtime is then the one the
+    engine library loads), and without a GPU it fails loudly like every compute entry point."""
+    root = os.path.dirname(HERE)
+    code = ("import sys; sys.argv = ['bench.py', '--e2e-child']; import runpy\n"
+            "try:\n    runpy.run_path(%r, run_name='not_main')\nfinally:\n    print('TORCH', 'torch' in sys.modules)\n" % os.path.join(root, "bench.py"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "TORCH False" in p.stdout, (p.stdout[-300:], p.stderr[-800:])
