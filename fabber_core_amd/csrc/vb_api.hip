@@ -487,7 +487,14 @@ hipError_t api_pool_free(void *p, hipStream_t stream)
 hipError_t api_pool_alloc(void **p, size_t bytes, hipStream_t stream)
 {
     hipMemPool_t pool = api_pool();
-    return pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
+    const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, stream) : hipMallocAsync(p, bytes, stream);
+    if (e != hipSuccess)
+        return e;
+    // The allocation is waited for: what follows is often a copy from pageable host memory, which the runtime carries out
+    // outside the stream's order - and under ROCm 7.2's runtime such a copy into memory the pool had only just mapped
+    // arrived incomplete (tools/measure/runtime_check_release.py: wrong results from the first run after the pools had
+    // been given back). The callers allocate at the start of a run, when the stream has nothing pending.
+    return hipStreamSynchronize(stream);
 }
 void api_keep_pool_memory()
 {
@@ -546,27 +553,48 @@ void destroy_side_streams()
     (void)hipSetDevice(now);
 }
 
-// keep_bytes: what every pool may keep for the next run (0 = give everything back)
+// keep_bytes: what every pool may keep for the next run (0 = give everything back). A pool that holds more is DESTROYED
+// (the next allocation makes a new one) rather than trimmed: under ROCm 7.2's runtime the first run after
+// hipMemPoolTrimTo(pool, 0) came back with wrong results - every voxel of a one-stream, one-block call
+// (tools/measure/runtime_check_release.py; ROCm 7.0's runtime did not show it) - and a destroyed pool has no such state.
 void api_release_pools(uint64_t keep_bytes)
 {
     PoolTable &t = pool_table();
     std::lock_guard<std::mutex> hold(t.lock);
     int before = 0;
     (void)hipGetDevice(&before);
-    for (auto &e : t.pools)
+    for (size_t i = 0; i < t.pools.size();)
     {
+        auto &e = t.pools[i];
         if (hipSetDevice(e.first) != hipSuccess)
+        {
+            i++;
             continue;
+        }
         hipMemPool_t pool = e.second;
-        if (!pool && hipDeviceGetDefaultMemPool(&pool, e.first) != hipSuccess)
+        const bool own = pool != nullptr;
+        if (!own && hipDeviceGetDefaultMemPool(&pool, e.first) != hipSuccess)
+        {
+            i++;
             continue;
+        }
         // (nothing to give back: no need to wait for the device - fabber_destroy calls this when the last handle goes)
         uint64_t reserved = UINT64_MAX;
         if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &reserved) == hipSuccess && reserved <= keep_bytes)
+        {
+            i++;
             continue;
+        }
         (void)hipGetLastError();
         (void)hipDeviceSynchronize();
-        (void)hipMemPoolTrimTo(pool, (size_t)keep_bytes);
+        if (own)
+        {
+            (void)hipMemPoolDestroy(pool);
+            t.pools.erase(t.pools.begin() + (long)i); // (api_pool() creates the next one)
+            continue;
+        }
+        (void)hipMemPoolTrimTo(pool, (size_t)keep_bytes); // (the device's default pool, where no pool of our own could be made)
+        i++;
     }
     (void)hipSetDevice(before);
 }
@@ -1334,8 +1362,12 @@ int32_t fabber_vb_run_host_multi(const fvb_config *cfg, const void *data, const 
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     std::vector<std::thread> pool;
+    // (a device listed several times - a rehearsal of the N-block path on one GPU - takes its blocks one after the other:
+    // several streams on one device's stream-ordered pool are what ROCm 7.2's runtime does not keep apart)
+    std::vector<std::mutex> one_at_a_time((size_t)visible);
     for (int i = 0; i < n; i++)
         pool.emplace_back([&, i] {
+            std::lock_guard<std::mutex> turn(one_at_a_time[(size_t)devs[i]]);
             hipStream_t st = nullptr;
             if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
             {
